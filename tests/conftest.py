@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def sample_phase():
+    from oracle import oracle as o
+    return o.read_tiff_phase(os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif"))
+
+
+@pytest.fixture(scope="session")
+def goldens():
+    import json
+    with open(os.path.join(GOLDEN, "sample_goldens.json")) as f:
+        return json.load(f)
