@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxel-iters/s of the flow-through tortuosity CG on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+(one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
+Workload (BASELINE.json metric: "1024^3 two-phase, 1/2/4/8 GPUs"): a seeded 1024^3
+overlapping-sphere pack (config 3: radius 24 voxels, porosity ~0.4) generated in HBM,
+phase 1 (pore) conducting, X direction, fp64 CG.  A "step" is ONE CG iteration over the
+whole volume; the volume is z-slab decomposed over the N ranks (strong scaling: the total
+work is fixed).  Inputs, mask and matrix codes are resident in HBM before the timed
+region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+# compulsory HBM bytes per voxel of each kernel
+BYTES_PER_VOXEL = {"fused_a": 49.0, "update_r": 24.0, "apply": 17.0, "update_p": 24.0, "update_xr": 48.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=1024, help="voxels per edge")
+    ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli"])
+    ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
+    ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
+    ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
+    ap.add_argument("--solve-budget-s", type=float, default=150.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-apply-bench", action="store_true")
+    return ap.parse_args()
+
+
+def make_structure(oia, args, shape, z0, nzl):
+    if args.structure == "bernoulli":
+        return oia.gen_bernoulli_device(shape, 20251031, 0.5, z0, nzl), "Bernoulli(0.5), seed 20251031"
+    radius = 24 if shape[2] >= 512 else max(4, shape[2] // 24)
+    return (oia.gen_spheres_device(shape, 20251031, radius, 0.4, z0, nzl),
+            f"overlapping spheres r={radius}, target porosity 0.4, seed 20251031")
+
+
+def cpu_baseline(oia, args):
+    """The oracle's matrix-free CG (same algorithm, OpenMP) on a bounded sample of the same
+    structure, timed on this box's host cores.  A reported baseline, not the target."""
+    import numpy as np
+    from oracle import oracle as o
+
+    n = args.cpu_size
+    shape = (n, n, n)
+    buf, desc = make_structure(oia, args, shape, 0, n)
+    phase = buf.download(np.uint8, shape)
+    buf.free()
+    mask, nact = o.active_mask(phase, 1, 0)
+    if nact == 0:
+        return None
+    code = o.codes(mask, 0)
+    x0 = o.initial_field(mask, 0, 0.0, 1.0)
+    threads = o.lib().oi_oracle_num_threads()
+    t0 = time.time()
+    o.cg_fixed(code, x0, 5)
+    per_iter = (time.time() - t0) / 5
+    iters = int(max(10, min(2000, args.cpu_seconds / max(per_iter, 1e-6))))
+    t0 = time.time()
+    o.cg_fixed(code, x0, iters)
+    dt = time.time() - t0
+    return {"value": n ** 3 * iters / dt / 1e6, "unit": "Mvoxel-iters/s", "cores": threads, "kind": "port",
+            "sample": f"{n}^3 {desc}, X direction, {iters} CG iterations in {dt:.1f} s, "
+                      "CPU restatement (matrix-free CG, OpenMP), not Hypre FlexGMRES+SMG"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+
+    import openimpala_amd as oia
+
+    dist = None
+    torch = None
+    comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        uid = torch.zeros(oia.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(oia.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        comm = oia.Comm.create(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    n = args.size
+    shape = (n, n, n)
+    z0, z1 = oia.slab_range(n, world, rank)
+    nzl = z1 - z0
+    t_gen = time.time()
+    buf, desc = make_structure(oia, args, shape, z0, nzl)
+    t_gen = time.time() - t_gen
+    kernel = oia.KERNEL_FUSED if args.kernel == "fused" else oia.KERNEL_UNFUSED
+    precond = oia.PRECOND_JACOBI if args.precond == "jacobi" else oia.PRECOND_NONE
+    t_create = time.time()
+    # eps = 1e-300 during the timed region: every one of the K steps does full work
+    kw = dict(eps=1e-300, kernel=kernel, precond=precond, profile=1, maxiter=200000, device=local_rank)
+    if comm is not None:
+        t = oia.TortuosityMI355(buf, 1, oia.Direction.X, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=n,
+                                **kw)
+    else:
+        t = oia.TortuosityMI355(buf, 1, oia.Direction.X, 0.0, 1.0, shape=shape, **kw)
+    t_create = time.time() - t_create
+    buf.free()
+    st = t.stats()
+    if st.active_vf <= 0:
+        raise RuntimeError("synthetic structure does not percolate")
+
+    # ---- stand-alone stencil apply (the kernel the 70 %-of-roofline target names) ----
+    apply_info = None
+    if not args.no_apply_bench:
+        ms = t.bench_apply(20, oia.KERNEL_FUSED)
+        vox_local = n * n * nzl
+        gbs = BYTES_PER_VOXEL["apply"] * vox_local / ms / 1e6
+        apply_info = {"kernel": "fused_a<PURE> (q = A p, 17 B/voxel)", "ms_per_launch": ms, "achieved": gbs,
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                      "gvoxel_per_s": vox_local / ms / 1e6}
+
+    # ---- timed region: K CG iterations ----
+    t.cg_begin()
+    t.cg_iterate(args.warmup)
+    t.sync()
+    t.reset_kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    t.cg_iterate(args.steps)
+    t.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = t.kernel_times()
+    it_done, relres, conv = t.cg_state()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    steps_done = min(args.steps, max(0, it_done - args.warmup)) if conv else args.steps
+    value = n ** 3 * args.steps / dt / 1e6
+
+    # dominant kernel of the timed region, from the HIP events on the solver's stream
+    main_k = max((k for k in ktimes if k in BYTES_PER_VOXEL), key=lambda k: ktimes[k][0])
+    ms_launch = ktimes[main_k][0] / max(1, ktimes[main_k][1])
+    achieved = BYTES_PER_VOXEL[main_k] * (n * n * nzl) / ms_launch / 1e6
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_file):
+        try:
+            pmc = json.load(open(pmc_file))
+            ent = pmc.get(f"{main_k}:{n}:{world}")
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": main_k, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": BYTES_PER_VOXEL[main_k] * n * n * nzl,
+                "ms_per_launch": ms_launch,
+                "bytes_per_voxel_iter": sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL),
+                "iteration_GBps": sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL) * n * n * nzl
+                / (dt / args.steps) / 1e9}
+    t.cg_finish()
+
+    # ---- wall time to relative residual 1e-6 (second half of the BASELINE metric) ----
+    solve = None
+    if not args.no_solve:
+        t.reset_kernel_times()
+        barrier()
+        t.set_eps(1e-6)
+        s0 = time.perf_counter()
+        t.cg_begin()
+        done, its, rel = False, 0, float("nan")
+        while not done and time.perf_counter() - s0 < args.solve_budget_s:
+            t.cg_iterate(250)
+            its, rel, done = t.cg_state()
+            if dist is not None:  # every rank must take the same decision
+                flag = torch.tensor([1 if (done or time.perf_counter() - s0 >= args.solve_budget_s) else 0],
+                                    device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() and not done:
+                    break
+        t.cg_finish()
+        barrier()
+        s1 = time.perf_counter() - s0
+        solve = {"eps": 1e-6, "converged": bool(done), "iterations": its, "relres": rel, "seconds": s1,
+                 "mvoxel_iters_per_s": n ** 3 * its / s1 / 1e6 if s1 > 0 else None}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(oia, args)
+
+    if rank == 0:
+        out = {
+            "metric": "Mvoxel-iters/sec", "value": value, "unit": "Mvoxel-iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n}^3 two-phase {desc}; phase 1, X direction; matrix-free CG "
+                                   f"({args.kernel}, precond {args.precond}); z-slabs over {world} GPU(s)",
+                       "voxels": n ** 3, "active_vf": st.active_vf, "volume_fraction": st.vf,
+                       "unknowns": st.n_free, "parallelism": f"z-slab x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "apply_roofline": apply_info,
+            "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in ktimes.items()},
+            "steps_effective": steps_done, "relres_after_timed_region": relres,
+            "time_to_1e-6": solve,
+            "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
+                        "flood_sweeps": st.flood_sweeps},
+            "device_bytes": st.bytes_device,
+        }
+        print(json.dumps(out), flush=True)
+    t.destroy()
+    if comm is not None:
+        comm.destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

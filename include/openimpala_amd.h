@@ -1,0 +1,218 @@
+/*
+ * openimpala_amd.h -- C ABI of the MI355X-native flow-through tortuosity solver.
+ *
+ * Drop-in boundary for ONE path of kramergroup/openImpala: the `src/props`
+ * TortuosityHypre solve (percolation mask -> masked 7-point Laplacian ->
+ * Krylov solve -> boundary fluxes -> tau).  Each entry point names the reference
+ * interface it replaces (paths relative to the reference tree).  Plain pointers and
+ * sizes only; no AMReX, HYPRE or torch types cross this boundary.
+ *
+ * Data convention (identical to the reference's Fortran-ordered boxes and to the
+ * TIFF/RAW/HDF5 payload order): voxel (i,j,k) = (X,Y,Z) lives at
+ * phase[i + nx*(j + ny*k)]; X = TIFF width (unit stride), Z = TIFF page (slowest).
+ * Direction codes follow OpenImpala::Direction (src/props/Tortuosity.H:9-13):
+ * X = 0, Y = 1, Z = 2.
+ *
+ * Threading: a handle is not thread-safe (as the reference class); distinct handles
+ * may be driven from distinct host threads.  The library never aborts the process:
+ * hard failures come back as oi_status, soft failures additionally as NaN / +Inf in
+ * *tau exactly as TortuosityHypre::value() would return them.
+ */
+#ifndef OPENIMPALA_AMD_H
+#define OPENIMPALA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OI_ABI_VERSION 1
+
+typedef enum oi_status {
+  OI_OK = 0,
+  OI_BAD_ARG = 1,
+  OI_NO_PERCOLATION = 2,     /* active volume fraction 0: tau = NaN  (TortuosityHypre.cpp:170-178,764-777) */
+  OI_NOT_CONVERGED = 3,      /* tau = NaN                            (TortuosityHypre.cpp:782-787) */
+  OI_FLUX_NOT_CONSERVED = 4, /* |in|-|out| > 1e-6 relative: tau = NaN (TortuosityHypre.cpp:794-823) */
+  OI_HIP_ERROR = 5,
+  OI_RCCL_ERROR = 6,
+  OI_NO_DEVICE = 7,          /* no HIP device / extension unusable: never a silent CPU fallback */
+  OI_IO_ERROR = 8
+} oi_status;
+
+typedef struct oi_tort oi_tort; /* replaces an OpenImpala::TortuosityHypre object */
+typedef struct oi_comm oi_comm; /* replaces MPI_COMM_WORLD / amrex::ParallelDescriptor for this path */
+
+enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1 };
+enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2 };
+
+/* Options.  `eps` / `maxiter` are the reference's hypre.eps / hypre.maxiter
+ * (TortuosityHypre.cpp:142-149: 1e-9 / 200).  The reference's 200 counts
+ * multigrid-preconditioned FlexGMRES iterations; CG needs O(10 N) iterations, so
+ * maxiter <= 0 selects 40*(nx+ny+nz). */
+typedef struct oi_tort_opts {
+  double eps;
+  int maxiter;
+  int precond;        /* OI_PRECOND_* */
+  int remspot_passes; /* tortuosity.remspot_passes (TortuosityHypre.cpp:254-256), default 0 */
+  int verbose;        /* 0 silent .. 3 */
+  int check_every;    /* host looks at the device convergence flag every this many iterations (<=0: auto) */
+  int kernel;         /* OI_KERNEL_* */
+  int profile;        /* 1: bracket every kernel launch with HIP events (oi_tort_kernel_times) */
+  int device;         /* HIP device ordinal; -1 = the calling thread's current device */
+} oi_tort_opts;
+
+void oi_tort_default_opts(oi_tort_opts* opts);
+
+/* What TortuosityHypre exposes through its getters (TortuosityHypre.H:114-120)
+ * plus timings of the phases the reference wraps in BL_PROFILE. */
+typedef struct oi_tort_stats {
+  int converged;          /* getSolverConverged() */
+  int iterations;         /* getSolverIterations() */
+  double final_relres;    /* getFinalRelativeResidualNorm(): ||b - A x|| / ||b|| of the full system */
+  double flux_in;         /* getFluxIn() */
+  double flux_out;        /* getFluxOut() */
+  double active_vf;       /* getActiveVolumeFraction() */
+  double vf;              /* VolumeFraction::value for phase_id over the whole domain */
+  double deff;            /* D_eff / D_0 (TortuosityHypre.cpp:868) */
+  double tau;             /* cached value() */
+  int64_t n_active;       /* voxels in the percolating mask (global) */
+  int64_t n_free;         /* unknowns: active voxels not on a Dirichlet face (global) */
+  int64_t n_phase;        /* voxels with phase == phase_id (global) */
+  int flood_sweeps;       /* device sweeps the percolation flood fill took */
+  double t_upload_s, t_mask_s, t_setup_s, t_solve_s, t_flux_s;
+  double bytes_device;    /* device memory held by the handle */
+} oi_tort_stats;
+
+/* ---- construction: TortuosityHypre::TortuosityHypre (TortuosityHypre.cpp:100-191) ----
+ * Copies `phase` (host memory, nx*ny*nz bytes; the caller may free it at once, like the
+ * reference's deep copy at :132), optionally runs the remspot filter, builds the
+ * percolation mask on the device and prepares the linear system.  vf of the reference
+ * signature is recomputed on the device (VolumeFraction.cpp:22-66). */
+oi_status oi_tort_create(oi_tort** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
+                         int dir, double vlo, double vhi, const oi_tort_opts* opts);
+
+/* Same, `phase_dev` already resident in HBM (device pointer, same layout). */
+oi_status oi_tort_create_device(oi_tort** out, const uint8_t* phase_dev, int nx, int ny, int nz,
+                                int phase_id, int dir, double vlo, double vhi,
+                                const oi_tort_opts* opts);
+
+/* One z-slab of a volume decomposed over `comm` (replaces the BoxArray +
+ * DistributionMapping + FillBoundary machinery, Diffusion.cpp:266-268).  This rank
+ * owns global planes [z0, z0 + nz_local); `phase` holds only those planes.
+ * `on_device` != 0: `phase` is a device pointer.  Collective over comm. */
+oi_status oi_tort_create_slab(oi_tort** out, oi_comm* comm, const uint8_t* phase, int on_device,
+                              int nx, int ny, int nz_global, int z0, int nz_local, int phase_id,
+                              int dir, double vlo, double vhi, const oi_tort_opts* opts);
+
+/* TortuosityHypre::~TortuosityHypre (TortuosityHypre.cpp:195-203) */
+void oi_tort_destroy(oi_tort* h);
+
+/* Tortuosity::value(refresh) (Tortuosity.H:47-69, TortuosityHypre.cpp:761-891).
+ * Solves on first call or when refresh != 0; *tau is NaN / +Inf exactly where the
+ * reference returns them.  Collective over the handle's comm. */
+oi_status oi_tort_value(oi_tort* h, int refresh, double* tau);
+
+/* TortuosityHypre::checkMatrixProperties (TortuosityHypre.cpp:896-982) evaluated on the
+ * matrix-free operator's coefficients: *n_violations = 0 means pass. */
+oi_status oi_tort_check_matrix_properties(oi_tort* h, int64_t* n_violations);
+
+/* getters (TortuosityHypre.H:114-120) */
+oi_status oi_tort_get_stats(const oi_tort* h, oi_tort_stats* stats);
+
+/* The potential field (what the reference writes as plotfile component
+ * "solution_potential", TortuosityHypre.cpp:710-749): nx*ny*nz_local doubles. */
+oi_status oi_tort_get_solution(oi_tort* h, double* phi);
+/* "active_mask" plotfile component: nx*ny*nz_local bytes (0/1). */
+oi_status oi_tort_get_mask(oi_tort* h, uint8_t* mask);
+
+/* VolumeFraction::value (VolumeFraction.cpp:22-66) on a host array, computed on the device. */
+oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phase_id, int64_t* phase_count,
+                             int64_t* total_count);
+
+/* tortuosity_remspot (Tortuosity_filcc.F90:88-177), one whole-domain pass per `passes`,
+ * in place on a host array (host-side: the filter is sequential by definition). */
+oi_status oi_remspot(uint8_t* phase, int nx, int ny, int nz, int passes);
+
+/* change hypre.eps of an existing handle (takes effect at the next solve / cg_begin) */
+oi_status oi_tort_set_eps(oi_tort* h, double eps);
+
+/* ---- stepping interface (bench / tests): the pieces of solve() individually ---- */
+oi_status oi_tort_cg_begin(oi_tort* h);              /* x0 = ramp, r0, p0; resets the iteration count */
+oi_status oi_tort_cg_iterate(oi_tort* h, int n);     /* enqueue n CG iterations (asynchronous) */
+oi_status oi_tort_cg_finish(oi_tort* h);             /* flush the deferred x update, synchronise */
+oi_status oi_tort_sync(oi_tort* h);
+oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int* converged);
+/* element-wise checks of single kernels against the oracle: v, q are host arrays of
+ * nx*ny*nz_local doubles; variant = OI_KERNEL_UNFUSED | OI_KERNEL_FUSED */
+oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q, int variant);
+oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
+/* run the stand-alone stencil apply `reps` times on device-resident vectors and
+ * return the HIP-event time of the launches (ms per launch) */
+oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_launch);
+
+/* process-wide tuning of the fused CG kernel: rows per LDS tile (4 or 8) and planes per
+ * block (0 = automatic).  Affects launches made after the call. */
+void oi_tort_set_tuning(int fused_tile_rows, int fused_planes_per_block);
+
+/* per-kernel HIP-event timings gathered while opts.profile = 1.  names: fixed list,
+ * see oi_kernel_name().  Returns the number of kernels written (<= cap). */
+int oi_tort_kernel_times(oi_tort* h, int cap, int* kernel_ids, double* total_ms, int64_t* launches);
+const char* oi_kernel_name(int kernel_id);
+void oi_tort_reset_kernel_times(oi_tort* h);
+
+/* ---- communicator: one process per GPU, RCCL over xGMI ----
+ * Bootstrap as with MPI_Init in the reference (Diffusion.cpp:173-174) but host-agnostic:
+ * rank 0 obtains 128 opaque bytes, the host moves them to every rank by any channel
+ * (torch.distributed, MPI, a file), every rank calls oi_comm_create. */
+#define OI_COMM_ID_BYTES 128
+oi_status oi_comm_unique_id(void* id_out);
+oi_status oi_comm_create(oi_comm** out, const void* id, int nranks, int rank, int device);
+/* `nranks` linked in-process communicators that run as `nranks` host threads on ONE
+ * device (device-to-device copies instead of RCCL): exercises every slab code path
+ * on a single-GPU box. */
+oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device);
+void oi_comm_destroy(oi_comm* c);
+int oi_comm_rank(const oi_comm* c);
+int oi_comm_size(const oi_comm* c);
+
+/* ---- seeded synthetic microstructures, generated in HBM (BASELINE.json configs) ----
+ * phase_dev: device pointer to nx*ny*nz_local bytes holding global planes
+ * [z0, z0+nz_local).  Bit-identical to the oracle's generators. */
+oi_status oi_gen_bernoulli_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
+                                  int nz_local, uint64_t seed, uint64_t thr53);
+oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
+                                int nz_local, uint64_t seed, int nspheres, int radius_half_voxels);
+
+/* ---- device memory helpers for hosts without a GPU array library ---- */
+oi_status oi_dev_malloc(void** ptr, size_t bytes);
+oi_status oi_dev_free(void* ptr);
+oi_status oi_dev_upload(void* dst_dev, const void* src_host, size_t bytes);
+oi_status oi_dev_download(void* dst_host, const void* src_dev, size_t bytes);
+int oi_device_count(void);
+const char* oi_last_error(void); /* thread-local text of the last failure */
+const char* oi_status_string(oi_status s);
+int oi_abi_version(void);
+
+/* ---- readers (src/io): file -> thresholded 0/1 phase bytes, voxel > thr -> 1 ----
+ * oi_read_*: *phase is malloc'ed by the library (release with oi_free_host).
+ * TiffReader::threshold (TiffReader.cpp:289-444,449-455), RawReader::threshold
+ * (RawReader.cpp:379-491), HDF5Reader::threshold (HDF5Reader.cpp:333-402). */
+oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
+                       int* bits_per_sample);
+/* dtype: OI_RAW_* below, same numbering as the reference's RawDataType (RawReader.H:30-46) */
+enum {
+  OI_RAW_UNKNOWN = 0, OI_RAW_UINT8 = 1, OI_RAW_INT8, OI_RAW_INT16_LE, OI_RAW_INT16_BE, OI_RAW_UINT16_LE, OI_RAW_UINT16_BE,
+  OI_RAW_INT32_LE, OI_RAW_INT32_BE, OI_RAW_UINT32_LE, OI_RAW_UINT32_BE, OI_RAW_FLOAT32_LE,
+  OI_RAW_FLOAT32_BE, OI_RAW_FLOAT64_LE, OI_RAW_FLOAT64_BE
+};
+oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
+                      uint8_t** phase);
+void oi_free_host(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENIMPALA_AMD_H */

@@ -1,0 +1,280 @@
+// oi_comm.cpp -- RCCL (one process per GPU) and in-process (host threads on one GPU)
+// transports behind oi_comm.  See oi_comm.h.
+#include "oi_comm.h"
+
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "oi_device.h"
+
+namespace oi {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+}  // namespace oi
+
+#define HIPC(call)                                                                       \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return OI_HIP_ERROR;                                                               \
+    }                                                                                    \
+  } while (0)
+#define NCCLC(call)                                                                      \
+  do {                                                                                   \
+    ncclResult_t r_ = (call);                                                            \
+    if (r_ != ncclSuccess) {                                                             \
+      oi::set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+      return OI_RCCL_ERROR;                                                              \
+    }                                                                                    \
+  } while (0)
+
+// --------------------------------------------------------------------------------------
+// RCCL transport: one rank = one process = one GPU.  Both neighbour messages of an
+// exchange go into ONE group so the two xGMI links are driven concurrently.
+// --------------------------------------------------------------------------------------
+struct RcclComm : oi_comm {
+  ncclComm_t nccl = nullptr;
+  void* scratch = nullptr;  // 64 bytes of device memory for the host-value collectives
+  ~RcclComm() override {
+    if (scratch) (void)hipFree(scratch);
+    if (nccl) ncclCommDestroy(nccl);
+  }
+  oi_status exchange(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,
+                     hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    NCCLC(ncclGroupStart());
+    if (rank > 0) {
+      NCCLC(ncclSend(send_lo, bytes, ncclInt8, rank - 1, nccl, s));
+      NCCLC(ncclRecv(recv_lo, bytes, ncclInt8, rank - 1, nccl, s));
+    }
+    if (rank < size - 1) {
+      NCCLC(ncclSend(send_hi, bytes, ncclInt8, rank + 1, nccl, s));
+      NCCLC(ncclRecv(recv_hi, bytes, ncclInt8, rank + 1, nccl, s));
+    }
+    NCCLC(ncclGroupEnd());
+    return OI_OK;
+  }
+  oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    NCCLC(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, nccl, s));
+    return OI_OK;
+  }
+  oi_status allreduce_sum_u64_host(unsigned long long* vals, int n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    if (n > 8) return OI_BAD_ARG;
+    HIPC(hipMemcpyAsync(scratch, vals, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, s));
+    NCCLC(ncclAllReduce(scratch, scratch, n, ncclUint64, ncclSum, nccl, s));
+    HIPC(hipMemcpyAsync(vals, scratch, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return OI_OK;
+  }
+  oi_status allreduce_max_i32_host(int* vals, int n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    if (n > 16) return OI_BAD_ARG;
+    HIPC(hipMemcpyAsync(scratch, vals, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    NCCLC(ncclAllReduce(scratch, scratch, n, ncclInt32, ncclMax, nccl, s));
+    HIPC(hipMemcpyAsync(vals, scratch, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return OI_OK;
+  }
+};
+
+// --------------------------------------------------------------------------------------
+// In-process transport: `size` host threads, each driving one slab on the SAME device.
+// Messages are device-to-device copies ordered with HIP events; threads rendezvous on a
+// reusable barrier.  It exists so every slab code path (ghost planes, split reductions,
+// flood-fill rounds) runs on a single-GPU box; it is not a performance path.
+// --------------------------------------------------------------------------------------
+namespace {
+struct LocalShared {
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  unsigned long long generation = 0;
+  std::vector<const void*> send_lo, send_hi;
+  std::vector<hipEvent_t> ev_ready, ev_done;
+  std::vector<double*> stage;          // per-rank device staging for the f64 all-reduce
+  const double** stage_ptrs_dev = nullptr;  // device array of the n staging pointers
+  std::vector<unsigned long long> hu64;
+  std::vector<int> hi32;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const unsigned long long gen = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+  ~LocalShared() {
+    for (auto e : ev_ready) (void)hipEventDestroy(e);
+    for (auto e : ev_done) (void)hipEventDestroy(e);
+    for (auto p : stage) (void)hipFree(p);
+    if (stage_ptrs_dev) (void)hipFree((void*)stage_ptrs_dev);
+  }
+};
+constexpr int kStageDoubles = 16;
+}  // namespace
+
+struct LocalComm : oi_comm {
+  std::shared_ptr<LocalShared> sh;
+  oi_status exchange(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,
+                     hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    sh->send_lo[rank] = send_lo;
+    sh->send_hi[rank] = send_hi;
+    HIPC(hipEventRecord(sh->ev_ready[rank], s));
+    sh->barrier();
+    if (rank > 0) {
+      HIPC(hipStreamWaitEvent(s, sh->ev_ready[rank - 1], 0));
+      HIPC(hipMemcpyAsync(recv_lo, sh->send_hi[rank - 1], bytes, hipMemcpyDeviceToDevice, s));
+    }
+    if (rank < size - 1) {
+      HIPC(hipStreamWaitEvent(s, sh->ev_ready[rank + 1], 0));
+      HIPC(hipMemcpyAsync(recv_hi, sh->send_lo[rank + 1], bytes, hipMemcpyDeviceToDevice, s));
+    }
+    HIPC(hipEventRecord(sh->ev_done[rank], s));
+    sh->barrier();
+    // nobody may overwrite a send plane before its neighbours have copied it
+    if (rank > 0) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank - 1], 0));
+    if (rank < size - 1) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank + 1], 0));
+    sh->barrier();  // events are re-recorded by the next collective only after everyone has waited
+    return OI_OK;
+  }
+  oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    if (n > kStageDoubles) return OI_BAD_ARG;
+    HIPC(hipMemcpyAsync(sh->stage[rank], dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    HIPC(hipEventRecord(sh->ev_ready[rank], s));
+    sh->barrier();
+    for (int r = 0; r < size; ++r)
+      if (r != rank) HIPC(hipStreamWaitEvent(s, sh->ev_ready[r], 0));
+    oi::launch_sum_scalars(dev, sh->stage_ptrs_dev, size, n, s);  // fixed order: identical on all ranks
+    HIPC(hipEventRecord(sh->ev_done[rank], s));
+    sh->barrier();
+    for (int r = 0; r < size; ++r)
+      if (r != rank) HIPC(hipStreamWaitEvent(s, sh->ev_done[r], 0));
+    sh->barrier();
+    return OI_OK;
+  }
+  oi_status allreduce_sum_u64_host(unsigned long long* vals, int n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    if (n > 8) return OI_BAD_ARG;
+    HIPC(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) sh->hu64[rank * 8 + i] = vals[i];
+    sh->barrier();
+    for (int i = 0; i < n; ++i) {
+      unsigned long long t = 0;
+      for (int r = 0; r < size; ++r) t += sh->hu64[r * 8 + i];
+      vals[i] = t;
+    }
+    sh->barrier();
+    return OI_OK;
+  }
+  oi_status allreduce_max_i32_host(int* vals, int n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    if (n > 16) return OI_BAD_ARG;
+    HIPC(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) sh->hi32[rank * 16 + i] = vals[i];
+    sh->barrier();
+    for (int i = 0; i < n; ++i) {
+      int t = sh->hi32[i];
+      for (int r = 1; r < size; ++r) t = sh->hi32[r * 16 + i] > t ? sh->hi32[r * 16 + i] : t;
+      vals[i] = t;
+    }
+    sh->barrier();
+    return OI_OK;
+  }
+};
+
+extern "C" {
+
+oi_status oi_comm_unique_id(void* id_out) {
+  static_assert(OI_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  if (!id_out) return OI_BAD_ARG;
+  ncclUniqueId id;
+  NCCLC(ncclGetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return OI_OK;
+}
+
+oi_status oi_comm_create(oi_comm** out, const void* id, int nranks, int rank, int device) {
+  if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return OI_BAD_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    oi::set_error("no HIP device");
+    return OI_NO_DEVICE;
+  }
+  if (device >= 0) HIPC(hipSetDevice(device));
+  HIPC(hipGetDevice(&device));
+  auto c = std::make_unique<RcclComm>();
+  c->rank = rank;
+  c->size = nranks;
+  c->device = device;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  NCCLC(ncclCommInitRank(&c->nccl, nranks, uid, rank));
+  HIPC(hipMalloc(&c->scratch, 128));
+  *out = c.release();
+  return OI_OK;
+}
+
+oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device) {
+  if (!out_array || nranks < 1 || nranks > 64) return OI_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    oi::set_error("no HIP device");
+    return OI_NO_DEVICE;
+  }
+  if (device >= 0) HIPC(hipSetDevice(device));
+  HIPC(hipGetDevice(&device));
+  auto sh = std::make_shared<LocalShared>();
+  sh->n = nranks;
+  sh->send_lo.assign(nranks, nullptr);
+  sh->send_hi.assign(nranks, nullptr);
+  sh->hu64.assign(nranks * 8, 0);
+  sh->hi32.assign(nranks * 16, 0);
+  sh->ev_ready.resize(nranks);
+  sh->ev_done.resize(nranks);
+  sh->stage.resize(nranks);
+  for (int r = 0; r < nranks; ++r) {
+    HIPC(hipEventCreateWithFlags(&sh->ev_ready[r], hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&sh->ev_done[r], hipEventDisableTiming));
+    HIPC(hipMalloc((void**)&sh->stage[r], sizeof(double) * kStageDoubles));
+  }
+  HIPC(hipMalloc((void**)&sh->stage_ptrs_dev, sizeof(double*) * nranks));
+  HIPC(hipMemcpy((void*)sh->stage_ptrs_dev, sh->stage.data(), sizeof(double*) * nranks, hipMemcpyHostToDevice));
+  for (int r = 0; r < nranks; ++r) {
+    auto* c = new LocalComm();
+    c->rank = r;
+    c->size = nranks;
+    c->device = device;
+    c->sh = sh;
+    out_array[r] = c;
+  }
+  return OI_OK;
+}
+
+void oi_comm_destroy(oi_comm* c) { delete c; }
+int oi_comm_rank(const oi_comm* c) { return c ? c->rank : 0; }
+int oi_comm_size(const oi_comm* c) { return c ? c->size : 1; }
+
+}  // extern "C"

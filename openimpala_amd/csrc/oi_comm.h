@@ -1,0 +1,31 @@
+// oi_comm.h -- slab-neighbour transport of the tortuosity path.
+//
+// The reference moves ghost cells with amrex::FillBoundary and reduces scalars with
+// amrex::ParallelDescriptor / HYPRE-internal MPI (call sites: SURVEY.md 2.2).  Here a
+// rank is one process owning one MI355X; z-slabs form an open chain, so the only
+// messages are one contiguous ghost plane to each z-neighbour (RCCL point-to-point
+// over xGMI) and a few scalars (RCCL all-reduce).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/openimpala_amd.h"
+
+struct oi_comm {
+  int rank = 0, size = 1, device = 0;
+  virtual ~oi_comm() {}
+  // Sends `send_lo` to rank-1 (lands in its recv_hi) and `send_hi` to rank+1 (lands in its
+  // recv_lo); chain ends skip the missing neighbour.  Asynchronous on `s`.
+  virtual oi_status exchange(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
+                             size_t bytes, hipStream_t s) = 0;
+  // in-place sum of n doubles resident on the device, asynchronous on `s`
+  virtual oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) = 0;
+  // host-value collectives for the (rare) setup steps; they synchronise `s`
+  virtual oi_status allreduce_sum_u64_host(unsigned long long* vals, int n, hipStream_t s) = 0;
+  virtual oi_status allreduce_max_i32_host(int* vals, int n, hipStream_t s) = 0;
+};
+
+namespace oi {
+void set_error(const char* fmt, ...);
+}

@@ -1,0 +1,105 @@
+// oi_device.h -- device-side layout and kernel launchers shared by the host driver.
+//
+// HBM layout of one z-slab (global planes [z0, z0+nzl)) -- see DESIGN.md section 3:
+//   * fp64 vectors x, r, q, p0, p1: (nzl+2) planes of ny rows of `pitch` doubles
+//     (pitch = nx rounded up to even so every row is 16-byte aligned); plane 0 and
+//     plane nzl+1 are ghost planes (zeros at a domain face, the neighbour slab's
+//     boundary plane otherwise), so z-neighbours never need a bounds test.
+//   * code bytes (same shape, 1 B/voxel): number of active 6-neighbours of a FREE
+//     voxel, 0 for every other voxel -- the whole matrix.
+//   * bit planes (open / reach_lo / reach_hi -> active): 64 voxels per uint64 word
+//     along x, W = ceil(nx/64) words per row, same ghost-plane convention.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oi {
+
+struct Geom {
+  int nx, ny, nz;      // global voxel counts
+  int z0, nzl;         // this slab: global planes [z0, z0+nzl)
+  int dir;             // flow axis 0/1/2
+  int pitch;           // doubles (and code bytes) per row
+  int W;               // uint64 words per row of a bit plane
+  long long plane;     // pitch * ny      elements per plane
+  long long wplane;    // W * ny          words per bit plane
+  long long nvec;      // (nzl+2) * plane elements per vector incl. ghost planes
+  long long nwords;    // (nzl+2) * wplane
+  double vlo, vhi;
+};
+
+// slots of the device-resident CG history: hist[3*k + {0,1,2}] = {p.q, r.r, r.z} of iteration k
+enum { H_PQ = 0, H_RR = 1, H_RZ = 2, H_STRIDE = 3 };
+
+struct Ctrl {
+  int done;        // 0 while iterating; else the number of iterations after which ||r|| <= tol
+  int pad;
+  double tol2;     // (eps * ||b||)^2
+};
+
+enum KernelId {
+  K_PACK = 0, K_SEED, K_FLOOD, K_MASK, K_CODES, K_INIT, K_RESID0, K_APPLY, K_UPDATE_P, K_UPDATE_XR,
+  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_COUNT
+};
+
+// maximum number of per-block partial sums any reducing kernel writes
+constexpr int kMaxPartials = 4096;
+
+// ---- launchers (all asynchronous on `s`) ----
+void launch_pack_open(const uint8_t* phase /*nzl planes, no ghosts, row pitch nx*/, const Geom& g,
+                      int phase_id, uint64_t* open, unsigned long long* n_phase, hipStream_t s);
+void launch_seed(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, hipStream_t s);
+void launch_flood_sweep(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, int* changed,
+                        hipStream_t s);
+void launch_mask_and(const Geom& g, uint64_t* rlo_to_active, const uint64_t* rhi,
+                     unsigned long long* counts /*[0]=active,[1]=lo face,[2]=hi face*/, hipStream_t s);
+void launch_codes(const Geom& g, const uint64_t* active, uint8_t* code, unsigned long long* n_free,
+                  hipStream_t s);
+void launch_init_field(const Geom& g, const uint64_t* active, double* x, hipStream_t s);
+void launch_unpack_mask(const Geom& g, const uint64_t* active, uint8_t* mask_out /*nzl planes, pitch nx*/,
+                        hipStream_t s);
+
+// r = -A x on free cells, p = z (z = r or r/code), partials {rr, rz}
+int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double* r, double* p, int jacobi,
+                     double* partials, hipStream_t s);
+// q = A v, partials {v.q}; returns number of partial blocks
+int launch_apply(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
+                 const Ctrl* ctrl, hipStream_t s);
+// p = z + beta p with beta = rz_k / rz_{k-1} read from hist
+void launch_update_p(const Geom& g, const uint8_t* code, const double* r, double* p, int jacobi,
+                     const double* hist, int k, const Ctrl* ctrl, hipStream_t s);
+// x += alpha p; r -= alpha q; partials {rr, rz};  alpha = rz_k / pq_k
+int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, const double* p, const double* q,
+                     int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);
+// fused: x += alpha_{k-1} p_in ; p_out = z + beta_k p_in ; q = A p_out ; partials {p_out.q}
+int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const double* p_in,
+                   double* p_out, double* q, int jacobi, const double* hist, int k, double* partials,
+                   const Ctrl* ctrl, hipStream_t s);
+// stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
+int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
+                       const Ctrl* ctrl, hipStream_t s);
+void set_fused_tuning(int by, int zchunk);
+// r -= alpha q; partials {rr, rz}
+int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi,
+                    const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);
+// x += alpha_k p  (deferred update flush of the fused variant)
+void launch_axpy_hist(const Geom& g, double* x, const double* p, const double* hist, int k, hipStream_t s);
+// dst[slot..slot+ncomp) = sum of partials (deterministic order); optional convergence test on
+// dst[check_rr_index]: sets ctrl->done = iter_done when <= tol2
+void launch_finalize(const double* partials, int nblocks, int ncomp, double* dst, Ctrl* ctrl, int check,
+                     int iter_done, hipStream_t s);
+void launch_check_done(const double* rr, Ctrl* ctrl, int iter_done, hipStream_t s);
+// boundary fluxes: out[0] = flux_in sum, out[1] = flux_out sum (local part)
+void launch_flux(const Geom& g, const uint64_t* active, const double* x, double* partials, double* out2,
+                 hipStream_t s);
+void launch_gen_bernoulli(uint8_t* phase, int nx, int ny, int nz, int z0, int nzl, uint64_t seed,
+                          uint64_t thr53, hipStream_t s);
+void launch_gen_spheres(uint8_t* phase, int nx, int ny, int nz, int z0, int nzl, const int* centres_dev,
+                        const int* cell_start_dev, int ncx, int ncy, int ncz, int cell, int r2h, hipStream_t s);
+void launch_sum_scalars(double* dst, const double* const* srcs, int nsrc, int n, hipStream_t s);
+// dense host-order (nx per row, nzl planes) <-> pitched/ghosted device vector
+void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipStream_t s);
+void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipStream_t s);
+void launch_codes_out(const Geom& g, const uint8_t* code, uint8_t* dense, hipStream_t s);
+
+}  // namespace oi

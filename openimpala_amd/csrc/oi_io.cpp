@@ -1,0 +1,320 @@
+// oi_io.cpp -- host-side image readers of the Diffusion inputs-file interface:
+// file -> thresholded 0/1 phase bytes in file order (x fastest, page/plane slowest).
+//
+// Restates the behaviour of the reference readers without libtiff:
+//   TiffReader  (src/io/TiffReader.cpp:139-202 metadata, :289-444 decode): multi-directory
+//               stacks, strips or tiles, 1/8/16/32/64 bits per sample, UINT/INT/IEEEFP,
+//               1 sample per pixel, contiguous planar config; 1-bit data honours FILLORDER
+//               and ignores PHOTOMETRIC; voxel > threshold -> 1 else 0.
+//               Supported encodings here: uncompressed and PackBits (classic TIFF, both
+//               byte orders); anything else is reported, never guessed.
+//   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/openimpala_amd.h"
+
+namespace oi {
+void set_error(const char* fmt, ...);
+}
+
+namespace {
+
+struct File {
+  std::vector<uint8_t> d;
+  bool le = true;
+  uint16_t u16(size_t o) const { return le ? (uint16_t)(d[o] | d[o + 1] << 8) : (uint16_t)(d[o] << 8 | d[o + 1]); }
+  uint32_t u32(size_t o) const {
+    return le ? (uint32_t)d[o] | (uint32_t)d[o + 1] << 8 | (uint32_t)d[o + 2] << 16 | (uint32_t)d[o + 3] << 24
+              : (uint32_t)d[o] << 24 | (uint32_t)d[o + 1] << 16 | (uint32_t)d[o + 2] << 8 | (uint32_t)d[o + 3];
+  }
+};
+
+bool slurp(const char* path, std::vector<uint8_t>& out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (n < 0) { fclose(f); return false; }
+  out.resize((size_t)n);
+  const size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == (size_t)n;
+}
+
+struct Ifd {
+  uint32_t w = 0, h = 0, bps = 1, comp = 1, spp = 1, rps = 0, fmt = 1, fill = 1, planar = 1;
+  uint32_t tile_w = 0, tile_h = 0;
+  std::vector<uint64_t> offs, counts;
+  bool tiled = false;
+};
+
+size_t type_size(uint16_t t) {
+  switch (t) {
+    case 1: case 2: case 6: case 7: return 1;
+    case 3: case 8: return 2;
+    case 4: case 9: case 11: return 4;
+    case 5: case 10: case 12: return 8;
+    default: return 0;
+  }
+}
+
+bool read_values(const File& f, size_t entry, std::vector<uint64_t>& out) {
+  const uint16_t type = f.u16(entry + 2);
+  const uint32_t count = f.u32(entry + 4);
+  const size_t ts = type_size(type);
+  if (ts == 0) return false;
+  size_t pos = entry + 8;
+  if (ts * count > 4) pos = f.u32(entry + 8);
+  if (pos + ts * count > f.d.size()) return false;
+  out.resize(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    if (ts == 1) out[i] = f.d[pos + i];
+    else if (ts == 2) out[i] = f.u16(pos + 2 * i);
+    else out[i] = f.u32(pos + 4 * i);
+  }
+  return true;
+}
+
+bool parse_ifd(const File& f, size_t off, Ifd& ifd, size_t& next) {
+  if (off + 2 > f.d.size()) return false;
+  const uint16_t n = f.u16(off);
+  if (off + 2 + 12 * (size_t)n + 4 > f.d.size()) return false;
+  std::vector<uint64_t> v;
+  for (uint16_t e = 0; e < n; ++e) {
+    const size_t ent = off + 2 + 12 * (size_t)e;
+    const uint16_t tag = f.u16(ent);
+    if (!read_values(f, ent, v) || v.empty()) continue;
+    switch (tag) {
+      case 256: ifd.w = (uint32_t)v[0]; break;
+      case 257: ifd.h = (uint32_t)v[0]; break;
+      case 258: ifd.bps = (uint32_t)v[0]; break;
+      case 259: ifd.comp = (uint32_t)v[0]; break;
+      case 266: ifd.fill = (uint32_t)v[0]; break;
+      case 273: ifd.offs = v; break;
+      case 277: ifd.spp = (uint32_t)v[0]; break;
+      case 278: ifd.rps = (uint32_t)v[0]; break;
+      case 279: ifd.counts = v; break;
+      case 284: ifd.planar = (uint32_t)v[0]; break;
+      case 322: ifd.tile_w = (uint32_t)v[0]; ifd.tiled = true; break;
+      case 323: ifd.tile_h = (uint32_t)v[0]; ifd.tiled = true; break;
+      case 324: ifd.offs = v; ifd.tiled = true; break;
+      case 325: ifd.counts = v; ifd.tiled = true; break;
+      case 339: ifd.fmt = (uint32_t)v[0]; break;
+      default: break;
+    }
+  }
+  next = f.u32(off + 2 + 12 * (size_t)n);
+  return true;
+}
+
+// PackBits (TIFF compression 32773)
+bool unpackbits(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
+  out.clear();
+  out.reserve(expect);
+  size_t i = 0;
+  while (i < n && out.size() < expect) {
+    const int8_t c = (int8_t)src[i++];
+    if (c >= 0) {
+      const size_t len = (size_t)c + 1;
+      if (i + len > n) return false;
+      out.insert(out.end(), src + i, src + i + len);
+      i += len;
+    } else if (c != -128) {
+      if (i >= n) return false;
+      out.insert(out.end(), (size_t)(1 - c), src[i++]);
+    }
+  }
+  return true;
+}
+
+template <typename T>
+T load_swapped(const uint8_t* p, bool swap) {
+  uint8_t b[sizeof(T)];
+  for (size_t i = 0; i < sizeof(T); ++i) b[i] = swap ? p[sizeof(T) - 1 - i] : p[i];
+  T v;
+  memcpy(&v, b, sizeof(T));
+  return v;
+}
+
+// interpretBytesAsDouble of the reference (TiffReader.cpp, used at :385,:430)
+double sample_as_double(const uint8_t* p, uint32_t bps, uint32_t fmt, bool swap) {
+  switch (bps) {
+    case 8: return fmt == 2 ? (double)(int8_t)p[0] : (double)p[0];
+    case 16: return fmt == 2 ? (double)load_swapped<int16_t>(p, swap) : (double)load_swapped<uint16_t>(p, swap);
+    case 32:
+      if (fmt == 3) return (double)load_swapped<float>(p, swap);
+      return fmt == 2 ? (double)load_swapped<int32_t>(p, swap) : (double)load_swapped<uint32_t>(p, swap);
+    case 64:
+      if (fmt == 3) return load_swapped<double>(p, swap);
+      return fmt == 2 ? (double)load_swapped<int64_t>(p, swap) : (double)load_swapped<uint64_t>(p, swap);
+    default: return 0.0;
+  }
+}
+
+bool host_is_le() {
+  const uint16_t one = 1;
+  return *reinterpret_cast<const uint8_t*>(&one) == 1;
+}
+
+}  // namespace
+
+extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
+                                  int* bits_per_sample) {
+  if (!path || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
+  *phase = nullptr;
+  File f;
+  if (!slurp(path, f.d) || f.d.size() < 8) {
+    oi::set_error("cannot read TIFF file '%s'", path);
+    return OI_IO_ERROR;
+  }
+  if (f.d[0] == 'I' && f.d[1] == 'I') f.le = true;
+  else if (f.d[0] == 'M' && f.d[1] == 'M') f.le = false;
+  else { oi::set_error("'%s' is not a TIFF file", path); return OI_IO_ERROR; }
+  if (f.u16(2) != 42) {
+    oi::set_error("'%s': only classic TIFF (magic 42) is supported", path);
+    return OI_IO_ERROR;
+  }
+  std::vector<Ifd> pages;
+  size_t off = f.u32(4);
+  while (off) {  // TiffReader.cpp:175-177: depth = number of directories
+    Ifd ifd;
+    size_t next = 0;
+    if (!parse_ifd(f, off, ifd, next)) { oi::set_error("'%s': corrupt IFD", path); return OI_IO_ERROR; }
+    pages.push_back(ifd);
+    if (pages.size() > (1u << 20)) { oi::set_error("'%s': IFD loop", path); return OI_IO_ERROR; }
+    off = next;
+  }
+  if (pages.empty()) { oi::set_error("'%s': no directories", path); return OI_IO_ERROR; }
+  const Ifd& p0 = pages[0];
+  const bool valid_bps = p0.bps == 1 || p0.bps == 8 || p0.bps == 16 || p0.bps == 32 || p0.bps == 64;
+  if (p0.w == 0 || p0.h == 0 || !valid_bps || p0.planar != 1 || p0.spp != 1) {  // TiffReader.cpp:167-173
+    oi::set_error("'%s': unsupported TIFF (W=%u H=%u BPS=%u planar=%u SPP=%u)", path, p0.w, p0.h, p0.bps, p0.planar,
+                  p0.spp);
+    return OI_IO_ERROR;
+  }
+  const size_t W = p0.w, H = p0.h, D = pages.size();
+  uint8_t* out = (uint8_t*)malloc(W * H * D);
+  if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
+  const bool swap = f.le != host_is_le();
+  const size_t bytes_ps = p0.bps >= 8 ? p0.bps / 8 : 1;
+  std::vector<uint8_t> buf;
+  for (size_t k = 0; k < D; ++k) {
+    const Ifd& pg = pages[k];
+    if (pg.w != p0.w || pg.h != p0.h || pg.bps != p0.bps) {
+      free(out);
+      oi::set_error("'%s': page %zu differs in size/depth from page 0", path, k);
+      return OI_IO_ERROR;
+    }
+    if (pg.comp != 1 && pg.comp != 32773) {
+      free(out);
+      oi::set_error("'%s': TIFF compression %u is not supported (uncompressed and PackBits are)", path, pg.comp);
+      return OI_IO_ERROR;
+    }
+    // geometry of one chunk (strip or tile)
+    const size_t cw = pg.tiled ? pg.tile_w : W;
+    size_t ch = pg.tiled ? pg.tile_h : (pg.rps == 0 || pg.rps > H ? H : pg.rps);
+    if (cw == 0 || ch == 0) { free(out); oi::set_error("'%s': bad strip/tile geometry", path); return OI_IO_ERROR; }
+    const size_t row_bytes = p0.bps == 1 ? (cw + 7) / 8 : cw * bytes_ps;
+    const size_t across = pg.tiled ? (W + cw - 1) / cw : 1;
+    const size_t down = (H + ch - 1) / ch;
+    if (pg.offs.size() < across * down || pg.counts.size() < across * down) {
+      free(out);
+      oi::set_error("'%s': page %zu lacks strip/tile offsets", path, k);
+      return OI_IO_ERROR;
+    }
+    for (size_t cy = 0; cy < down; ++cy)
+      for (size_t cx = 0; cx < across; ++cx) {
+        const size_t ci = cy * across + cx;
+        const size_t rows_here = pg.tiled ? ch : std::min(ch, H - cy * ch);
+        const size_t expect = row_bytes * rows_here;
+        const uint64_t o = pg.offs[ci], n = pg.counts[ci];
+        if (o + n > f.d.size()) { free(out); oi::set_error("'%s': chunk outside file", path); return OI_IO_ERROR; }
+        const uint8_t* src = f.d.data() + o;
+        size_t avail = n;
+        if (pg.comp == 32773) {
+          if (!unpackbits(src, n, buf, expect)) { free(out); oi::set_error("'%s': bad PackBits data", path); return OI_IO_ERROR; }
+          src = buf.data();
+          avail = buf.size();
+        }
+        for (size_t r = 0; r < rows_here; ++r) {
+          const size_t y = cy * ch + r;
+          if (y >= H) break;
+          for (size_t c = 0; c < cw; ++c) {
+            const size_t x = cx * cw + c;
+            if (x >= W) break;
+            double val = 0.0;
+            if (p0.bps == 1) {  // TiffReader.cpp:419-426 (strips) / :376-381 (tiles)
+              const size_t bi = r * row_bytes + c / 8;
+              if (bi < avail) {
+                const int bit = (int)(c % 8);
+                // libtiff hands data back MSB-first unless the file says LSB2MSB and the
+                // reference then picks the bit by FILLORDER (TiffReader.cpp:425)
+                val = (double)((pg.fill == 2 ? (src[bi] >> bit) : (src[bi] >> (7 - bit))) & 1);
+              }
+            } else {
+              const size_t bo = (r * cw + c) * bytes_ps;
+              if (bo + bytes_ps <= avail) val = sample_as_double(src + bo, p0.bps, pg.fmt, swap);
+            }
+            out[(k * H + y) * W + x] = val > threshold ? 1 : 0;  // TiffReader.cpp:434
+          }
+        }
+      }
+  }
+  *phase = out;
+  *nx = (int)W; *ny = (int)H; *nz = (int)D;
+  if (bits_per_sample) *bits_per_sample = (int)p0.bps;
+  return OI_OK;
+}
+
+extern "C" oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
+                                 uint8_t** phase) {
+  if (!path || !phase || nx < 1 || ny < 1 || nz < 1) return OI_BAD_ARG;
+  *phase = nullptr;
+  size_t bpv = 0;
+  bool le = true;
+  switch (dtype) {  // RawReader::getBytesPerVoxel / endianness table (RawReader.cpp:325-338)
+    case OI_RAW_UINT8: case OI_RAW_INT8: bpv = 1; break;
+    case OI_RAW_INT16_LE: case OI_RAW_UINT16_LE: bpv = 2; break;
+    case OI_RAW_INT16_BE: case OI_RAW_UINT16_BE: bpv = 2; le = false; break;
+    case OI_RAW_INT32_LE: case OI_RAW_UINT32_LE: case OI_RAW_FLOAT32_LE: bpv = 4; break;
+    case OI_RAW_INT32_BE: case OI_RAW_UINT32_BE: case OI_RAW_FLOAT32_BE: bpv = 4; le = false; break;
+    case OI_RAW_FLOAT64_LE: bpv = 8; break;
+    case OI_RAW_FLOAT64_BE: bpv = 8; le = false; break;
+    default: oi::set_error("unknown raw data type %d", dtype); return OI_BAD_ARG;
+  }
+  std::vector<uint8_t> d;
+  if (!slurp(path, d)) { oi::set_error("cannot read raw file '%s'", path); return OI_IO_ERROR; }
+  const size_t n = (size_t)nx * ny * nz;
+  if (d.size() != n * bpv) {  // the reference insists on an exact size match
+    oi::set_error("'%s': size %zu does not match %dx%dx%d x %zu bytes", path, d.size(), nx, ny, nz, bpv);
+    return OI_IO_ERROR;
+  }
+  uint8_t* out = (uint8_t*)malloc(n);
+  if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
+  const bool swap = bpv > 1 && le != host_is_le();
+  for (size_t v = 0; v < n; ++v) {
+    const uint8_t* p = d.data() + v * bpv;
+    double val = 0.0;
+    switch (dtype) {
+      case OI_RAW_UINT8: val = (double)p[0]; break;
+      case OI_RAW_INT8: val = (double)(int8_t)p[0]; break;
+      case OI_RAW_UINT16_LE: case OI_RAW_UINT16_BE: val = (double)load_swapped<uint16_t>(p, swap); break;
+      case OI_RAW_INT16_LE: case OI_RAW_INT16_BE: val = (double)load_swapped<int16_t>(p, swap); break;
+      case OI_RAW_UINT32_LE: case OI_RAW_UINT32_BE: val = (double)load_swapped<uint32_t>(p, swap); break;
+      case OI_RAW_INT32_LE: case OI_RAW_INT32_BE: val = (double)load_swapped<int32_t>(p, swap); break;
+      case OI_RAW_FLOAT32_LE: case OI_RAW_FLOAT32_BE: val = (double)load_swapped<float>(p, swap); break;
+      default: val = load_swapped<double>(p, swap); break;
+    }
+    out[v] = val > threshold ? 1 : 0;  // strictly greater (RawReader.H:214)
+  }
+  *phase = out;
+  return OI_OK;
+}
+
+extern "C" void oi_free_host(void* p) { free(p); }

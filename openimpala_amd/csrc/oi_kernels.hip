@@ -1,0 +1,899 @@
+// oi_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the flow-through tortuosity path.
+//
+// Everything here is HBM-bandwidth-bound integer/fp64 streaming work: 64-wide
+// wavefronts read x-contiguous rows with 16-byte lanes, the stencil's x/y reuse goes
+// through LDS tiles, z reuse through registers, dot products through wavefront
+// shuffles + one LDS slot per wave + per-block partials summed in a fixed order (no
+// float atomics: bit-reproducible).  No MFMA: 0.26 flop/B.
+//
+// Compiled with -ffp-contract=off: every product/sum is rounded exactly as in the
+// CPU oracle, so single-kernel outputs are bit-identical to it.
+#include "oi_device.h"
+
+namespace oi {
+
+// --------------------------------------------------------------------------------------
+// small device helpers
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Sum over the block; result valid in thread 0.  `lds` holds >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // protects lds reuse between consecutive calls
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w) t += lds[w];
+  return t;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ bool bit_at(const uint64_t* bits, const Geom& g, int gz, int j, int i) {
+  return (bits[(long long)gz * g.wplane + (long long)j * g.W + (i >> 6)] >> (i & 63)) & 1ULL;
+}
+
+static inline int cap_blocks(long long work_items, int per_block, int cap) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// --------------------------------------------------------------------------------------
+// phase bytes -> "open" bit planes (open = phase == phase_id), and the phase count of
+// VolumeFraction::value (reference src/props/VolumeFraction.cpp:22-66).
+// One wavefront builds one 64-voxel word with a ballot: 64 coalesced bytes in.
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_open(const uint8_t* __restrict__ phase, Geom g, int phase_id,
+                                                    uint64_t* __restrict__ open,
+                                                    unsigned long long* __restrict__ n_phase) {
+  const int lane = threadIdx.x & 63;
+  const long long nw_owned = (long long)g.nzl * g.wplane;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  unsigned long long cnt = 0;
+  for (long long w = wave0; w < nw_owned; w += nwaves) {
+    const int ww = (int)(w % g.W);
+    const long long row = w / g.W;  // k*ny + j over owned planes
+    const int i = ww * 64 + lane;
+    bool o = false;
+    if (i < g.nx) o = phase[row * g.nx + i] == (uint8_t)phase_id;
+    const unsigned long long word = __ballot(o);
+    if (lane == 0) {
+      open[g.wplane + w] = word;  // owned planes start after the lo ghost plane
+      cnt += __popcll(word);
+    }
+  }
+  __shared__ double red[4];
+  // integer count through the fp64 block sum is exact below 2^53
+  const double tot = block_sum((double)cnt, red);
+  if (threadIdx.x == 0 && tot != 0.0) atomicAdd(n_phase, (unsigned long long)tot);
+}
+
+void launch_pack_open(const uint8_t* phase, const Geom& g, int phase_id, uint64_t* open,
+                      unsigned long long* n_phase, hipStream_t s) {
+  const long long nw = (long long)g.nzl * g.wplane;
+  const int blocks = cap_blocks(nw, 4, 8192);
+  hipLaunchKernelGGL(k_pack_open, dim3(blocks), dim3(256), 0, s, phase, g, phase_id, open, n_phase);
+}
+
+// --------------------------------------------------------------------------------------
+// Flood-fill seeds: cells of the phase on the lo / hi face of the flow axis
+// (reference TortuosityHypre.cpp:424-449).  reach arrays must be zeroed before.
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seed(Geom g, const uint64_t* __restrict__ open,
+                                               uint64_t* __restrict__ rlo, uint64_t* __restrict__ rhi) {
+  const long long nw_owned = (long long)g.nzl * g.wplane;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < nw_owned;
+       w += (long long)gridDim.x * blockDim.x) {
+    const int ww = (int)(w % g.W);
+    const int j = (int)((w / g.W) % g.ny);
+    const int kz = g.z0 + (int)(w / g.wplane);
+    const uint64_t o = open[g.wplane + w];
+    uint64_t lo = 0, hi = 0;
+    if (g.dir == 0) {
+      if (ww == 0) lo = o & 1ULL;
+      if (ww == ((g.nx - 1) >> 6)) hi = o & (1ULL << ((g.nx - 1) & 63));
+    } else if (g.dir == 1) {
+      if (j == 0) lo = o;
+      if (j == g.ny - 1) hi = o;
+    } else {
+      if (kz == 0) lo = o;
+      if (kz == g.nz - 1) hi = o;
+    }
+    rlo[g.wplane + w] = lo;
+    rhi[g.wplane + w] = hi;
+  }
+}
+
+void launch_seed(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.wplane, 256, 4096);
+  hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), 0, s, g, open, rlo, rhi);
+}
+
+// --------------------------------------------------------------------------------------
+// One flood-fill sweep on bit planes (reference parallelFloodFill,
+// TortuosityHypre.cpp:336-380: "a phase cell becomes reached if a 6-neighbour is
+// reached", iterated to the fixed point).  Per 64-voxel word: OR in the y/z neighbour
+// words and the x neighbours across the word boundary, then flood every run of open
+// bits that holds a reached bit with the carry trick  ((o + s) ^ o) & o | s  in both bit
+// directions.  Monotone, so in-place racy reads only delay, never corrupt.
+// Each thread walks TJ rows up and down (Gauss-Seidel in y inside the strip).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t fill_runs(uint64_t o, uint64_t s) {
+  const uint64_t up = (((o + s) ^ o) & o) | s;
+  const uint64_t ro = __brevll(o), rs = __brevll(s);
+  const uint64_t dn = __brevll((((ro + rs) ^ ro) & ro) | rs);
+  return up | dn;
+}
+
+constexpr int kFloodTJ = 8;
+
+__global__ void __launch_bounds__(256) k_flood_sweep(Geom g, const uint64_t* __restrict__ open,
+                                                      uint64_t* rlo, uint64_t* rhi, int* __restrict__ changed) {
+  const int nstrips = (g.ny + kFloodTJ - 1) / kFloodTJ;
+  const long long nitems = (long long)g.nzl * nstrips * g.W;
+  bool any = false;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nitems;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int ww = (int)(t % g.W);
+    const int strip = (int)((t / g.W) % nstrips);
+    const int gz = 1 + (int)(t / ((long long)g.W * nstrips));
+    const int j0 = strip * kFloodTJ, j1 = min(g.ny, j0 + kFloodTJ);
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int jj = 0; jj < j1 - j0; ++jj) {
+        const int j = pass == 0 ? j0 + jj : j1 - 1 - jj;
+        const long long c = (long long)gz * g.wplane + (long long)j * g.W + ww;
+        const uint64_t o = open[c];
+        if (o == 0) continue;
+        const uint64_t a0 = rlo[c], b0 = rhi[c];
+        uint64_t a = a0 | rlo[c - g.wplane] | rlo[c + g.wplane];
+        uint64_t b = b0 | rhi[c - g.wplane] | rhi[c + g.wplane];
+        if (j > 0) { a |= rlo[c - g.W]; b |= rhi[c - g.W]; }
+        if (j < g.ny - 1) { a |= rlo[c + g.W]; b |= rhi[c + g.W]; }
+        if (ww > 0) { a |= rlo[c - 1] >> 63; b |= rhi[c - 1] >> 63; }
+        if (ww < g.W - 1) { a |= rlo[c + 1] << 63; b |= rhi[c + 1] << 63; }
+        a = fill_runs(o, a & o);
+        b = fill_runs(o, b & o);
+        if (a != a0) { rlo[c] = a; any = true; }
+        if (b != b0) { rhi[c] = b; any = true; }
+      }
+    }
+  }
+  if (any) *changed = 1;
+}
+
+void launch_flood_sweep(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, int* changed,
+                        hipStream_t s) {
+  const int nstrips = (g.ny + kFloodTJ - 1) / kFloodTJ;
+  const int blocks = cap_blocks((long long)g.nzl * nstrips * g.W, 256, 8192);
+  hipLaunchKernelGGL(k_flood_sweep, dim3(blocks), dim3(256), 0, s, g, open, rlo, rhi, changed);
+}
+
+// active = reached from lo AND reached from hi (reference TortuosityHypre.cpp:526-538),
+// written over rlo (ghost planes included); counts active cells (owned planes) and the
+// active cells on the two Dirichlet faces (they give ||b||).
+__global__ void __launch_bounds__(256) k_mask_and(Geom g, uint64_t* rlo, const uint64_t* __restrict__ rhi,
+                                                   unsigned long long* __restrict__ counts) {
+  unsigned long long na = 0, nlo = 0, nhi = 0;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < g.nwords;
+       w += (long long)gridDim.x * blockDim.x) {
+    const uint64_t a = rlo[w] & rhi[w];
+    rlo[w] = a;
+    const int gz = (int)(w / g.wplane);
+    if (gz >= 1 && gz <= g.nzl && a) {
+      na += __popcll(a);
+      const int ww = (int)(w % g.W);
+      const int j = (int)((w / g.W) % g.ny);
+      const int kz = g.z0 + gz - 1;
+      if (g.dir == 0) {
+        if (ww == 0) nlo += a & 1ULL;
+        if (ww == ((g.nx - 1) >> 6)) nhi += (a >> ((g.nx - 1) & 63)) & 1ULL;
+      } else if (g.dir == 1) {
+        if (j == 0) nlo += __popcll(a);
+        if (j == g.ny - 1) nhi += __popcll(a);
+      } else {
+        if (kz == 0) nlo += __popcll(a);
+        if (kz == g.nz - 1) nhi += __popcll(a);
+      }
+    }
+  }
+  __shared__ double red[4];
+  const double ta = block_sum((double)na, red);
+  const double tl = block_sum((double)nlo, red);
+  const double th = block_sum((double)nhi, red);
+  if (threadIdx.x == 0) {
+    if (ta != 0.0) atomicAdd(&counts[0], (unsigned long long)ta);
+    if (tl != 0.0) atomicAdd(&counts[1], (unsigned long long)tl);
+    if (th != 0.0) atomicAdd(&counts[2], (unsigned long long)th);
+  }
+}
+
+void launch_mask_and(const Geom& g, uint64_t* rlo_to_active, const uint64_t* rhi, unsigned long long* counts,
+                     hipStream_t s) {
+  const int blocks = cap_blocks(g.nwords, 256, 4096);
+  hipLaunchKernelGGL(k_mask_and, dim3(blocks), dim3(256), 0, s, g, rlo_to_active, rhi, counts);
+}
+
+// --------------------------------------------------------------------------------------
+// Matrix codes.  code = number of active 6-neighbours for a FREE voxel (active and not
+// on a Dirichlet face), else 0: the diagonal of the reference's row
+// (TortuosityHypreFill.F90:126-169, dx = 1); the off-diagonals are -1 exactly where the
+// neighbour is active, which the apply gets for free because every vector is 0 there.
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_codes(Geom g, const uint64_t* __restrict__ active,
+                                                uint8_t* __restrict__ code, unsigned long long* __restrict__ n_free) {
+  const long long nown = (long long)g.nzl * g.plane;
+  unsigned long long nf = 0;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nown;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % g.pitch);
+    const int j = (int)((e / g.pitch) % g.ny);
+    const int gz = 1 + (int)(e / g.plane);
+    const int kz = g.z0 + gz - 1;
+    int c = 0;
+    if (i < g.nx && bit_at(active, g, gz, j, i)) {
+      const int cd = g.dir == 0 ? i : (g.dir == 1 ? j : kz);
+      const int nd = g.dir == 0 ? g.nx : (g.dir == 1 ? g.ny : g.nz);
+      if (cd != 0 && cd != nd - 1) {
+        c += (i > 0 && bit_at(active, g, gz, j, i - 1));
+        c += (i < g.nx - 1 && bit_at(active, g, gz, j, i + 1));
+        c += (j > 0 && bit_at(active, g, gz, j - 1, i));
+        c += (j < g.ny - 1 && bit_at(active, g, gz, j + 1, i));
+        c += bit_at(active, g, gz - 1, j, i);  // ghost planes are 0 at a domain face
+        c += bit_at(active, g, gz + 1, j, i);
+      }
+    }
+    code[g.plane + e] = (uint8_t)c;
+    nf += (c != 0);
+  }
+  __shared__ double red[4];
+  const double t = block_sum((double)nf, red);
+  if (threadIdx.x == 0 && t != 0.0) atomicAdd(n_free, (unsigned long long)t);
+}
+
+void launch_codes(const Geom& g, const uint64_t* active, uint8_t* code, unsigned long long* n_free,
+                  hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.plane, 256, 8192);
+  hipLaunchKernelGGL(k_codes, dim3(blocks), dim3(256), 0, s, g, active, code, n_free);
+}
+
+// Initial field: the reference's linear ramp on active cells (TortuosityHypreFill.F90:
+// 233-262) with the exact Dirichlet values on the two faces (F90:191-228); ghost planes
+// are filled from the ghost bits so no exchange is needed before the first apply.
+__global__ void __launch_bounds__(256) k_init_field(Geom g, const uint64_t* __restrict__ active,
+                                                     double* __restrict__ x) {
+  const int nd = g.dir == 0 ? g.nx : (g.dir == 1 ? g.ny : g.nz);
+  const double extent = (double)(nd - 1);
+  const double factor = (extent < 1e-15) ? 0.0 : 1.0 / extent;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < g.nvec;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % g.pitch);
+    const int j = (int)((e / g.pitch) % g.ny);
+    const int gz = (int)(e / g.plane);
+    const int kz = g.z0 + gz - 1;
+    double v = 0.0;
+    if (i < g.nx && bit_at(active, g, gz, j, i)) {
+      const int cd = g.dir == 0 ? i : (g.dir == 1 ? j : kz);
+      v = g.vlo + (g.vhi - g.vlo) * (double)cd * factor;
+      if (cd == 0) v = g.vlo;
+      else if (cd == nd - 1) v = g.vhi;
+    }
+    x[e] = v;
+  }
+}
+
+void launch_init_field(const Geom& g, const uint64_t* active, double* x, hipStream_t s) {
+  const int blocks = cap_blocks(g.nvec, 256, 8192);
+  hipLaunchKernelGGL(k_init_field, dim3(blocks), dim3(256), 0, s, g, active, x);
+}
+
+__global__ void __launch_bounds__(256) k_unpack_mask(Geom g, const uint64_t* __restrict__ active,
+                                                      uint8_t* __restrict__ out) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % g.nx);
+    const int j = (int)((e / g.nx) % g.ny);
+    const int gz = 1 + (int)(e / ((long long)g.nx * g.ny));
+    out[e] = bit_at(active, g, gz, j, i) ? 1 : 0;
+  }
+}
+
+void launch_unpack_mask(const Geom& g, const uint64_t* active, uint8_t* mask_out, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.ny * g.nx, 256, 8192);
+  hipLaunchKernelGGL(k_unpack_mask, dim3(blocks), dim3(256), 0, s, g, active, mask_out);
+}
+
+// --------------------------------------------------------------------------------------
+// Direct (cache-served) masked 7-point apply on voxel pairs.  Summation order is the
+// oracle's: ((((xm + xp) + ym) + yp) + zm) + zp, then code*v - sum.
+// --------------------------------------------------------------------------------------
+struct Pair {
+  double a, b;
+};
+
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double a, double b) {
+  *reinterpret_cast<double2*>(p) = make_double2(a, b);
+}
+
+// (A v) for the pair at element e = (gz, j, i..i+1); i even.  Needs the row/plane bounds.
+__device__ __forceinline__ Pair apply_pair(const Geom& g, const double* __restrict__ v, long long e, int i, int j,
+                                           unsigned c0, unsigned c1) {
+  const double2 c = ld2(v + e);
+  const double xm = (i > 0) ? v[e - 1] : 0.0;
+  const double xp = (i + 2 < g.pitch) ? v[e + 2] : 0.0;  // columns >= nx hold zeros
+  double2 ym = make_double2(0.0, 0.0), yp = make_double2(0.0, 0.0);
+  if (j > 0) ym = ld2(v + e - g.pitch);
+  if (j < g.ny - 1) yp = ld2(v + e + g.pitch);
+  const double2 zm = ld2(v + e - g.plane), zp = ld2(v + e + g.plane);
+  Pair q;
+  const double s0 = ((((xm + c.y) + ym.x) + yp.x) + zm.x) + zp.x;
+  const double s1 = ((((c.x + xp) + ym.y) + yp.y) + zm.y) + zp.y;
+  q.a = c0 ? (double)c0 * c.x - s0 : 0.0;
+  q.b = c1 ? (double)c1 * c.y - s1 : 0.0;
+  return q;
+}
+
+#define OI_PAIR_LOOP_BEGIN                                                                   \
+  const int hp = g.pitch >> 1;                                                               \
+  const long long npairs = (long long)g.nzl * g.ny * hp;                                     \
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;           \
+       t += (long long)gridDim.x * blockDim.x) {                                             \
+    const int i = 2 * (int)(t % hp);                                                         \
+    const int j = (int)((t / hp) % g.ny);                                                    \
+    const long long e = g.plane + 2 * t; /* owned planes start after the lo ghost plane */ \
+    const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);            \
+    const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
+#define OI_PAIR_LOOP_END }
+
+// r = -A x on free cells (x holds the Dirichlet values), p = z, partials {r.r, r.z}
+__global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __restrict__ code,
+                                                    const double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ p, int jacobi, double* __restrict__ partials) {
+  double rr = 0.0, rz = 0.0;
+  OI_PAIR_LOOP_BEGIN
+  (void)j;
+  const Pair q = apply_pair(g, x, e, i, j, c0, c1);
+  const double r0 = c0 ? -q.a : 0.0, r1 = c1 ? -q.b : 0.0;
+  const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;
+  const double z1 = (jacobi && c1) ? r1 / (double)c1 : r1;
+  st2(r + e, r0, r1);
+  st2(p + e, z0, z1);
+  rr += r0 * r0; rr += r1 * r1;
+  rz += r0 * z0; rz += r1 * z1;
+  OI_PAIR_LOOP_END
+  __shared__ double red[4];
+  const double a = block_sum(rr, red);
+  const double b = block_sum(rz, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
+}
+
+int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double* r, double* p, int jacobi,
+                     double* partials, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
+  hipLaunchKernelGGL(k_residual0, dim3(blocks), dim3(256), 0, s, g, code, x, r, p, jacobi, partials);
+  return blocks;
+}
+
+// q = A v, partials {v.q}
+__global__ void __launch_bounds__(256) k_apply(Geom g, const uint8_t* __restrict__ code,
+                                                const double* __restrict__ v, double* __restrict__ q,
+                                                double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->done) return;
+  double pq = 0.0;
+  OI_PAIR_LOOP_BEGIN
+  const Pair a = apply_pair(g, v, e, i, j, c0, c1);
+  st2(q + e, a.a, a.b);
+  const double2 c = ld2(v + e);
+  pq += c.x * a.a; pq += c.y * a.b;
+  OI_PAIR_LOOP_END
+  __shared__ double red[4];
+  const double t = block_sum(pq, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+int launch_apply(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
+                 const Ctrl* ctrl, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
+  hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, s, g, code, v, q, partials, ctrl);
+  return blocks;
+}
+
+// --------------------------------------------------------------------------------------
+// CG vector kernels (unfused variant): flat 16-byte streams over the owned planes.
+// alpha_k = rz_k / pq_k and beta_k = rz_k / rz_{k-1} are formed in registers from the
+// device-resident history, so the host never sits in the loop.  A vanishing
+// denominator (exact convergence) turns the step into a no-op instead of a NaN.
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ double safe_div(double a, double b) { return b != 0.0 ? a / b : 0.0; }
+
+__global__ void __launch_bounds__(256) k_update_p(Geom g, const uint8_t* __restrict__ code,
+                                                   const double* __restrict__ r, double* __restrict__ p, int jacobi,
+                                                   const double* __restrict__ hist, int k,
+                                                   const Ctrl* __restrict__ ctrl) {
+  if (ctrl->done) return;
+  const double beta = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * (k - 1) + H_RZ]);
+  OI_PAIR_LOOP_BEGIN
+  (void)i; (void)j;
+  const double2 rv = ld2(r + e), pv = ld2(p + e);
+  const double z0 = (jacobi && c0) ? rv.x / (double)c0 : rv.x;
+  const double z1 = (jacobi && c1) ? rv.y / (double)c1 : rv.y;
+  st2(p + e, z0 + beta * pv.x, z1 + beta * pv.y);
+  OI_PAIR_LOOP_END
+}
+
+void launch_update_p(const Geom& g, const uint8_t* code, const double* r, double* p, int jacobi,
+                     const double* hist, int k, const Ctrl* ctrl, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
+  hipLaunchKernelGGL(k_update_p, dim3(blocks), dim3(256), 0, s, g, code, r, p, jacobi, hist, k, ctrl);
+}
+
+template <bool WITH_X>
+__global__ void __launch_bounds__(256) k_update_xr(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+                                                    double* __restrict__ r, const double* __restrict__ p,
+                                                    const double* __restrict__ q, int jacobi,
+                                                    const double* __restrict__ hist, int k,
+                                                    double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->done) return;
+  const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
+  double rr = 0.0, rz = 0.0;
+  OI_PAIR_LOOP_BEGIN
+  (void)i; (void)j;
+  const double2 rv = ld2(r + e), qv = ld2(q + e);
+  if (WITH_X) {
+    const double2 xv = ld2(x + e), pv = ld2(p + e);
+    st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+  }
+  const double r0 = rv.x - alpha * qv.x, r1 = rv.y - alpha * qv.y;
+  st2(r + e, r0, r1);
+  const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;
+  const double z1 = (jacobi && c1) ? r1 / (double)c1 : r1;
+  rr += r0 * r0; rr += r1 * r1;
+  rz += r0 * z0; rz += r1 * z1;
+  OI_PAIR_LOOP_END
+  __shared__ double red[4];
+  const double a = block_sum(rr, red);
+  const double b = block_sum(rz, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
+}
+
+int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, const double* p, const double* q,
+                     int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
+  hipLaunchKernelGGL(k_update_xr<true>, dim3(blocks), dim3(256), 0, s, g, code, x, r, p, q, jacobi, hist, k,
+                     partials, ctrl);
+  return blocks;
+}
+
+int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi, const double* hist,
+                    int k, double* partials, const Ctrl* ctrl, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
+  hipLaunchKernelGGL(k_update_xr<false>, dim3(blocks), dim3(256), 0, s, g, code, (double*)nullptr, r,
+                     (const double*)nullptr, q, jacobi, hist, k, partials, ctrl);
+  return blocks;
+}
+
+__global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ x, const double* __restrict__ p,
+                                                    const double* __restrict__ hist, int k) {
+  const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
+  const long long npairs = (long long)g.nzl * g.plane / 2;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long e = g.plane + 2 * t;
+    const double2 xv = ld2(x + e), pv = ld2(p + e);
+    st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+  }
+}
+
+void launch_axpy_hist(const Geom& g, double* x, const double* p, const double* hist, int k, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
+  hipLaunchKernelGGL(k_axpy_hist, dim3(blocks), dim3(256), 0, s, g, x, p, hist, k);
+}
+
+// --------------------------------------------------------------------------------------
+// Fused CG kernel A (z-marching, LDS-staged halo tiles):
+//     x     += alpha_{k-1} * p_in            (deferred solution update)
+//     p_out  = z + beta_k * p_in             (z = r or r/code)
+//     q      = A p_out,   partial p_out.q
+// A block owns a BX x BY column of voxels and marches over a chunk of z planes.  Every
+// thread owns one x-pair; the p_out values of planes g-1, g, g+1 of its pair live in
+// registers (z reuse), plane g of the whole tile incl. a one-voxel halo ring lives in a
+// double-buffered LDS plane (x/y reuse; halo values are recomputed from r and p_in,
+// which the neighbouring tile's block pulls through the same XCD L2).  Compulsory HBM
+// traffic: r 8 + p_in 8 + code 1 + x 8+8 + p_out 8 + q 8 = 49 B/voxel.
+// LDS row: [pad | left halo | BX tile doubles | right halo | pad]: every access is a
+// conflict-free 16-byte ds_read/ds_write_b128.
+// --------------------------------------------------------------------------------------
+constexpr int kBX = 128;            // tile width in voxels = 64 lanes x 2
+constexpr int kLP = kBX + 4;        // LDS row pitch in doubles
+
+// PURE = true turns the kernel into the stand-alone stencil apply q = A v (v passed as
+// `r`; no p/x traffic: 8 + 1 + 8 = 17 B/voxel), partial v.q.
+template <int BY, bool PURE>
+__global__ void __launch_bounds__(64 * BY) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+                                                      const double* __restrict__ r, const double* __restrict__ p_in,
+                                                      double* __restrict__ p_out, double* __restrict__ q, int jacobi,
+                                                      const double* __restrict__ hist, int k, int zchunk, int tiles_x,
+                                                      int tiles_y, int nzc, double* __restrict__ partials,
+                                                      const Ctrl* __restrict__ ctrl) {
+  static_assert(BY >= 4, "waves 0,1 load the y halo rows, wave 2 the x halo columns");
+  if (ctrl && ctrl->done) return;
+  __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
+  __shared__ double red[BY];
+
+  // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2), so
+  // give every XCD one contiguous range of logical tiles (x fastest, then y, then z chunk).
+  const int ntiles = tiles_x * tiles_y * nzc;
+  int L = blockIdx.x;
+  if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
+
+  double beta = 0.0, alpha_prev = 0.0;
+  if (!PURE && k > 0) {
+    beta = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * (k - 1) + H_RZ]);
+    alpha_prev = safe_div(hist[H_STRIDE * (k - 1) + H_RZ], hist[H_STRIDE * (k - 1) + H_PQ]);
+  }
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // w = row inside the tile
+  const int i = tx * kBX + 2 * lane, j = ty * BY + w;
+  const bool own = (i < g.pitch) && (j < g.ny);
+  const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);  // output planes [gs, ge)
+  const long long rowoff = (long long)j * g.pitch + i;
+
+  // halo duty: wave 0 -> row j0-1, wave 1 -> row j0+BY (pairs); wave 2, lanes < 2*BY -> x halos
+  const int j0 = ty * BY;
+  const int hrow = (w == 0) ? j0 - 1 : j0 + BY;
+  const bool yhalo = (w < 2) && (i < g.pitch) && hrow >= 0 && hrow < g.ny;
+  const int xh_row = j0 + (lane >> 1);
+  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
+
+  // p_new of one plane for this thread's own pair
+  auto pnew_pair = [&](int gz, double2& pin) -> double2 {
+    pin = make_double2(0.0, 0.0);
+    if (!own) return make_double2(0.0, 0.0);
+    const long long e = (long long)gz * g.plane + rowoff;
+    const double2 rv = ld2(r + e);
+    if (PURE) return rv;
+    pin = ld2(p_in + e);
+    double z0 = rv.x, z1 = rv.y;
+    if (jacobi) {
+      const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+      if (cc & 0xff) z0 = rv.x / (double)(cc & 0xff);
+      if (cc >> 8) z1 = rv.y / (double)(cc >> 8);
+    }
+    return make_double2(z0 + beta * pin.x, z1 + beta * pin.y);
+  };
+  auto pnew_at = [&](long long e) -> double {
+    double z = r[e];
+    if (PURE) return z;
+    if (jacobi) { const unsigned c = code[e]; if (c) z = z / (double)c; }
+    return z + beta * p_in[e];
+  };
+  // stage plane gz (own pair value pn) plus the halo ring into LDS buffer b
+  auto stage = [&](int b, int gz, double2 pn) {
+    double* T = tile[b];
+    *reinterpret_cast<double2*>(&T[(w + 1) * kLP + 2 + 2 * lane]) = pn;
+    if (w < 2) {
+      double2 h = make_double2(0.0, 0.0);
+      if (yhalo) {
+        const long long e = (long long)gz * g.plane + (long long)hrow * g.pitch + i;
+        h.x = pnew_at(e); h.y = pnew_at(e + 1);
+      }
+      *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+    } else if (w == 2 && lane < 2 * BY) {
+      double h = 0.0;
+      if (xhalo) h = pnew_at((long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i);
+      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    }
+  };
+
+  double2 pin_cur, pin_nxt, pin_tmp;
+  double2 pn_prev = pnew_pair(gs - 1, pin_tmp);
+  double2 pn_cur = pnew_pair(gs, pin_cur);
+  if (!PURE && gs == 1 && own) st2(p_out + rowoff, pn_prev.x, pn_prev.y);  // lo ghost plane of p stays current
+  stage(gs & 1, gs, pn_cur);
+  __syncthreads();
+
+  double pq = 0.0;
+  for (int gz = gs; gz < ge; ++gz) {
+    const double2 pn_nxt = pnew_pair(gz + 1, pin_nxt);
+    if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
+    if (own) {
+      const double* T = tile[gz & 1];
+      const int base = (w + 1) * kLP + 2 + 2 * lane;
+      const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
+      const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
+      const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
+      const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
+      const long long e = (long long)gz * g.plane + rowoff;
+      const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+      const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
+      const double s0 = ((((lf.y + pn_cur.y) + ym.x) + yp.x) + pn_prev.x) + pn_nxt.x;
+      const double s1 = ((((pn_cur.x + rt.x) + ym.y) + yp.y) + pn_prev.y) + pn_nxt.y;
+      const double q0 = c0 ? (double)c0 * pn_cur.x - s0 : 0.0;
+      const double q1 = c1 ? (double)c1 * pn_cur.y - s1 : 0.0;
+      st2(q + e, q0, q1);
+      if (!PURE) {
+        st2(p_out + e, pn_cur.x, pn_cur.y);
+        if (k > 0) {
+          const double2 xv = ld2(x + e);
+          st2(x + e, xv.x + alpha_prev * pin_cur.x, xv.y + alpha_prev * pin_cur.y);
+        }
+      }
+      pq += pn_cur.x * q0; pq += pn_cur.y * q1;
+    }
+    if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && own)  // hi ghost plane of p stays current
+      st2(p_out + (long long)ge * g.plane + rowoff, pn_nxt.x, pn_nxt.y);
+    pn_prev = pn_cur; pn_cur = pn_nxt; pin_cur = pin_nxt;
+    __syncthreads();
+  }
+  const double t = block_sum(pq, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+static int g_fused_by = 8;       // tile rows (4 or 8)
+static int g_fused_zchunk = 0;   // planes per block, 0 = auto
+
+void set_fused_tuning(int by, int zchunk) {
+  if (by == 4 || by == 8) g_fused_by = by;
+  g_fused_zchunk = zchunk > 0 ? zchunk : 0;
+}
+
+template <bool PURE>
+static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const double* r, const double* p_in,
+                        double* p_out, double* q, int jacobi, const double* hist, int k, double* partials,
+                        const Ctrl* ctrl, hipStream_t s) {
+  const int by = g_fused_by;
+  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)tiles_x * tiles_y;
+  int zchunk = g_fused_zchunk;
+  if (zchunk <= 0) {
+    // >= ~4096 blocks when the volume allows it, but chunks of >= 64 planes so the two
+    // redundant halo planes per chunk stay near 3 %
+    long long want = (4096 + cols - 1) / cols;
+    if (want < 1) want = 1;
+    zchunk = (int)((g.nzl + want - 1) / want);
+    if (zchunk < 64) zchunk = 64;
+  }
+  if (zchunk > g.nzl) zchunk = g.nzl;
+  int nzc = (g.nzl + zchunk - 1) / zchunk;
+  if (cols * nzc > kMaxPartials) {  // the partial-sum array bounds the grid
+    const int maxc = (int)(kMaxPartials / cols) > 0 ? (int)(kMaxPartials / cols) : 1;
+    zchunk = (g.nzl + maxc - 1) / maxc;
+    nzc = (g.nzl + zchunk - 1) / zchunk;
+  }
+  const int blocks = (int)(cols * nzc);
+  if (by == 8)
+    hipLaunchKernelGGL((k_fused_a<8, PURE>), dim3(blocks), dim3(512), 0, s, g, code, x, r, p_in, p_out, q, jacobi,
+                       hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  else
+    hipLaunchKernelGGL((k_fused_a<4, PURE>), dim3(blocks), dim3(256), 0, s, g, code, x, r, p_in, p_out, q, jacobi,
+                       hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  return blocks;
+}
+
+int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const double* p_in,
+                   double* p_out, double* q, int jacobi, const double* hist, int k, double* partials,
+                   const Ctrl* ctrl, hipStream_t s) {
+  return launch_tiled<false>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s);
+}
+
+int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
+                       const Ctrl* ctrl, hipStream_t s) {
+  return launch_tiled<true>(g, code, nullptr, v, nullptr, nullptr, q, 0, nullptr, 0, partials, ctrl, s);
+}
+
+// --------------------------------------------------------------------------------------
+// Deterministic final sums: one block adds the per-block partials in a fixed order.
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ partials, int nblocks, int ncomp,
+                                                   double* __restrict__ dst, Ctrl* ctrl, int check, int iter_done) {
+  if (ctrl && ctrl->done) return;
+  __shared__ double red[4];
+  for (int c = 0; c < ncomp; ++c) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += partials[(long long)b * ncomp + c];
+    const double t = block_sum(v, red);
+    if (threadIdx.x == 0) {
+      dst[c] = t;
+      if (check && c == 0 && t <= ctrl->tol2) ctrl->done = iter_done;
+    }
+  }
+}
+
+void launch_finalize(const double* partials, int nblocks, int ncomp, double* dst, Ctrl* ctrl, int check,
+                     int iter_done, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partials, nblocks, ncomp, dst, ctrl, check, iter_done);
+}
+
+__global__ void k_check_done(const double* __restrict__ rr, Ctrl* ctrl, int iter_done) {
+  if (!ctrl->done && *rr <= ctrl->tol2) ctrl->done = iter_done;
+}
+
+void launch_check_done(const double* rr, Ctrl* ctrl, int iter_done, hipStream_t s) {
+  hipLaunchKernelGGL(k_check_done, dim3(1), dim3(1), 0, s, rr, ctrl, iter_done);
+}
+
+// dst[i] = sum over sources of srcs[s][i]  (in-process "all-reduce" of the local transport)
+__global__ void k_sum_scalars(double* dst, const double* const* srcs, int nsrc, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double v = 0.0;
+    for (int s = 0; s < nsrc; ++s) v += srcs[s][i];
+    dst[i] = v;
+  }
+}
+
+void launch_sum_scalars(double* dst, const double* const* srcs, int nsrc, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_scalars, dim3((n + 63) / 64), dim3(64), 0, s, dst, srcs, nsrc, n);
+}
+
+// --------------------------------------------------------------------------------------
+// Boundary fluxes (reference global_fluxes, TortuosityHypre.cpp:1066-1104, dx = 1):
+// one-sided differences on the lo / hi face where face cell and inner cell are active.
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_flux(Geom g, const uint64_t* __restrict__ active,
+                                               const double* __restrict__ x, double* __restrict__ partials) {
+  // face cells are indexed by the two non-flow coordinates (a fastest)
+  const int na = g.dir == 0 ? g.ny : g.nx;
+  const int nb = g.dir == 2 ? g.ny : g.nzl;  // for dir 0/1 the second coordinate is the local plane
+  const int nd = g.dir == 0 ? g.nx : (g.dir == 1 ? g.ny : g.nz);
+  double fin = 0.0, fout = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)na * nb;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(t % na), b = (int)(t / na);
+    for (int side = 0; side < 2; ++side) {
+      int i, j, gz, ii, jj, gg;  // face cell and inner cell
+      if (g.dir == 0) {
+        j = jj = a; gz = gg = b + 1; i = side ? g.nx - 1 : 0; ii = side ? g.nx - 2 : 1;
+      } else if (g.dir == 1) {
+        i = ii = a; gz = gg = b + 1; j = side ? g.ny - 1 : 0; jj = side ? g.ny - 2 : 1;
+      } else {
+        i = ii = a; j = jj = b;
+        const int kz = side ? g.nz - 1 : 0;
+        gz = kz - g.z0 + 1; gg = side ? gz - 1 : gz + 1;
+        if (gz < 1 || gz > g.nzl) continue;  // the face plane belongs to another slab
+      }
+      if (nd < 2) continue;
+      if (!bit_at(active, g, gz, j, i) || !bit_at(active, g, gg, jj, ii)) continue;
+      const double vb = x[(long long)gz * g.plane + (long long)j * g.pitch + i];
+      const double vi = x[(long long)gg * g.plane + (long long)jj * g.pitch + ii];
+      if (side == 0) fin += -((vi - vb) / 1.0);
+      else fout += -((vb - vi) / 1.0);
+    }
+  }
+  __shared__ double red[4];
+  const double ti = block_sum(fin, red);
+  const double to = block_sum(fout, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ti; partials[2 * blockIdx.x + 1] = to; }
+}
+
+void launch_flux(const Geom& g, const uint64_t* active, const double* x, double* partials, double* out2,
+                 hipStream_t s) {
+  const int na = g.dir == 0 ? g.ny : g.nx;
+  const int nb = g.dir == 2 ? g.ny : g.nzl;
+  const int blocks = cap_blocks((long long)na * nb, 256, 1024);
+  hipLaunchKernelGGL(k_flux, dim3(blocks), dim3(256), 0, s, g, active, x, partials);
+  launch_finalize(partials, blocks, 2, out2, nullptr, 0, 0, s);
+}
+
+// --------------------------------------------------------------------------------------
+// Seeded synthetic microstructures (pure integer arithmetic, identical to the oracle).
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gen_bernoulli(uint8_t* __restrict__ phase, int nx, int ny, int z0,
+                                                        int nzl, uint64_t seed, uint64_t thr53) {
+  const long long n = (long long)nx * ny * nzl;
+  const long long off = (long long)nx * ny * z0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n;
+       v += (long long)gridDim.x * blockDim.x) {
+    const uint64_t h = mix64(seed * 0xD1342543DE82EF95ULL + (uint64_t)(v + off));
+    phase[v] = ((h >> 11) < thr53) ? 1 : 0;
+  }
+}
+
+void launch_gen_bernoulli(uint8_t* phase, int nx, int ny, int nz, int z0, int nzl, uint64_t seed,
+                          uint64_t thr53, hipStream_t s) {
+  (void)nz;
+  const int blocks = cap_blocks((long long)nx * ny * nzl, 256, 8192);
+  hipLaunchKernelGGL(k_gen_bernoulli, dim3(blocks), dim3(256), 0, s, phase, nx, ny, z0, nzl, seed, thr53);
+}
+
+// spheres binned on the host into cells of edge `cell` half-voxels (>= radius); a voxel
+// tests the 27 cells around its own.
+__global__ void __launch_bounds__(256) k_gen_spheres(uint8_t* __restrict__ phase, int nx, int ny, int z0, int nzl,
+                                                      const int* __restrict__ centres,
+                                                      const int* __restrict__ cell_start, int ncx, int ncy, int ncz,
+                                                      int cell, int r2h) {
+  const long long n = (long long)nx * ny * nzl;
+  const long long rr = (long long)r2h * r2h;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n;
+       v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % nx), j = (int)((v / nx) % ny), kz = z0 + (int)(v / ((long long)nx * ny));
+    const int px = 2 * i + 1, py = 2 * j + 1, pz = 2 * kz + 1;
+    const int cx = px / cell, cy = py / cell, cz = pz / cell;
+    uint8_t pore = 1;
+    for (int dz = -1; dz <= 1 && pore; ++dz)
+      for (int dy = -1; dy <= 1 && pore; ++dy)
+        for (int dx = -1; dx <= 1 && pore; ++dx) {
+          const int ax = cx + dx, ay = cy + dy, az = cz + dz;
+          if (ax < 0 || ay < 0 || az < 0 || ax >= ncx || ay >= ncy || az >= ncz) continue;
+          const int c = ax + ncx * (ay + ncy * az);
+          for (int sidx = cell_start[c]; sidx < cell_start[c + 1]; ++sidx) {
+            const long long ddx = px - centres[3 * sidx], ddy = py - centres[3 * sidx + 1],
+                            ddz = pz - centres[3 * sidx + 2];
+            if (ddx * ddx + ddy * ddy + ddz * ddz < rr) { pore = 0; break; }
+          }
+        }
+    phase[v] = pore;
+  }
+}
+
+void launch_gen_spheres(uint8_t* phase, int nx, int ny, int nz, int z0, int nzl, const int* centres_dev,
+                        const int* cell_start_dev, int ncx, int ncy, int ncz, int cell, int r2h, hipStream_t s) {
+  (void)nz;
+  const int blocks = cap_blocks((long long)nx * ny * nzl, 256, 8192);
+  hipLaunchKernelGGL(k_gen_spheres, dim3(blocks), dim3(256), 0, s, phase, nx, ny, z0, nzl, centres_dev,
+                     cell_start_dev, ncx, ncy, ncz, cell, r2h);
+}
+
+// --------------------------------------------------------------------------------------
+// dense (host order, row pitch nx, owned planes only) <-> pitched / ghosted device layout
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pitch_in(Geom g, const double* __restrict__ dense, double* __restrict__ vec) {
+  const long long nown = (long long)g.nzl * g.plane;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nown;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % g.pitch);
+    const long long row = e / g.pitch;
+    vec[g.plane + e] = (i < g.nx) ? dense[row * g.nx + i] : 0.0;
+  }
+}
+__global__ void __launch_bounds__(256) k_pitch_out(Geom g, const double* __restrict__ vec, double* __restrict__ dense) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % g.nx);
+    const long long row = e / g.nx;
+    dense[e] = vec[g.plane + row * g.pitch + i];
+  }
+}
+__global__ void __launch_bounds__(256) k_codes_out(Geom g, const uint8_t* __restrict__ code, uint8_t* __restrict__ dense) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % g.nx);
+    const long long row = e / g.nx;
+    dense[e] = code[g.plane + row * g.pitch + i];
+  }
+}
+
+void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipStream_t s) {
+  hipLaunchKernelGGL(k_pitch_in, dim3(cap_blocks((long long)g.nzl * g.plane, 256, 8192)), dim3(256), 0, s, g, dense,
+                     vec);
+}
+void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipStream_t s) {
+  hipLaunchKernelGGL(k_pitch_out, dim3(cap_blocks((long long)g.nzl * g.ny * g.nx, 256, 8192)), dim3(256), 0, s, g,
+                     vec, dense);
+}
+void launch_codes_out(const Geom& g, const uint8_t* code, uint8_t* dense, hipStream_t s) {
+  hipLaunchKernelGGL(k_codes_out, dim3(cap_blocks((long long)g.nzl * g.ny * g.nx, 256, 8192)), dim3(256), 0, s, g,
+                     code, dense);
+}
+
+}  // namespace oi

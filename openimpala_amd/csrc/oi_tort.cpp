@@ -1,0 +1,984 @@
+// oi_tort.cpp -- host driver behind the C ABI (include/openimpala_amd.h): the MI355X
+// replacement for OpenImpala::TortuosityHypre (reference src/props/TortuosityHypre.cpp).
+//
+//   create : phase bytes -> open bits -> flood fill from both faces -> active mask ->
+//            code bytes (the matrix) ; TortuosityHypre ctor :100-191
+//   value  : CG on the Dirichlet-eliminated system entirely on the device (scalars stay
+//            in HBM, the host only polls a convergence flag) -> boundary fluxes -> tau ;
+//            value() :761-891, solve() :654-756, global_fluxes() :1000-1134
+//
+// There is NO CPU fallback: without a usable HIP device every entry point fails with
+// OI_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "oi_comm.h"
+#include "oi_device.h"
+
+namespace oi {
+const char* last_error();
+}
+using namespace oi;
+
+#define HIPC(call)                                                                       \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return OI_HIP_ERROR;                                                               \
+    }                                                                                    \
+  } while (0)
+#define OIC(call)                \
+  do {                           \
+    oi_status s_ = (call);       \
+    if (s_ != OI_OK) return s_;  \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static const char* kKernelNames[K_COUNT] = {
+    "pack_open", "seed", "flood_sweep", "mask_and", "codes", "init_field", "residual0", "apply",
+    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate"};
+
+struct ProfRec {
+  int kid;
+  hipEvent_t a, b;
+};
+
+struct oi_tort {
+  Geom g{};
+  oi_tort_opts opts{};
+  oi_comm* comm = nullptr;  // not owned
+  int phase_id = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  // device memory
+  uint64_t *open = nullptr, *active = nullptr /* reach_lo, then the mask */, *rhi = nullptr;
+  uint8_t* code = nullptr;
+  double *x = nullptr, *r = nullptr, *q = nullptr, *p[2] = {nullptr, nullptr};
+  double* partials = nullptr;
+  double* hist = nullptr;
+  Ctrl* ctrl = nullptr;
+  double* scal = nullptr;                // 8 doubles of scratch (flux sums)
+  unsigned long long* counters = nullptr;  // 8 u64
+  int* changed = nullptr;
+  // pinned host mirrors
+  Ctrl* h_ctrl = nullptr;
+  unsigned long long* h_counters = nullptr;
+  int* h_changed = nullptr;
+  double* h_scal = nullptr;
+  size_t bytes_device = 0;
+
+  // state
+  bool fused = true;
+  bool jacobi = false;
+  bool percolates = false;
+  bool vectors_ready = false;
+  bool cg_active = false;
+  bool solved = false;
+  int maxiter = 0;
+  int iters_issued = 0;
+  int iters_done = 0;
+  int hist_cap = 0;
+  double bnorm = 0.0;
+  long long n_lo = 0, n_hi = 0;
+  oi_tort_stats st{};
+  oi_status value_status = OI_OK;
+
+  // profiling
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+  double k_ms[K_COUNT] = {0};
+  long long k_n[K_COUNT] = {0};
+};
+
+// ---- profiling helpers -----------------------------------------------------------------
+static hipEvent_t prof_event(oi_tort* h) {
+  if (!h->ev_pool.empty()) {
+    hipEvent_t e = h->ev_pool.back();
+    h->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+static void prof_harvest(oi_tort* h) {
+  if (h->prof_pending.empty()) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& p : h->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      h->k_ms[p.kid] += ms;
+      h->k_n[p.kid] += 1;
+    }
+    h->ev_pool.push_back(p.a);
+    h->ev_pool.push_back(p.b);
+  }
+  h->prof_pending.clear();
+}
+struct ProfScope {
+  oi_tort* h;
+  ProfRec rec;
+  bool on;
+  ProfScope(oi_tort* h_, int kid) : h(h_), on(h_->opts.profile != 0) {
+    if (on) {
+      rec.kid = kid;
+      rec.a = prof_event(h);
+      rec.b = prof_event(h);
+      (void)hipEventRecord(rec.a, h->stream);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(rec.b, h->stream);
+      h->prof_pending.push_back(rec);
+      if (h->prof_pending.size() > 8192) prof_harvest(h);
+    }
+  }
+};
+#define PROF(kid) ProfScope prof_scope_(h, kid)
+
+// ---- small helpers ---------------------------------------------------------------------
+template <typename T>
+static oi_status dmalloc(oi_tort* h, T** p, size_t count) {
+  HIPC(hipMalloc((void**)p, count * sizeof(T)));
+  h->bytes_device += count * sizeof(T);
+  return OI_OK;
+}
+
+static oi_status ensure_device(int device, int* out_device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    oi::set_error("no HIP device visible: this library has no CPU fallback");
+    return OI_NO_DEVICE;
+  }
+  if (device >= 0) HIPC(hipSetDevice(device));
+  HIPC(hipGetDevice(out_device));
+  return OI_OK;
+}
+
+static void free_setup_buffers(oi_tort* h) {
+  if (h->open) { (void)hipFree(h->open); h->bytes_device -= sizeof(uint64_t) * h->g.nwords; h->open = nullptr; }
+  if (h->rhi) { (void)hipFree(h->rhi); h->bytes_device -= sizeof(uint64_t) * h->g.nwords; h->rhi = nullptr; }
+}
+
+extern "C" void oi_tort_destroy(oi_tort* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1],
+                 h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
+  for (void* d : dev)
+    if (d) (void)hipFree(d);
+  void* pin[] = {h->h_ctrl, h->h_counters, h->h_changed, h->h_scal};
+  for (void* d : pin)
+    if (d) (void)hipHostFree(d);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" void oi_tort_default_opts(oi_tort_opts* o) {
+  if (!o) return;
+  o->eps = 1e-9;  // reference default, TortuosityHypre.cpp:142
+  o->maxiter = 0;
+  o->precond = OI_PRECOND_NONE;
+  o->remspot_passes = 0;
+  o->verbose = 0;
+  o->check_every = 0;
+  o->kernel = OI_KERNEL_AUTO;
+  o->profile = 0;
+  o->device = -1;
+}
+
+// exchange one ghost plane pair of an array with `elem` bytes per voxel-slot
+static oi_status exchange_planes(oi_tort* h, void* base, size_t plane_bytes) {
+  if (!h->comm || h->comm->size == 1) return OI_OK;
+  char* b = (char*)base;
+  const Geom& g = h->g;
+  return h->comm->exchange(b + plane_bytes * 1, b + plane_bytes * 0, b + plane_bytes * (size_t)g.nzl,
+                           b + plane_bytes * (size_t)(g.nzl + 1), plane_bytes, h->stream);
+}
+
+// ---- construction ----------------------------------------------------------------------
+static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
+  Geom& g = h->g;
+  const double t0 = now_s();
+  HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  hipStream_t s = h->stream;
+
+  OIC(dmalloc(h, &h->open, (size_t)g.nwords));
+  OIC(dmalloc(h, &h->active, (size_t)g.nwords));
+  OIC(dmalloc(h, &h->rhi, (size_t)g.nwords));
+  OIC(dmalloc(h, &h->counters, 8));
+  OIC(dmalloc(h, &h->changed, 1));
+  OIC(dmalloc(h, &h->scal, 8));
+  OIC(dmalloc(h, &h->partials, (size_t)2 * kMaxPartials));
+  OIC(dmalloc(h, &h->ctrl, 1));
+  HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
+  HIPC(hipHostMalloc((void**)&h->h_counters, 8 * sizeof(unsigned long long)));
+  HIPC(hipHostMalloc((void**)&h->h_changed, sizeof(int)));
+  HIPC(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double)));
+  HIPC(hipMemsetAsync(h->open, 0, sizeof(uint64_t) * g.nwords, s));
+  HIPC(hipMemsetAsync(h->active, 0, sizeof(uint64_t) * g.nwords, s));
+  HIPC(hipMemsetAsync(h->rhi, 0, sizeof(uint64_t) * g.nwords, s));
+  HIPC(hipMemsetAsync(h->counters, 0, 8 * sizeof(unsigned long long), s));
+
+  // phase bytes -> open bits (+ phase voxel count)
+  const size_t nphase = (size_t)g.nx * g.ny * g.nzl;
+  const uint8_t* dphase = phase;
+  uint8_t* tmp = nullptr;
+  if (!on_device) {
+    HIPC(hipMalloc((void**)&tmp, nphase));
+    HIPC(hipMemcpyAsync(tmp, phase, nphase, hipMemcpyHostToDevice, s));
+    dphase = tmp;
+  }
+  { PROF(K_PACK); launch_pack_open(dphase, g, h->phase_id, h->open, &h->counters[3], s); }
+  HIPC(hipStreamSynchronize(s));
+  if (tmp) HIPC(hipFree(tmp));
+  h->st.t_upload_s = now_s() - t0;
+
+  // flood fill from both faces (generateActivityMask, TortuosityHypre.cpp:394-558)
+  const double t1 = now_s();
+  { PROF(K_SEED); launch_seed(g, h->open, h->active, h->rhi, s); }
+  const int sweeps_per_round = 8;
+  int sweeps = 0;
+  const long long max_rounds = 4LL * ((long long)g.nx + g.ny + g.nz) + 64;
+  for (long long round = 0; round < max_rounds; ++round) {
+    HIPC(hipMemsetAsync(h->changed, 0, sizeof(int), s));
+    OIC(exchange_planes(h, h->active, sizeof(uint64_t) * g.wplane));
+    OIC(exchange_planes(h, h->rhi, sizeof(uint64_t) * g.wplane));
+    for (int i = 0; i < sweeps_per_round; ++i) {
+      PROF(K_FLOOD);
+      launch_flood_sweep(g, h->open, h->active, h->rhi, h->changed, s);
+    }
+    sweeps += sweeps_per_round;
+    HIPC(hipMemcpyAsync(h->h_changed, h->changed, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    int ch = *h->h_changed;
+    if (h->comm) OIC(h->comm->allreduce_max_i32_host(&ch, 1, s));
+    if (!ch) break;
+  }
+  h->st.flood_sweeps = sweeps;
+  OIC(exchange_planes(h, h->active, sizeof(uint64_t) * g.wplane));
+  OIC(exchange_planes(h, h->rhi, sizeof(uint64_t) * g.wplane));
+  { PROF(K_MASK); launch_mask_and(g, h->active, h->rhi, h->counters, s); }
+  HIPC(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  unsigned long long cnt[4] = {h->h_counters[0], h->h_counters[1], h->h_counters[2], h->h_counters[3]};
+  if (h->comm) OIC(h->comm->allreduce_sum_u64_host(cnt, 4, s));
+  const double total = (double)g.nx * g.ny * g.nz;
+  h->st.n_active = (int64_t)cnt[0];
+  h->n_lo = (long long)cnt[1];
+  h->n_hi = (long long)cnt[2];
+  h->st.n_phase = (int64_t)cnt[3];
+  h->st.vf = (double)cnt[3] / total;
+  h->st.active_vf = (double)cnt[0] / total;  // TortuosityHypre.cpp:549-553
+  h->st.t_mask_s = now_s() - t1;
+  free_setup_buffers(h);
+  h->percolates = h->st.active_vf > std::numeric_limits<double>::epsilon();  // :170
+  h->st.tau = std::numeric_limits<double>::quiet_NaN();
+  if (!h->percolates) {
+    h->solved = true;  // value() returns NaN without solving (:170-178)
+    h->value_status = OI_NO_PERCOLATION;
+    return OI_OK;
+  }
+
+  // the matrix: one code byte per voxel
+  const double t2 = now_s();
+  OIC(dmalloc(h, &h->code, (size_t)g.nvec));
+  HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
+  HIPC(hipMemsetAsync(h->counters, 0, 8 * sizeof(unsigned long long), s));
+  { PROF(K_CODES); launch_codes(g, h->active, h->code, &h->counters[0], s); }
+  OIC(exchange_planes(h, h->code, (size_t)g.plane));
+  HIPC(hipMemcpyAsync(h->h_counters, h->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  unsigned long long nf = h->h_counters[0];
+  if (h->comm) OIC(h->comm->allreduce_sum_u64_host(&nf, 1, s));
+  h->st.n_free = (int64_t)nf;
+  // ||b|| of the reference's full system: vlo / vhi on the active Dirichlet-face cells
+  h->bnorm = std::sqrt((double)h->n_lo * g.vlo * g.vlo + (double)h->n_hi * g.vhi * g.vhi);
+
+  h->maxiter = h->opts.maxiter > 0 ? h->opts.maxiter : 40 * (g.nx + g.ny + g.nz);
+  h->hist_cap = h->maxiter + 2;
+  OIC(dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap));
+  OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+  OIC(dmalloc(h, &h->r, (size_t)g.nvec));
+  OIC(dmalloc(h, &h->q, (size_t)g.nvec));
+  OIC(dmalloc(h, &h->p[0], (size_t)g.nvec));
+  if (h->fused) OIC(dmalloc(h, &h->p[1], (size_t)g.nvec));
+  h->vectors_ready = true;
+  h->st.t_setup_s = now_s() - t2;
+  h->st.bytes_device = (double)h->bytes_device;
+  return OI_OK;
+}
+
+static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phase, bool on_device, int nx,
+                               int ny, int nz, int z0, int nzl, int phase_id, int dir, double vlo, double vhi,
+                               const oi_tort_opts* opts) {
+  if (!out) return OI_BAD_ARG;
+  *out = nullptr;
+  if (!phase || nx < 1 || ny < 1 || nz < 1 || nzl < 1 || z0 < 0 || z0 + nzl > nz || dir < 0 || dir > 2) {
+    oi::set_error("bad geometry/direction");
+    return OI_BAD_ARG;
+  }
+  oi_tort_opts o;
+  oi_tort_default_opts(&o);
+  if (opts) o = *opts;
+  if (!(o.eps > 0.0)) {  // AMREX_ALWAYS_ASSERT(m_eps > 0), TortuosityHypre.cpp:159
+    oi::set_error("eps must be positive");
+    return OI_BAD_ARG;
+  }
+  int device = 0;
+  OIC(ensure_device(comm ? comm->device : o.device, &device));
+  std::unique_ptr<oi_tort, void (*)(oi_tort*)> h(new oi_tort(), oi_tort_destroy);
+  h->opts = o;
+  h->comm = (comm && comm->size > 1) ? comm : nullptr;
+  h->device = device;
+  h->phase_id = phase_id;
+  h->jacobi = o.precond == OI_PRECOND_JACOBI;
+  h->fused = o.kernel != OI_KERNEL_UNFUSED;
+  Geom& g = h->g;
+  g.nx = nx; g.ny = ny; g.nz = nz; g.z0 = z0; g.nzl = nzl; g.dir = dir;
+  g.pitch = (nx + 1) & ~1;
+  g.W = (nx + 63) / 64;
+  g.plane = (long long)g.pitch * ny;
+  g.wplane = (long long)g.W * ny;
+  g.nvec = (long long)(nzl + 2) * g.plane;
+  g.nwords = (long long)(nzl + 2) * g.wplane;
+  g.vlo = vlo; g.vhi = vhi;
+  const oi_status st = build(h.get(), phase, on_device);
+  if (st != OI_OK) return st;
+  *out = h.release();
+  return OI_OK;
+}
+
+extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes);
+
+extern "C" oi_status oi_tort_create(oi_tort** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
+                                    int dir, double vlo, double vhi, const oi_tort_opts* opts) {
+  if (opts && opts->remspot_passes > 0 && phase && nx > 0 && ny > 0 && nz > 0) {
+    // preconditionPhaseFab (TortuosityHypre.cpp:248-292) works on the solver's private copy
+    std::vector<uint8_t> copy(phase, phase + (size_t)nx * ny * nz);
+    OIC(oi_remspot(copy.data(), nx, ny, nz, opts->remspot_passes));
+    return create_common(out, nullptr, copy.data(), false, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+  }
+  return create_common(out, nullptr, phase, false, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+}
+
+extern "C" oi_status oi_tort_create_device(oi_tort** out, const uint8_t* phase_dev, int nx, int ny, int nz,
+                                           int phase_id, int dir, double vlo, double vhi,
+                                           const oi_tort_opts* opts) {
+  if (opts && opts->remspot_passes > 0) {
+    oi::set_error("remspot needs the host entry point");
+    return OI_BAD_ARG;
+  }
+  return create_common(out, nullptr, phase_dev, true, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+}
+
+extern "C" oi_status oi_tort_create_slab(oi_tort** out, oi_comm* comm, const uint8_t* phase, int on_device,
+                                         int nx, int ny, int nz_global, int z0, int nz_local, int phase_id,
+                                         int dir, double vlo, double vhi, const oi_tort_opts* opts) {
+  if (opts && opts->remspot_passes > 0 && comm && comm->size > 1) {
+    oi::set_error("remspot is defined on the whole domain (sequential); run it before slabbing");
+    return OI_BAD_ARG;
+  }
+  return create_common(out, comm, phase, on_device != 0, nx, ny, nz_global, z0, nz_local, phase_id, dir, vlo, vhi,
+                       opts);
+}
+
+// ---- CG --------------------------------------------------------------------------------
+static oi_status reduce_to(oi_tort* h, int nblocks, int ncomp, double* dst, bool check, int iter_done) {
+  const bool multi = h->comm != nullptr;
+  {
+    PROF(K_FINALIZE);
+    launch_finalize(h->partials, nblocks, ncomp, dst, h->ctrl, (check && !multi) ? 1 : 0, iter_done, h->stream);
+  }
+  if (multi) {
+    OIC(h->comm->allreduce_sum_f64(dst, ncomp, h->stream));
+    if (check) launch_check_done(dst, h->ctrl, iter_done, h->stream);
+  }
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
+  if (!h) return OI_BAD_ARG;
+  if (!h->percolates || !h->vectors_ready) return OI_NO_PERCOLATION;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  hipStream_t s = h->stream;
+  Ctrl c;
+  c.done = 0; c.pad = 0;
+  c.tol2 = (h->opts.eps * h->bnorm) * (h->opts.eps * h->bnorm);
+  *h->h_ctrl = c;
+  HIPC(hipMemcpyAsync(h->ctrl, h->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+  HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * h->hist_cap, s));
+  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, s));
+  HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
+  HIPC(hipMemsetAsync(h->p[0], 0, sizeof(double) * g.nvec, s));
+  if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, sizeof(double) * g.nvec, s));
+  { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
+  int nb;
+  { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, h->p[0], h->jacobi, h->partials, s); }
+  // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
+  OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
+  if (h->fused) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+  h->iters_issued = 0;
+  h->iters_done = 0;
+  h->cg_active = true;
+  return OI_OK;
+}
+
+static oi_status cg_one_iteration(oi_tort* h, int k) {
+  const Geom& g = h->g;
+  hipStream_t s = h->stream;
+  int nb;
+  if (h->fused) {
+    double* p_in = h->p[(k + 1) & 1];
+    double* p_out = h->p[k & 1];
+    {
+      PROF(K_FUSED_A);
+      nb = launch_fused_a(g, h->code, h->x, h->r, p_in, p_out, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s);
+    }
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
+    { PROF(K_UPDATE_R); nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
+    OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
+    OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+  } else {
+    if (k > 0) {
+      PROF(K_UPDATE_P);
+      launch_update_p(g, h->code, h->r, h->p[0], h->jacobi, h->hist, k, h->ctrl, s);
+    }
+    OIC(exchange_planes(h, h->p[0], sizeof(double) * g.plane));
+    { PROF(K_APPLY); nb = launch_apply(g, h->code, h->p[0], h->q, h->partials, h->ctrl, s); }
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
+    {
+      PROF(K_UPDATE_XR);
+      nb = launch_update_xr(g, h->code, h->x, h->r, h->p[0], h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s);
+    }
+    OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
+  }
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_cg_iterate(oi_tort* h, int n) {
+  if (!h || n < 0) return OI_BAD_ARG;
+  if (!h->cg_active) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  for (int i = 0; i < n; ++i) {
+    if (h->iters_issued >= h->maxiter) break;
+    OIC(cg_one_iteration(h, h->iters_issued));
+    ++h->iters_issued;
+  }
+  return OI_OK;
+}
+
+// reads the device control block; updates iters_done / converged
+static oi_status poll_ctrl(oi_tort* h) {
+  HIPC(hipMemcpyAsync(h->h_ctrl, h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
+  if (!h || !h->cg_active) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  OIC(poll_ctrl(h));
+  const int done = h->h_ctrl->done;
+  const int K = done ? done - 1 : h->iters_issued;  // iterations whose x/r updates are in effect
+  if (h->fused && K > 0) {
+    // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
+    PROF(K_AXPY);
+    launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->hist, K - 1, h->stream);
+  }
+  double rr = 0.0;
+  HIPC(hipMemcpyAsync(h->h_scal, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  rr = h->h_scal[0];
+  h->iters_done = K;
+  h->st.iterations = K;
+  h->st.final_relres = h->bnorm > 0.0 ? std::sqrt(rr) / h->bnorm : std::sqrt(rr);
+  // converged <=> finite and 0 <= relres <= eps  (TortuosityHypre.cpp:685-688)
+  h->st.converged = done != 0 && std::isfinite(h->st.final_relres) && h->st.final_relres <= h->opts.eps;
+  h->cg_active = false;
+  if (h->opts.profile) prof_harvest(h);
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_set_eps(oi_tort* h, double eps) {
+  if (!h || !(eps > 0.0)) return OI_BAD_ARG;
+  if (h->cg_active) return OI_BAD_ARG;
+  h->opts.eps = eps;
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_sync(oi_tort* h) {
+  if (!h) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipStreamSynchronize(h->stream));
+  if (h->opts.profile) prof_harvest(h);
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int* converged) {
+  if (!h || !h->vectors_ready) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  OIC(poll_ctrl(h));
+  const int done = h->h_ctrl->done;
+  const int K = done ? done - 1 : h->iters_issued;
+  HIPC(hipMemcpyAsync(h->h_scal, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  if (iterations_done) *iterations_done = K;
+  if (relres) *relres = h->bnorm > 0.0 ? std::sqrt(h->h_scal[0]) / h->bnorm : std::sqrt(h->h_scal[0]);
+  if (converged) *converged = done != 0;
+  return OI_OK;
+}
+
+static oi_status solve(oi_tort* h) {
+  const double t0 = now_s();
+  OIC(oi_tort_cg_begin(h));
+  int batch = h->opts.check_every > 0 ? h->opts.check_every : 32;
+  hipEvent_t ev[2];
+  HIPC(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  // pinned landing pads for the two in-flight polls
+  Ctrl* land = nullptr;
+  HIPC(hipHostMalloc((void**)&land, 2 * sizeof(Ctrl)));
+  land[0].done = land[1].done = 0;
+  int nb = 0;
+  bool stop = false;
+  oi_status rc = OI_OK;
+  // initial check (converged before iterating)
+  rc = poll_ctrl(h);
+  if (rc == OI_OK && h->h_ctrl->done) stop = true;
+  while (rc == OI_OK && !stop && h->iters_issued < h->maxiter) {
+    rc = oi_tort_cg_iterate(h, batch);
+    if (rc != OI_OK) break;
+    const int slot = nb & 1;
+    if (hipMemcpyAsync(&land[slot], h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipEventRecord(ev[slot], h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+    if (nb > 0) {  // look at the PREVIOUS batch while this one runs
+      if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+      if (land[slot ^ 1].done) stop = true;
+    }
+    ++nb;
+    if (h->opts.verbose > 1 && (nb % 16) == 0) {
+      fprintf(stderr, "[openimpala_amd] issued %d CG iterations\n", h->iters_issued);
+    }
+  }
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  (void)hipHostFree(land);
+  if (rc != OI_OK) return rc;
+  OIC(oi_tort_cg_finish(h));
+  h->st.t_solve_s = now_s() - t0;
+  return OI_OK;
+}
+
+static oi_status fluxes(oi_tort* h) {
+  const double t0 = now_s();
+  OIC(exchange_planes(h, h->x, sizeof(double) * h->g.plane));
+  { PROF(K_FLUX); launch_flux(h->g, h->active, h->x, h->partials, h->scal, h->stream); }
+  if (h->comm) OIC(h->comm->allreduce_sum_f64(h->scal, 2, h->stream));
+  HIPC(hipMemcpyAsync(h->h_scal, h->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  h->st.flux_in = h->h_scal[0] * 1.0;  // face_area_element = dx*dx = 1 (TortuosityHypre.cpp:1123-1133)
+  h->st.flux_out = h->h_scal[1] * 1.0;
+  h->st.t_flux_s = now_s() - t0;
+  return OI_OK;
+}
+
+// TortuosityHypre::value (TortuosityHypre.cpp:761-891)
+extern "C" oi_status oi_tort_value(oi_tort* h, int refresh, double* tau) {
+  if (!h || !tau) return OI_BAD_ARG;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  const double inf = std::numeric_limits<double>::infinity();
+  *tau = nan;
+  if (!h->percolates) {  // :764-777
+    h->st.tau = nan;
+    return OI_NO_PERCOLATION;
+  }
+  if (h->solved && !refresh) {
+    *tau = h->st.tau;
+    return h->value_status;
+  }
+  HIPC(hipSetDevice(h->device));
+  OIC(solve(h));
+  h->solved = true;
+  const Geom& g = h->g;
+  if (!h->st.converged) {  // :782-787
+    if (h->opts.verbose >= 1)
+      fprintf(stderr, "[openimpala_amd] WARNING: solver did not converge (%d iterations, relres %.3e)\n",
+              h->st.iterations, h->st.final_relres);
+    h->st.tau = nan;
+    h->value_status = OI_NOT_CONVERGED;
+    return h->value_status;
+  }
+  OIC(fluxes(h));
+  constexpr double tiny = 1.e-15;    // tiny_flux_threshold, :64
+  constexpr double flux_tol = 1.e-6;  // :794
+  const double fin = std::abs(h->st.flux_in), fout = std::abs(h->st.flux_out);
+  const double avg = 0.5 * (fin + fout);
+  if (avg > tiny && std::abs(fin - fout) / avg > flux_tol) {  // :800-823
+    if (h->opts.verbose >= 1) fprintf(stderr, "[openimpala_amd] WARNING: flux not conserved\n");
+    h->st.tau = nan;
+    h->value_status = OI_FLUX_NOT_CONSERVED;
+    return h->value_status;
+  }
+  const double nd[3] = {(double)g.nx, (double)g.ny, (double)g.nz};
+  const double L = nd[g.dir];  // ProbLength: the RealBox is [0,N] per axis (Diffusion.cpp:302-305)
+  const double A = g.dir == 0 ? nd[1] * nd[2] : (g.dir == 1 ? nd[0] * nd[2] : nd[0] * nd[1]);
+  const double grad = (g.vhi - g.vlo) / L;  // :841
+  double value;
+  h->st.deff = 0.0;
+  if (avg < tiny) value = inf;                 // :846-852
+  else if (std::abs(grad) < tiny) value = inf;  // :860-865
+  else {
+    const double deff = (avg / A) / std::abs(grad);  // :868
+    h->st.deff = deff;
+    value = std::abs(deff) < tiny ? inf : h->st.active_vf / deff;  // :869-876
+  }
+  h->st.tau = value;
+  h->value_status = OI_OK;
+  *tau = value;
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_get_stats(const oi_tort* h, oi_tort_stats* st) {
+  if (!h || !st) return OI_BAD_ARG;
+  *st = h->st;
+  st->bytes_device = (double)h->bytes_device;
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_get_solution(oi_tort* h, double* phi) {
+  if (!h || !phi) return OI_BAD_ARG;
+  if (!h->vectors_ready) return OI_NO_PERCOLATION;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const size_t n = (size_t)g.nx * g.ny * g.nzl;
+  double* dense = nullptr;
+  HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
+  launch_pitch_copy_out(g, h->x, dense, h->stream);
+  hipError_t e = hipMemcpyAsync(phi, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dense);
+  HIPC(e);
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_get_mask(oi_tort* h, uint8_t* mask) {
+  if (!h || !mask) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const size_t n = (size_t)g.nx * g.ny * g.nzl;
+  uint8_t* dense = nullptr;
+  HIPC(hipMalloc((void**)&dense, n));
+  launch_unpack_mask(g, h->active, dense, h->stream);
+  hipError_t e = hipMemcpyAsync(mask, dense, n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dense);
+  HIPC(e);
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes) {
+  if (!h || !codes) return OI_BAD_ARG;
+  if (!h->vectors_ready) return OI_NO_PERCOLATION;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const size_t n = (size_t)g.nx * g.ny * g.nzl;
+  uint8_t* dense = nullptr;
+  HIPC(hipMalloc((void**)&dense, n));
+  launch_codes_out(g, h->code, dense, h->stream);
+  hipError_t e = hipMemcpyAsync(codes, dense, n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dense);
+  HIPC(e);
+  return OI_OK;
+}
+
+// q = A v with either stencil kernel; uses p[0] / q as scratch, so only outside a solve
+extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q, int variant) {
+  if (!h || !v || !q) return OI_BAD_ARG;
+  if (!h->vectors_ready) return OI_NO_PERCOLATION;
+  if (h->cg_active) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const size_t n = (size_t)g.nx * g.ny * g.nzl;
+  double* dense = nullptr;
+  HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
+  oi_status rc = OI_OK;
+  do {
+    if (hipMemcpyAsync(dense, v, n * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemsetAsync(h->p[0], 0, sizeof(double) * g.nvec, h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+    launch_pitch_copy_in(g, dense, h->p[0], h->stream);
+    rc = exchange_planes(h, h->p[0], sizeof(double) * g.plane);
+    if (rc != OI_OK) break;
+    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
+    else launch_apply_tiled(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
+    launch_pitch_copy_out(g, h->q, dense, h->stream);
+    if (hipMemcpyAsync(q, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) rc = OI_HIP_ERROR;
+  } while (0);
+  (void)hipFree(dense);
+  if (rc == OI_HIP_ERROR) oi::set_error("debug_apply: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  return rc;
+}
+
+extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_launch) {
+  if (!h || reps < 1 || !ms_per_launch) return OI_BAD_ARG;
+  if (!h->vectors_ready) return OI_NO_PERCOLATION;
+  if (h->cg_active) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  // a smooth non-trivial field: the ramp (p = x0); one untimed launch warms the code path
+  launch_init_field(g, h->active, h->p[0], h->stream);
+  hipEvent_t a, b;
+  HIPC(hipEventCreate(&a));
+  HIPC(hipEventCreate(&b));
+  for (int i = -1; i < reps; ++i) {
+    if (i == 0) HIPC(hipEventRecord(a, h->stream));
+    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
+    else launch_apply_tiled(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
+  }
+  HIPC(hipEventRecord(b, h->stream));
+  HIPC(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *ms_per_launch = (double)ms / reps;
+  return OI_OK;
+}
+
+// checkMatrixProperties (TortuosityHypre.cpp:896-982) for the matrix-free operator: the
+// stored code of every voxel must equal the row the reference would assemble:
+//   inactive or Dirichlet cell -> identity row (code 0); the Dirichlet right-hand side
+//   vlo/vhi is the value init_field stores; active interior cell -> diagonal = #active
+//   neighbours > 0 and off-diagonals -1 on exactly those neighbours (row sum 0).
+// Implemented by regenerating the codes from the mask into scratch and comparing.
+extern "C" oi_status oi_tort_check_matrix_properties(oi_tort* h, int64_t* n_violations) {
+  if (!h || !n_violations) return OI_BAD_ARG;
+  *n_violations = 0;
+  if (!h->vectors_ready) return OI_NO_PERCOLATION;
+  if (h->cg_active) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const size_t n = (size_t)g.nx * g.ny * g.nzl;
+  std::vector<uint8_t> code(n), mask(n);
+  OIC(oi_tort_debug_get_codes(h, code.data()));
+  OIC(oi_tort_get_mask(h, mask.data()));
+  // ghost-aware neighbour test needs the neighbouring slabs' boundary planes
+  std::vector<uint8_t> lo((size_t)g.nx * g.ny, 0), hi((size_t)g.nx * g.ny, 0);
+  if (h->comm) {
+    // ghost planes of the active bits were exchanged during construction: unpack them
+    Geom gg = g;
+    uint8_t* dense = nullptr;
+    HIPC(hipMalloc((void**)&dense, (size_t)g.nx * g.ny));
+    gg.nzl = 1;
+    // plane 0 (lo ghost): unpack by shifting the base pointer one plane down
+    launch_unpack_mask(gg, h->active - g.wplane, dense, h->stream);
+    HIPC(hipMemcpyAsync(lo.data(), dense, lo.size(), hipMemcpyDeviceToHost, h->stream));
+    launch_unpack_mask(gg, h->active + (long long)g.nzl * g.wplane, dense, h->stream);
+    HIPC(hipMemcpyAsync(hi.data(), dense, hi.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    (void)hipFree(dense);
+  }
+  const int nd[3] = {g.nx, g.ny, g.nz};
+  long long bad = 0;
+  const long long sx = 1, sy = g.nx, sz = (long long)g.nx * g.ny;
+  for (int k = 0; k < g.nzl; ++k)
+    for (int j = 0; j < g.ny; ++j)
+      for (int i = 0; i < g.nx; ++i) {
+        const long long m = i + sy * j + sz * k;
+        const int c[3] = {i, j, g.z0 + k};
+        const bool act = mask[m] != 0;
+        const bool dirichlet = act && (c[g.dir] == 0 || c[g.dir] == nd[g.dir] - 1);
+        if (!act || dirichlet) { bad += code[m] != 0; continue; }
+        int cnt = 0;
+        cnt += (i > 0 && mask[m - sx]) + (i < g.nx - 1 && mask[m + sx]);
+        cnt += (j > 0 && mask[m - sy]) + (j < g.ny - 1 && mask[m + sy]);
+        cnt += (k > 0 ? mask[m - sz] : lo[i + sy * j]) != 0;
+        cnt += (k < g.nzl - 1 ? mask[m + sz] : hi[i + sy * j]) != 0;
+        if (cnt <= 0 || code[m] != cnt) ++bad;  // Aii > 0 and zero row sum
+      }
+  unsigned long long b = (unsigned long long)bad;
+  if (h->comm) OIC(h->comm->allreduce_sum_u64_host(&b, 1, h->stream));
+  *n_violations = (int64_t)b;
+  return OI_OK;
+}
+
+extern "C" int oi_tort_kernel_times(oi_tort* h, int cap, int* kernel_ids, double* total_ms, int64_t* launches) {
+  if (!h) return 0;
+  prof_harvest(h);
+  int n = 0;
+  for (int k = 0; k < K_COUNT && n < cap; ++k) {
+    if (h->k_n[k] == 0) continue;
+    kernel_ids[n] = k;
+    total_ms[n] = h->k_ms[k];
+    launches[n] = h->k_n[k];
+    ++n;
+  }
+  return n;
+}
+extern "C" const char* oi_kernel_name(int kid) { return (kid >= 0 && kid < K_COUNT) ? kKernelNames[kid] : "?"; }
+extern "C" void oi_tort_reset_kernel_times(oi_tort* h) {
+  if (!h) return;
+  prof_harvest(h);
+  for (int k = 0; k < K_COUNT; ++k) { h->k_ms[k] = 0; h->k_n[k] = 0; }
+}
+
+// ---- stand-alone helpers ---------------------------------------------------------------
+extern "C" oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phase_id, int64_t* phase_count,
+                                        int64_t* total_count) {
+  if (!phase || !phase_count || !total_count) return OI_BAD_ARG;
+  int device = 0;
+  OIC(ensure_device(-1, &device));
+  *total_count = (int64_t)n;
+  *phase_count = 0;
+  if (n == 0) return OI_OK;
+  // treat the array as rows of up to 2^20 voxels
+  Geom g{};
+  g.nx = (int)std::min<size_t>(n, (size_t)1 << 20);
+  const size_t rows = n / g.nx;
+  g.ny = 1; g.nz = (int)rows; g.nzl = (int)rows; g.z0 = 0;
+  g.W = (g.nx + 63) / 64; g.wplane = g.W; g.nwords = (long long)(g.nzl + 2) * g.wplane;
+  uint8_t* d = nullptr;
+  uint64_t* bits = nullptr;
+  unsigned long long* cnt = nullptr;
+  HIPC(hipMalloc((void**)&d, n));
+  HIPC(hipMalloc((void**)&bits, sizeof(uint64_t) * g.nwords));
+  HIPC(hipMalloc((void**)&cnt, sizeof(unsigned long long)));
+  HIPC(hipMemset(cnt, 0, sizeof(unsigned long long)));
+  HIPC(hipMemcpy(d, phase, n, hipMemcpyHostToDevice));
+  launch_pack_open(d, g, phase_id, bits, cnt, nullptr);
+  unsigned long long c = 0;
+  HIPC(hipMemcpy(&c, cnt, sizeof(c), hipMemcpyDeviceToHost));
+  // tail that does not fill a row
+  for (size_t v = rows * g.nx; v < n; ++v) c += phase[v] == (uint8_t)phase_id;
+  (void)hipFree(d); (void)hipFree(bits); (void)hipFree(cnt);
+  *phase_count = (int64_t)c;
+  return OI_OK;
+}
+
+// tortuosity_remspot (Tortuosity_filcc.F90:88-177): in place, x-fastest order, one box.
+extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes) {
+  if (!q || nx < 1 || ny < 1 || nz < 1) return OI_BAD_ARG;
+  const long long sy = nx, sz = (long long)nx * ny;
+  for (int pass = 0; pass < passes; ++pass)
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+          const long long m = i + sy * j + sz * k;
+          const uint8_t c = q[m];
+          const bool connected = (i > 0 && q[m - 1] == c) || (i < nx - 1 && q[m + 1] == c) ||
+                                 (j > 0 && q[m - sy] == c) || (j < ny - 1 && q[m + sy] == c) ||
+                                 (k > 0 && q[m - sz] == c) || (k < nz - 1 && q[m + sz] == c);
+          if (!connected) q[m] = (c == 0) ? 1 : 0;
+        }
+  return OI_OK;
+}
+
+extern "C" oi_status oi_gen_bernoulli_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
+                                             int nz_local, uint64_t seed, uint64_t thr53) {
+  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1) return OI_BAD_ARG;
+  launch_gen_bernoulli(phase_dev, nx, ny, nz_global, z0, nz_local, seed, thr53, nullptr);
+  HIPC(hipGetLastError());
+  HIPC(hipDeviceSynchronize());
+  return OI_OK;
+}
+
+static inline uint64_t mix64_host(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+extern "C" oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
+                                           int nz_local, uint64_t seed, int nspheres, int r2h) {
+  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1 || nspheres < 0 || r2h < 1) return OI_BAD_ARG;
+  // centres in half-voxel units (same draw as the oracle), binned into cubic cells >= radius
+  const int cell = std::max(r2h, 8);
+  const int ncx = (2 * nx) / cell + 1, ncy = (2 * ny) / cell + 1, ncz = (2 * nz_global) / cell + 1;
+  std::vector<int> c(3 * (size_t)std::max(nspheres, 1));
+  std::vector<int> cell_of(nspheres);
+  std::vector<int> start((size_t)ncx * ncy * ncz + 1, 0);
+  for (int s = 0; s < nspheres; ++s) {
+    c[3 * s + 0] = (int)(mix64_host(seed * 0xD1342543DE82EF95ULL + 3ULL * s + 0) % (uint64_t)(2 * nx));
+    c[3 * s + 1] = (int)(mix64_host(seed * 0xD1342543DE82EF95ULL + 3ULL * s + 1) % (uint64_t)(2 * ny));
+    c[3 * s + 2] = (int)(mix64_host(seed * 0xD1342543DE82EF95ULL + 3ULL * s + 2) % (uint64_t)(2 * nz_global));
+    cell_of[s] = c[3 * s] / cell + ncx * (c[3 * s + 1] / cell + ncy * (c[3 * s + 2] / cell));
+    ++start[cell_of[s] + 1];
+  }
+  for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+  std::vector<int> fill(start.begin(), start.end() - 1), sorted(3 * (size_t)std::max(nspheres, 1));
+  for (int s = 0; s < nspheres; ++s) {
+    const int d = fill[cell_of[s]]++;
+    sorted[3 * d] = c[3 * s]; sorted[3 * d + 1] = c[3 * s + 1]; sorted[3 * d + 2] = c[3 * s + 2];
+  }
+  int *dc = nullptr, *ds = nullptr;
+  HIPC(hipMalloc((void**)&dc, sizeof(int) * sorted.size()));
+  HIPC(hipMalloc((void**)&ds, sizeof(int) * start.size()));
+  HIPC(hipMemcpy(dc, sorted.data(), sizeof(int) * sorted.size(), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ds, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+  launch_gen_spheres(phase_dev, nx, ny, nz_global, z0, nz_local, dc, ds, ncx, ncy, ncz, cell, r2h, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  (void)hipFree(dc); (void)hipFree(ds);
+  HIPC(e);
+  return OI_OK;
+}
+
+extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
+  if (!ptr) return OI_BAD_ARG;
+  int device = 0;
+  OIC(ensure_device(-1, &device));
+  HIPC(hipMalloc(ptr, bytes));
+  return OI_OK;
+}
+extern "C" oi_status oi_dev_free(void* ptr) { HIPC(hipFree(ptr)); return OI_OK; }
+extern "C" oi_status oi_dev_upload(void* dst, const void* src, size_t bytes) {
+  HIPC(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return OI_OK;
+}
+extern "C" oi_status oi_dev_download(void* dst, const void* src, size_t bytes) {
+  HIPC(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return OI_OK;
+}
+extern "C" int oi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" const char* oi_last_error(void) { return oi::last_error(); }
+extern "C" const char* oi_status_string(oi_status s) {
+  switch (s) {
+    case OI_OK: return "ok";
+    case OI_BAD_ARG: return "bad argument";
+    case OI_NO_PERCOLATION: return "no percolating path (active volume fraction is zero)";
+    case OI_NOT_CONVERGED: return "solver did not converge";
+    case OI_FLUX_NOT_CONSERVED: return "flux not conserved";
+    case OI_HIP_ERROR: return "HIP error";
+    case OI_RCCL_ERROR: return "RCCL error";
+    case OI_NO_DEVICE: return "no HIP device";
+    case OI_IO_ERROR: return "I/O error";
+  }
+  return "?";
+}
+extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
+extern "C" void oi_tort_set_tuning(int fused_by, int fused_zchunk) { oi::set_fused_tuning(fused_by, fused_zchunk); }

@@ -33,10 +33,33 @@ def build(force=False):
     return _LIB_PATH
 
 
+def cpu_budget(cap=16):
+    """Threads the oracle may use: the smaller of the affinity mask, the cgroup CPU quota
+    and `cap` (a GPU box exposes all host cores but grants ~16; oversubscribed OpenMP
+    barriers would crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        n = min(n, int(os.environ["OMP_NUM_THREADS"]))
+    return max(1, min(n, cap))
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before libgomp initialises
         L = C.CDLL(_LIB_PATH)
         i, ll, d, u64 = C.c_int, C.c_longlong, C.c_double, C.c_uint64
         L.oi_oracle_num_threads.restype = i
@@ -65,6 +88,7 @@ def lib():
                                        C.POINTER(ll), C.POINTER(ll)]
         L.oi_oracle_tau.argtypes = [d, i, d, d, i, i, i, i, d, d, C.POINTER(d), C.POINTER(i)]
         L.oi_oracle_tau.restype = d
+        L.oi_oracle_set_threads(cpu_budget())
         _lib = L
     return _lib
 

@@ -1,0 +1,86 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/openimpala_amd.h declares, and refuses to compute without a GPU (no fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import openimpala_amd as oia
+
+from conftest import ROOT, GOLDEN
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "openimpala_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_agree():
+    assert _declared_symbols() == sorted(oia.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = oia.lib()
+    for name in _declared_symbols():
+        assert hasattr(L, name), name
+    assert L.oi_abi_version() == oia.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    # sizes as the C compiler lays the structs out (natural alignment, no packing)
+    assert oia.Opts.__dict__ is not None
+    import ctypes as C
+    assert C.sizeof(oia.Opts) == 40
+    assert C.sizeof(oia.Stats) == 8 + 7 * 8 + 3 * 8 + 8 + 5 * 8 + 8
+
+
+@pytest.mark.skipif(oia.lib().oi_device_count() > 0, reason="GPU present")
+def test_no_gpu_means_loud_failure_not_fallback():
+    ph = np.ones((4, 4, 4), np.uint8)
+    with pytest.raises(oia.OpenImpalaError) as e:
+        oia.TortuosityMI355(ph, 1, oia.Direction.X)
+    assert e.value.status == oia.OI_NO_DEVICE
+    with pytest.raises(oia.OpenImpalaError):
+        oia.VolumeFraction(ph, 1).value()
+
+
+def test_tiff_reader_matches_oracle_reader():
+    """The readers are host code: TiffReader dims/bps as tTiffReader.cpp:98-103 asserts,
+    voxels identical to the oracle's independent numpy decoder."""
+    from oracle import oracle as o
+    tif = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")
+    r = oia.TiffReader(tif)
+    ph = r.threshold(0.5)
+    assert (r.width(), r.height(), r.depth(), r.bitsPerSample()) == (100, 100, 100, 1)
+    assert np.array_equal(ph, o.read_tiff_phase(tif))
+    assert np.array_equal(oia.TiffReader(tif).threshold(1.5), np.zeros_like(ph))
+
+
+def test_raw_reader_types(tmp_path):
+    rng = np.random.default_rng(0)
+    vals = rng.integers(0, 60000, size=(3, 4, 5))
+    for name, dt in (("UINT16_LE", "<u2"), ("UINT16_BE", ">u2"), ("INT32_BE", ">i4"), ("FLOAT32_LE", "<f4"),
+                     ("FLOAT64_BE", ">f8"), ("UINT8", "u1")):
+        a = (vals % 200 if name == "UINT8" else vals).astype(dt)
+        p = tmp_path / f"{name}.raw"
+        a.tofile(p)
+        got = oia.RawReader(str(p), 5, 4, 3, name).threshold(100.0)
+        assert np.array_equal(got, (a.astype(np.float64) > 100.0).astype(np.uint8)), name
+    with pytest.raises(oia.OpenImpalaError):
+        oia.RawReader(str(p), 5, 4, 4, "UINT8").threshold(1.0)  # size mismatch
+
+
+def test_remspot_matches_oracle():
+    from oracle import oracle as o
+    ph = o.gen_bernoulli((12, 10, 14), 5, 0.5)
+    assert np.array_equal(oia.remspot(ph, 2), o.remspot(ph, 2))
+
+
+def test_slab_ranges_cover_the_volume():
+    for nz, n in ((100, 8), (7, 3), (1024, 8), (5, 5)):
+        spans = [oia.slab_range(nz, n, r) for r in range(n)]
+        assert spans[0][0] == 0 and spans[-1][1] == nz
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all(z1 > z0 for z0, z1 in spans)

@@ -1,0 +1,187 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+inputs, the committed golden table, and size-independent properties at large sizes.
+
+Tolerances: integer/byte/index work (masks, codes, counts, generators) bit-exact; the
+single-kernel stencil apply bit-exact (same rounding order, -ffp-contract=off); whole
+solves within 1e-7 relative on tau / flux / D_eff, i.e. 100x tighter than the 1e-5 the
+north star asks for, because two converged CG runs differ only by reduction order.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import openimpala_amd as oia
+from oracle import oracle as o
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TIF = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")
+VARIANTS = [oia.KERNEL_FUSED, oia.KERNEL_UNFUSED]
+
+
+@pytest.fixture(scope="module")
+def sample():
+    return oia.TiffReader(TIF).threshold(0.5)
+
+
+def test_volume_fraction_goldens(sample, goldens):
+    for pid in (0, 1):
+        pc, tc = oia.VolumeFraction(sample, pid).value()
+        assert (pc, tc) == (goldens["phases"][str(pid)]["voxels"], 10 ** 6)
+    odd = o.gen_bernoulli((7, 9, 1031), 3, 0.3)  # ragged: exercises the row tail
+    assert oia.VolumeFraction(odd, 1).value() == o.volume_fraction(odd, 1)
+
+
+@pytest.mark.parametrize("pid", [0, 1])
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_sample_goldens(sample, goldens, pid, direction):
+    """BASELINE.json config 1: the bundled 100^3 TIFF against the golden table."""
+    g = goldens["phases"][str(pid)]
+    t = oia.TortuosityMI355(sample, pid, direction, g["vlo"], g["vhi"], eps=1e-10)
+    assert t.checkMatrixProperties()
+    tau = t.value()
+    st = t.stats()
+    assert t.status == oia.OI_OK and st.converged
+    assert st.n_phase == g["voxels"]
+    assert st.active_vf == pytest.approx(g["active_vf"], abs=5e-7)
+    assert st.n_free == g["free_unknowns"][direction]
+    assert st.flux_in == pytest.approx(g["flux"][direction], rel=1e-7)
+    assert st.flux_out == pytest.approx(g["flux"][direction], rel=1e-7)
+    assert st.deff == pytest.approx(g["deff"][direction], rel=1e-7)
+    assert tau == pytest.approx(g["tau"][direction], rel=1e-7)
+    assert abs(abs(st.flux_in) - abs(st.flux_out)) / abs(st.flux_in) <= 1e-6
+    t.destroy()
+
+
+def test_reference_default_tolerance_meets_1e5(sample, goldens):
+    """hypre.eps = 1e-9 (the reference default) already gives tau within 1e-5 of the goldens."""
+    g = goldens["phases"]["1"]
+    t = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"])
+    assert t.value() == pytest.approx(g["tau"][0], rel=1e-5)
+    assert t.getSolverConverged() and t.getFinalRelativeResidualNorm() <= 1e-9
+
+
+@pytest.mark.parametrize("shape", [(20, 24, 28), (33, 17, 129), (16, 40, 200), (9, 8, 7)])
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_mask_codes_apply_bit_exact(shape, direction):
+    """mask, matrix codes and both stencil kernels against the oracle, ragged shapes
+    (odd nx -> padded pitch, nx > one 128-wide tile, nx not a multiple of 64)."""
+    phase = o.gen_bernoulli(shape, 11 + direction, 0.6)
+    mask, nact = o.active_mask(phase, 1, direction)
+    if nact == 0:
+        pytest.skip("no percolation for this seed")
+    t = oia.TortuosityMI355(phase, 1, direction, -1.0, 1.0)
+    assert np.array_equal(t.mask(), mask)
+    code = o.codes(mask, direction)
+    assert np.array_equal(t.codes(), code)
+    assert t.stats().n_active == nact and t.stats().n_free == np.count_nonzero(code)
+    assert t.checkMatrixProperties()
+    rng = np.random.default_rng(5)
+    v = np.where(mask > 0, rng.standard_normal(shape), 0.0)  # vectors vanish on inactive cells
+    want = o.apply(code, v)
+    for variant in VARIANTS:
+        got = t.apply(v, variant)
+        assert np.array_equal(got, want), f"variant {variant}"
+    t.destroy()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("jacobi", [False, True])
+def test_solve_matches_oracle(sample, variant, jacobi):
+    sub = np.ascontiguousarray(sample[10:58, 20:60, 30:93])
+    for direction in range(3):
+        ref = o.tortuosity(sub, 0, direction, 0.0, 1.0, eps=1e-11, jacobi=jacobi)
+        t = oia.TortuosityMI355(sub, 0, direction, 0.0, 1.0, eps=1e-11, kernel=variant,
+                                precond=oia.PRECOND_JACOBI if jacobi else oia.PRECOND_NONE)
+        tau = t.value()
+        st = t.stats()
+        assert st.converged and abs(st.iterations - ref["iterations"]) <= 3
+        assert tau == pytest.approx(ref["tau"], rel=1e-8)
+        assert st.flux_in == pytest.approx(ref["flux_in"], rel=1e-8)
+        np.testing.assert_allclose(t.solution(), ref["x"], rtol=0, atol=1e-8)
+        t.destroy()
+
+
+def test_known_answers_and_failure_semantics(goldens):
+    n = 16
+    ph = np.ones((n, n, n), np.uint8)
+    for d in range(3):
+        t = oia.TortuosityMI355(ph, 1, d, -1.0, 1.0, eps=1e-12)
+        assert t.value() == pytest.approx(goldens["analytic"]["all_pore_16"]["tau"], rel=1e-10)
+        assert t.stats().deff == pytest.approx(goldens["analytic"]["all_pore_16"]["deff"], rel=1e-10)
+    ch = np.zeros((n, n, n), np.uint8)
+    ch[6:10, 6:10, :] = 1
+    t = oia.TortuosityMI355(ch, 1, 0)
+    assert t.value() == pytest.approx(0.9375, rel=1e-10) and t.getActiveVolumeFraction() == 0.0625
+    t = oia.TortuosityMI355(ch, 1, 1)  # channel probed across: no percolation -> NaN, no solve
+    assert math.isnan(t.value()) and t.status == oia.OI_NO_PERCOLATION and t.getActiveVolumeFraction() == 0.0
+    assert math.isnan(t.value())  # cached
+    t = oia.TortuosityMI355(ph, 1, 0, 0.5, 0.5)  # vlo == vhi -> +Inf (TortuosityHypre.cpp:846-865)
+    assert math.isinf(t.value())
+    s = o.gen_spheres((40, 40, 40), 3, 5, 0.45)
+    t = oia.TortuosityMI355(s, 1, 2, maxiter=5)  # maxiter too small -> NaN, not converged
+    assert math.isnan(t.value()) and t.status == oia.OI_NOT_CONVERGED and not t.getSolverConverged()
+    assert t.getSolverIterations() == 5
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TortuosityMI355(s, 1, 0, eps=-1.0)
+
+
+def test_value_caches_and_refreshes(sample):
+    sub = np.ascontiguousarray(sample[:32, :32, :32])
+    t = oia.TortuosityMI355(sub, 0, 0)
+    a = t.value()
+    it = t.getSolverIterations()
+    assert t.value() == a
+    assert t.value(refresh=True) == a and t.getSolverIterations() == it  # deterministic reductions
+
+
+def test_remspot_option_matches_oracle(sample):
+    sub = np.ascontiguousarray(sample[:30, :30, :30])
+    ref = o.tortuosity(o.remspot(sub, 1), 1, 0, eps=1e-10)
+    t = oia.TortuosityMI355(sub, 1, 0, eps=1e-10, remspot_passes=1)
+    assert t.value() == pytest.approx(ref["tau"], rel=1e-8)
+
+
+def test_device_generators_match_oracle():
+    shape = (24, 20, 36)
+    b = oia.gen_bernoulli_device(shape, 20251031, 0.5)
+    assert np.array_equal(b.download(np.uint8, shape), o.gen_bernoulli(shape, 20251031, 0.5))
+    s = oia.gen_spheres_device((40, 44, 48), 9, 6, 0.4)
+    assert np.array_equal(s.download(np.uint8, (40, 44, 48)), o.gen_spheres((40, 44, 48), 9, 6, 0.4))
+    # slab of a larger volume == the same planes of the whole volume
+    part = oia.gen_spheres_device((40, 44, 48), 9, 6, 0.4, z0=13, nz_local=9)
+    assert np.array_equal(part.download(np.uint8, (9, 44, 48)), o.gen_spheres((40, 44, 48), 9, 6, 0.4)[13:22])
+
+
+def test_512_bernoulli_properties():
+    """BASELINE.json config 2 at full size: properties that do not need the oracle."""
+    shape = (512, 512, 512)
+    buf = oia.gen_bernoulli_device(shape, 20251031, 0.5)
+    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-6)
+    st = t.stats()
+    assert 0.49 < st.vf < 0.51 and 0.0 < st.active_vf <= st.vf
+    assert t.checkMatrixProperties()
+    # "CG to 1e-6" is a throughput stopping point: the reference's own flux-conservation
+    # test (1e-6) may reject it; then value() is NaN by contract
+    tau6 = t.value()
+    st = t.stats()
+    assert st.converged and st.final_relres <= 1e-6
+    assert t.status in (oia.OI_OK, oia.OI_FLUX_NOT_CONSERVED)
+    assert math.isnan(tau6) == (t.status == oia.OI_FLUX_NOT_CONSERVED)
+    it6 = st.iterations
+    # parity setting: the reference default 1e-9
+    t.set_eps(1e-9)
+    tau = t.value(refresh=True)
+    st = t.stats()
+    assert t.status == oia.OI_OK and st.converged and st.iterations > it6 and tau > 1.0
+    assert abs(abs(st.flux_in) - abs(st.flux_out)) / abs(st.flux_in) <= 1e-6
+    # the solution obeys the discrete maximum principle: vlo <= phi <= vhi on active cells
+    # tau is invariant under the boundary values (linear problem)
+    t2 = oia.TortuosityMI355(buf, 1, 0, -3.0, 5.0, shape=shape, eps=1e-9)
+    assert t2.value() == pytest.approx(tau, rel=1e-6)
+    assert t2.stats().flux_in == pytest.approx(8.0 * st.flux_in, rel=1e-6)
+    t.destroy(); t2.destroy(); buf.free()
