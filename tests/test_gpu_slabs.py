@@ -1,0 +1,92 @@
+"""Slab-decomposed solves on ONE GPU: `n` host threads, each owning a z-slab and an
+in-process communicator (device-to-device ghost-plane copies, fixed-order reductions).
+Everything except the RCCL calls themselves is the code the multi-GPU run executes."""
+import threading
+
+import numpy as np
+import pytest
+
+import openimpala_amd as oia
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def run_slabs(phase, phase_id, direction, nranks, vlo=0.0, vhi=1.0, **opts):
+    nz = phase.shape[0]
+    comms = oia.Comm.create_local(nranks)
+    out = [None] * nranks
+    err = []
+
+    def work(r):
+        try:
+            z0, z1 = oia.slab_range(nz, nranks, r)
+            t = oia.TortuosityMI355(np.ascontiguousarray(phase[z0:z1]), phase_id, direction, vlo, vhi,
+                                    comm=comms[r], z0=z0, nz_global=nz, **opts)
+            ok = t.checkMatrixProperties()
+            tau = t.value()
+            st = t.stats()
+            out[r] = dict(tau=tau, status=t.status, ok=ok, st=st.asdict(), mask=t.mask(),
+                          x=t.solution() if st.n_active else None, span=(z0, z1))
+            t.destroy()
+        except Exception as e:  # surface the failure in the main thread
+            err.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "slab threads hung"
+    assert not err, err
+    for c in comms:
+        c.destroy()
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_slabs_match_single_domain(nranks, direction):
+    phase = o.gen_spheres((36, 40, 44), 21, 5, 0.45)
+    ref = o.tortuosity(phase, 1, direction, -1.0, 1.0, eps=1e-11)
+    single = oia.TortuosityMI355(phase, 1, direction, -1.0, 1.0, eps=1e-11)
+    tau1 = single.value()
+    it1 = single.getSolverIterations()
+    outs = run_slabs(phase, 1, direction, nranks, -1.0, 1.0, eps=1e-11)
+    mask = np.concatenate([r["mask"] for r in outs])
+    assert np.array_equal(mask, ref["mask"])
+    for r in outs:
+        assert r["ok"] and r["status"] == oia.OI_OK
+        assert r["st"]["n_active"] == ref["n_active"] and r["st"]["n_free"] == ref["n_free"]
+        assert r["tau"] == outs[0]["tau"]  # every rank reports the same global answer
+        assert abs(r["st"]["iterations"] - it1) <= 2
+    assert outs[0]["tau"] == pytest.approx(ref["tau"], rel=1e-8)
+    assert outs[0]["tau"] == pytest.approx(tau1, rel=1e-9)
+    x = np.concatenate([r["x"] for r in outs])
+    np.testing.assert_allclose(x, ref["x"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("variant,jacobi", [(oia.KERNEL_UNFUSED, False), (oia.KERNEL_FUSED, True)])
+def test_slab_variants_on_sample(sample_phase, goldens, variant, jacobi):
+    g = goldens["phases"]["1"]
+    sub = np.ascontiguousarray(sample_phase)
+    outs = run_slabs(sub, 1, 2, 4, g["vlo"], g["vhi"], eps=1e-10, kernel=variant,
+                     precond=oia.PRECOND_JACOBI if jacobi else oia.PRECOND_NONE)
+    assert outs[0]["tau"] == pytest.approx(g["tau"][2], rel=1e-7)
+    assert outs[0]["st"]["flux_in"] == pytest.approx(g["flux"][2], rel=1e-7)
+    assert outs[0]["st"]["active_vf"] == pytest.approx(g["active_vf"], abs=5e-7)
+
+
+def test_slabs_thin_and_uneven():
+    """nz not divisible by the rank count, slabs of one or two planes, flow along z."""
+    phase = o.gen_bernoulli((7, 24, 30), 4, 0.7)
+    ref = o.tortuosity(phase, 1, 2, eps=1e-11)
+    assert ref["status"] == 0
+    outs = run_slabs(phase, 1, 2, 5, eps=1e-11)
+    assert outs[0]["tau"] == pytest.approx(ref["tau"], rel=1e-8)
+    assert [r["span"] for r in outs] == [(0, 2), (2, 4), (4, 5), (5, 6), (6, 7)]
+
+
+def test_slabs_no_percolation_is_collective():
+    ph = np.ones((12, 12, 12), np.uint8)
+    ph[6] = 0  # plane z = 6 blocks the z direction
+    outs = run_slabs(ph, 1, 2, 3)
+    assert all(np.isnan(r["tau"]) and r["status"] == oia.OI_NO_PERCOLATION for r in outs)

@@ -1,0 +1,50 @@
+"""Summarise a tools_rocprof.sh output directory: per-kernel time stats and HBM bytes per
+launch from the FETCH_SIZE / WRITE_SIZE passes (gfx950: FETCH_SIZE counts 64 B per 128-B
+request for wide coalesced reads -> doubled, as MI355X_MICROARCH.md prescribes; both
+counters are in KiB)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    name = name.split("(")[0]
+    for tok in ("void ", "oi::"):
+        name = name.replace(tok, "")
+    return name.strip()
+
+
+def main(out):
+    stats = find(os.path.join(out, "trace"), "*kernel_stats.csv")
+    if stats:
+        print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+        rows = list(csv.DictReader(open(stats)))
+        for r in rows[:14]:
+            print("%-64s calls %6s  avg %10.1f us  total %8.2f ms  %5.1f%%" % (
+                short(r["Name"])[:64], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
+                float(r["Percentage"])))
+    for tag, counter, scale in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
+        f = find(os.path.join(out, tag), "*counter_collection.csv")
+        if not f:
+            continue
+        acc = defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            acc[k][0] += float(r["Counter_Value"])
+            acc[k][1] += 1
+        print(f"== {counter} per launch (KiB -> bytes, x{scale:g} gfx950 correction) ==")
+        for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:10]:
+            print("%-64s launches %6d  %14.0f bytes/launch" % (k[:64], n, v / n * 1024.0 * scale))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
