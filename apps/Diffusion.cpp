@@ -1,0 +1,254 @@
+// Diffusion -- inputs-file front end of the MI355X flow-through tortuosity solver.
+//
+// Keeps the user-facing boundary of the reference's `Diffusion` application
+// (src/props/Diffusion.cpp): `Diffusion <inputs> [key=value ...]`, the same keys
+// (:200-223, :605-611, :633; TortuosityHypre.cpp:147-151,254-256), reader dispatch by
+// file extension (:262-300), the per-direction loop (:655-706), the console lines and the
+// results file (:718-728).  The solve behind it is the HIP library (C ABI), reached
+// through the TortuosityMI355 mirror of OpenImpala::TortuosityHypre.
+//
+// Scope: calculation_method = flow_through.  The homogenization / REV branches of the
+// reference are a different PDE (periodic cell problem) and are not part of this path.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../include/TortuosityMI355.H"
+#include "Inputs.H"
+
+namespace {
+
+std::string lower(std::string s) {
+  std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return std::tolower(c); });
+  return s;
+}
+std::string upper(std::string s) {
+  std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return std::toupper(c); });
+  return s;
+}
+
+// stringToSolverType (Diffusion.cpp:45-58): unknown names are fatal
+OpenImpala::TortuosityMI355::SolverType solver_from_string(const std::string& s) {
+  using T = OpenImpala::TortuosityMI355::SolverType;
+  const std::string l = lower(s);
+  if (l == "jacobi") return T::Jacobi;
+  if (l == "gmres") return T::GMRES;
+  if (l == "flexgmres") return T::FlexGMRES;
+  if (l == "pcg") return T::PCG;
+  if (l == "bicgstab") return T::BiCGSTAB;
+  if (l == "smg") return T::SMG;
+  if (l == "pfmg") return T::PFMG;
+  throw std::runtime_error("Invalid solver string: '" + s + "'.");
+}
+
+struct Volume {
+  std::vector<std::uint8_t> phase;
+  int nx = 0, ny = 0, nz = 0;
+};
+
+Volume load_volume(const std::filesystem::path& path, double threshold, const oi::Inputs& in) {
+  if (!path.has_extension()) throw std::runtime_error("File has no extension: " + path.string());
+  const std::string ext = lower(path.extension().string());
+  Volume v;
+  std::uint8_t* data = nullptr;
+  oi_status st = OI_OK;
+  if (ext == ".tif" || ext == ".tiff") {
+    int bps = 0;
+    st = oi_read_tiff(path.c_str(), threshold, &data, &v.nx, &v.ny, &v.nz, &bps);
+  } else if (ext == ".dat") {
+    st = oi_read_dat(path.c_str(), threshold, &data, &v.nx, &v.ny, &v.nz);
+  } else if (ext == ".raw") {
+    // the reference's Diffusion does not wire RawReader (Diffusion.cpp:12); tRawReader's keys are used here
+    std::string type = "UINT8";
+    if (!in.query("raw.width", v.nx) || !in.query("raw.height", v.ny) || !in.query("raw.depth", v.nz))
+      throw std::runtime_error("a .raw input needs raw.width, raw.height and raw.depth");
+    in.query("raw.data_type", type);
+    static const std::map<std::string, int> types = {
+        {"UINT8", OI_RAW_UINT8}, {"INT8", OI_RAW_INT8}, {"INT16_LE", OI_RAW_INT16_LE}, {"INT16_BE", OI_RAW_INT16_BE},
+        {"UINT16_LE", OI_RAW_UINT16_LE}, {"UINT16_BE", OI_RAW_UINT16_BE}, {"INT32_LE", OI_RAW_INT32_LE},
+        {"INT32_BE", OI_RAW_INT32_BE}, {"UINT32_LE", OI_RAW_UINT32_LE}, {"UINT32_BE", OI_RAW_UINT32_BE},
+        {"FLOAT32_LE", OI_RAW_FLOAT32_LE}, {"FLOAT32_BE", OI_RAW_FLOAT32_BE}, {"FLOAT64_LE", OI_RAW_FLOAT64_LE},
+        {"FLOAT64_BE", OI_RAW_FLOAT64_BE}};
+    const auto it = types.find(upper(type));
+    if (it == types.end()) throw std::runtime_error("unknown raw.data_type: " + type);
+    st = oi_read_raw(path.c_str(), v.nx, v.ny, v.nz, it->second, threshold, &data);
+  } else if (ext == ".h5" || ext == ".hdf5") {
+    throw std::runtime_error("HDF5 input is not built into this front end yet (convert to TIFF or RAW): " + path.string());
+  } else {
+    throw std::runtime_error("Unsupported file extension for full domain load: " + ext);  // Diffusion.cpp:298-300
+  }
+  if (st != OI_OK) throw std::runtime_error(std::string(oi_status_string(st)) + ": " + oi_last_error());
+  v.phase.assign(data, data + static_cast<std::size_t>(v.nx) * v.ny * v.nz);
+  oi_free_host(data);
+  return v;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  const auto t_start = std::chrono::steady_clock::now();
+  if (argc < 2) {
+    std::cerr << "usage: Diffusion <inputs file> [key=value ...]\n";
+    return 2;
+  }
+  try {
+    oi::Inputs in;
+    in.load_file(argv[1]);
+    for (int a = 2; a < argc; ++a) in.add_argument(argv[a]);  // command line overrides the file
+
+    // ---- keys of Diffusion.cpp:200-213 (with the stale aliases of build/apps/inputs) ----
+    std::string filename, data_path = "./data/", results_path = "./results_diffusion/", hdf5_dataset = "image";
+    std::string solver_str = "FlexGMRES", method = "homogenization", output_filename = "results.txt";
+    double threshold = 0.5;
+    int phase_id = 1, box_size = 32, verbose = 1, write_plotfile = 0;
+    in.get("filename", filename);
+    in.query("data_path", data_path);
+    if (!in.query("results_path", results_path)) in.query("results_dir", results_path);
+    in.query("hdf5_dataset", hdf5_dataset);
+    if (!in.query("threshold_val", threshold)) in.query("threshold_value", threshold);
+    in.query("phase_id", phase_id);
+    in.query("solver_type", solver_str);
+    in.query("box_size", box_size);  // AMReX max grid size: meaningless for a flat array, accepted
+    in.query("verbose", verbose);
+    in.query("write_plotfile", write_plotfile);
+    in.query("calculation_method", method);
+    in.query("output_filename", output_filename);
+
+    const std::filesystem::path results_dir(results_path);
+    if (!std::filesystem::exists(results_dir)) {
+      std::filesystem::create_directories(results_dir);
+      if (verbose >= 1) std::cout << "Created results directory: " << results_dir.string() << std::endl;
+    }
+    const std::filesystem::path input_path = std::filesystem::path(data_path) / filename;
+    if (verbose >= 1) std::cout << "Reading full domain data from: " << input_path.string() << std::endl;
+    Volume vol;
+    try {
+      vol = load_volume(input_path, threshold, in);
+    } catch (const std::exception& e) {
+      std::cout << "Error loading full domain data: " << e.what() << std::endl;
+      std::cerr << "Full domain data loading failed." << std::endl;
+      return 1;
+    }
+
+    if (method != "flow_through") {
+      std::cerr << "calculation_method = " << method << ": only 'flow_through' (the TortuosityHypre path) is "
+                << "implemented by this build; the homogenization / REV study path is out of scope.\n";
+      return 2;
+    }
+
+    // ---- flow_through branch, Diffusion.cpp:591-733 ----
+    if (verbose >= 1) std::cout << "\n--- Full Domain Calculation: Tortuosity via Flow-Through ---\n";
+    double vlo = -1.0, vhi = 1.0;  // :605-606
+    in.query("tortuosity.vlo", vlo);
+    in.query("tortuosity.vhi", vhi);
+
+    oi_tort_opts opts;
+    oi_tort_default_opts(&opts);
+    if (!in.query("hypre.eps", opts.eps)) in.query("hypre_eps", opts.eps);
+    // hypre.maxiter counts multigrid-preconditioned FlexGMRES iterations in the reference (default
+    // 200); CG needs O(10 N).  It is read for compatibility and honoured only on request.
+    int hypre_maxiter = 0, honour = 0;
+    if (!in.query("hypre.maxiter", hypre_maxiter)) in.query("hypre_maxiter", hypre_maxiter);
+    in.query("gpu.honor_hypre_maxiter", honour);
+    if (honour && hypre_maxiter > 0) opts.maxiter = hypre_maxiter;
+    in.query("gpu.maxiter", opts.maxiter);
+    int tverbose = verbose;
+    in.query("tortuosity.verbose", tverbose);
+    in.query("tortuosity.remspot_passes", opts.remspot_passes);
+    std::string precond = "none", kernel = "auto";
+    in.query("gpu.precond", precond);
+    in.query("gpu.kernel", kernel);
+    opts.precond = lower(precond) == "jacobi" ? OI_PRECOND_JACOBI : OI_PRECOND_NONE;
+    opts.kernel = lower(kernel) == "unfused" ? OI_KERNEL_UNFUSED : (lower(kernel) == "fused" ? OI_KERNEL_FUSED : OI_KERNEL_AUTO);
+    in.query("gpu.device", opts.device);
+
+    if (verbose > 0) std::cout << "Calculating Volume Fraction for Phase ID: " << phase_id << "\n";
+    long long phase_voxels = 0, total_voxels = 0;
+    OpenImpala::volumeFraction(vol.phase.data(), vol.phase.size(), phase_id, phase_voxels, total_voxels);
+    const double volume_fraction = total_voxels > 0 ? static_cast<double>(phase_voxels) / static_cast<double>(total_voxels) : 0.0;
+    std::cout << "  Volume Fraction = " << std::fixed << std::setprecision(8) << volume_fraction << "\n";
+
+    std::string direction_str;
+    in.get("direction", direction_str);  // mandatory in this branch (:633)
+    const std::string up = upper(direction_str);
+    std::vector<OpenImpala::Direction> dirs;
+    if (up.find("ALL") != std::string::npos) {
+      dirs = {OpenImpala::Direction::X, OpenImpala::Direction::Y, OpenImpala::Direction::Z};
+    } else {
+      std::stringstream ss(up);
+      std::string d;
+      while (ss >> d) {
+        if (d == "X") dirs.push_back(OpenImpala::Direction::X);
+        else if (d == "Y") dirs.push_back(OpenImpala::Direction::Y);
+        else if (d == "Z") dirs.push_back(OpenImpala::Direction::Z);
+      }
+    }
+    if (dirs.empty()) std::cerr << "Warning: No valid directions specified in 'direction' input. Skipping tortuosity calculation.\n";
+
+    std::map<std::string, double> results;  // std::map: alphabetical X, Y, Z as in the reference
+    const auto solver_type = solver_from_string(solver_str);
+    for (const auto dir : dirs) {
+      const std::string dc = dir == OpenImpala::Direction::X ? "X" : (dir == OpenImpala::Direction::Y ? "Y" : "Z");
+      if (verbose >= 1) std::cout << "\n--- Solving for Tortuosity in Direction: " << dc << " ---\n";
+      OpenImpala::TortuosityMI355 solver(vol.phase.data(), vol.nx, vol.ny, vol.nz, volume_fraction, phase_id, dir,
+                                         solver_type, results_path, vlo, vhi, tverbose, write_plotfile != 0, &opts);
+      const double tau = solver.value();
+      results["Tortuosity_" + dc] = tau;
+      if (verbose >= 1) {
+        const oi_tort_stats s = solver.stats();
+        std::cout << "  Active Volume Fraction (percolating phase " << phase_id << "): " << std::defaultfloat
+                  << std::setprecision(6) << s.active_vf << "\n";
+        std::cout << "  Solver iterations: " << s.iterations << "\n";
+        std::cout << "  Final Relative Residual Norm: " << std::scientific << s.final_relres << std::defaultfloat << "\n";
+        std::cout << "  Solver Converged Status: " << (s.converged ? "Yes" : "No") << "\n";
+        std::cout << "    Flux In  = " << std::fixed << std::setprecision(8) << s.flux_in << "\n";
+        std::cout << "    Flux Out = " << std::fixed << std::setprecision(8) << s.flux_out << "\n";
+        std::cout << "  Timings [s]: mask " << std::defaultfloat << s.t_mask_s << ", solve " << s.t_solve_s << ", flux "
+                  << s.t_flux_s << "\n";
+      }
+      if (write_plotfile != 0 && solver.getSolverConverged()) {
+        // raw potential field instead of an AMReX plotfile: f64, x fastest, + a one-line header
+        std::vector<double> phi(vol.phase.size());
+        if (oi_tort_get_solution(solver.handle(), phi.data()) == OI_OK) {
+          const auto base = results_dir / ("tortuosity_solution_" + std::to_string(static_cast<int>(dir)));
+          std::ofstream(base.string() + ".raw", std::ios::binary)
+              .write(reinterpret_cast<const char*>(phi.data()), static_cast<std::streamsize>(phi.size() * sizeof(double)));
+          std::ofstream(base.string() + ".txt") << "solution_potential float64 little-endian nx=" << vol.nx
+                                                << " ny=" << vol.ny << " nz=" << vol.nz << " x-fastest\n";
+        }
+      }
+      std::cout << "  >>> Calculated Tortuosity (" << dc << "): " << std::fixed << std::setprecision(8) << tau << " <<<\n";
+    }
+
+    // ---- results file, Diffusion.cpp:709-732 ----
+    const std::filesystem::path out_path = results_dir / output_filename;
+    std::cout << "\nWriting final results to: " << out_path << "\n";
+    std::ofstream out(out_path);
+    if (out.is_open()) {
+      out << "# Tortuosity Calculation Results (Flow-Through Method)\n";
+      out << "# Input File: " << filename << "\n";
+      out << "# Analysis Phase ID: " << phase_id << "\n";
+      out << "# -----------------------------\n";
+      out << "VolumeFraction: " << std::fixed << std::setprecision(9) << volume_fraction << "\n";
+      for (const auto& kv : results) out << kv.first << ": " << std::fixed << std::setprecision(9) << kv.second << "\n";
+    } else {
+      std::cerr << "Warning: Could not open output file for writing: " << out_path.string() << "\n";
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::cout << std::endl << "Total run time (seconds) = " << std::defaultfloat << secs << std::endl;
+  } catch (const std::exception& e) {
+    std::cerr << "Diffusion: " << e.what() << std::endl;  // the reference would amrex::Abort here
+    return 1;
+  }
+  return 0;
+}

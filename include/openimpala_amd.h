@@ -210,6 +210,8 @@ enum {
 };
 oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
                       uint8_t** phase);
+/* DatReader::threshold (DatReader.cpp:74-160,204-241): 3 x int32 header + uint16 voxels */
+oi_status oi_read_dat(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz);
 void oi_free_host(void* p);
 
 #ifdef __cplusplus

@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_free_host"
+    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_read_dat oi_free_host"
 ).split()
 
 
@@ -143,6 +143,7 @@ def lib():
     L.oi_device_count.restype = i
     L.oi_read_tiff.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_raw.argtypes = [C.c_char_p, i, i, i, i, d, pp]
+    L.oi_read_dat.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_free_host.argtypes = [vp]
     L.oi_free_host.restype = None
     if L.oi_abi_version() != ABI_VERSION:
@@ -528,3 +529,22 @@ class RawReader:
         finally:
             lib().oi_free_host(p)
         return out.reshape(nz, ny, nx)
+
+
+class DatReader:
+    """OpenImpala::DatReader (src/io/DatReader.{H,cpp}): int32 W,H,D header + uint16 voxels."""
+
+    def __init__(self, filename):
+        self.filename = filename
+
+    def threshold(self, raw_threshold=0.5):
+        p = C.c_void_p()
+        nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().oi_read_dat(self.filename.encode(), raw_threshold, C.byref(p), C.byref(nx), C.byref(ny),
+                                 C.byref(nz)))
+        try:
+            n = nx.value * ny.value * nz.value
+            out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+        finally:
+            lib().oi_free_host(p)
+        return out.reshape(nz.value, ny.value, nx.value)

@@ -317,4 +317,26 @@ extern "C" oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int d
   return OI_OK;
 }
 
+// DatReader (src/io/DatReader.cpp:74-160 readFile, :204-241 threshold): little-endian
+// 3 x int32 header (W, H, D) + uint16 voxels, x fastest; the threshold is compared as
+// uint16 (the reference's DataType), extra trailing bytes are ignored.
+extern "C" oi_status oi_read_dat(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz) {
+  if (!path || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
+  *phase = nullptr;
+  std::vector<uint8_t> d;
+  if (!slurp(path, d) || d.size() < 12) { oi::set_error("cannot read DAT file '%s'", path); return OI_IO_ERROR; }
+  const bool swap = !host_is_le();
+  const int32_t w = load_swapped<int32_t>(d.data(), swap), h = load_swapped<int32_t>(d.data() + 4, swap),
+                dep = load_swapped<int32_t>(d.data() + 8, swap);
+  if (w <= 0 || h <= 0 || dep <= 0) { oi::set_error("'%s': invalid DAT header", path); return OI_IO_ERROR; }
+  const size_t n = (size_t)w * h * dep;
+  if (d.size() - 12 < 2 * n) { oi::set_error("'%s': DAT payload shorter than the header says", path); return OI_IO_ERROR; }
+  uint8_t* out = (uint8_t*)malloc(n);
+  if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
+  const uint16_t thr = (uint16_t)threshold;  // DatReader::threshold takes the raw type (uint16)
+  for (size_t v = 0; v < n; ++v) out[v] = load_swapped<uint16_t>(d.data() + 12 + 2 * v, swap) > thr ? 1 : 0;
+  *phase = out; *nx = w; *ny = h; *nz = dep;
+  return OI_OK;
+}
+
 extern "C" void oi_free_host(void* p) { free(p); }

@@ -1,0 +1,78 @@
+"""The C++ `Diffusion` front end: inputs grammar and refusal paths on CPU, the full
+flow-through run and the results-file text on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+APP = os.path.join(ROOT, "apps", "Diffusion")
+
+
+@pytest.fixture(scope="module")
+def app():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "openimpala_amd", "csrc")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps")], stdout=subprocess.DEVNULL)
+    return APP
+
+
+def _inputs(tmp_path, text):
+    p = tmp_path / "inputs"
+    p.write_text(text)
+    return str(p)
+
+
+def test_inputs_grammar_and_refusals(app, tmp_path):
+    base = f"""
+# comment line
+filename = "SampleData_2Phase_stack_3d_1bit.tif"   # quoted value, trailing comment
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+verbose = 0
+"""
+    # default calculation_method is homogenization (Diffusion.cpp:188): out of scope -> exit code 2
+    r = subprocess.run([app, _inputs(tmp_path, base)], capture_output=True, text=True)
+    assert r.returncode == 2 and "flow_through" in r.stderr
+    # mandatory key missing (ParmParse::get aborts in the reference)
+    r = subprocess.run([app, _inputs(tmp_path, "verbose = 0\n")], capture_output=True, text=True)
+    assert r.returncode == 1 and "filename" in r.stderr
+    # unsupported extension (Diffusion.cpp:298-300); command-line key=value overrides the file
+    r = subprocess.run([app, _inputs(tmp_path, base), "filename=foo.xyz"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unsupported file extension" in r.stdout
+    # bad number
+    r = subprocess.run([app, _inputs(tmp_path, base), "phase_id=abc"], capture_output=True, text=True)
+    assert r.returncode == 1 and "phase_id" in r.stderr
+
+
+@pytest.mark.gpu
+def test_diffusion_results_file(app, tmp_path, goldens):
+    g = goldens["phases"]["1"]
+    text = f"""
+filename = SampleData_2Phase_stack_3d_1bit.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+calculation_method = flow_through
+direction = All
+hypre.eps = 1e-10
+box_size = 32
+solver_type = FlexGMRES
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text), "verbose=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert ">>> Calculated Tortuosity (X):" in r.stdout and "Total run time (seconds) =" in r.stdout
+    lines = open(tmp_path / "res" / "results.txt").read().splitlines()
+    assert lines[0] == "# Tortuosity Calculation Results (Flow-Through Method)"
+    assert lines[1] == "# Input File: SampleData_2Phase_stack_3d_1bit.tif"
+    assert lines[2] == "# Analysis Phase ID: 1"
+    assert lines[4] == "VolumeFraction: 0.398309000"
+    got = {k: float(v) for k, v in (l.split(": ") for l in lines[4:])}
+    assert list(got) == ["VolumeFraction", "Tortuosity_X", "Tortuosity_Y", "Tortuosity_Z"]
+    for d, name in enumerate(("Tortuosity_X", "Tortuosity_Y", "Tortuosity_Z")):
+        assert got[name] == pytest.approx(g["tau"][d], rel=1e-7)
+    # phase 0 through a command-line override, single direction, stale alias keys accepted
+    r = subprocess.run([app, _inputs(tmp_path, text), "phase_id=0", "direction=z", "tortuosity.vlo=0",
+                        "output_filename=p0.txt", "verbose=0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(tmp_path / "res" / "p0.txt").read().splitlines()
+    assert lines[4] == "VolumeFraction: 0.601691000" and lines[5].startswith("Tortuosity_Z: 1.69305")
