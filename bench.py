@@ -39,9 +39,12 @@ def parse():
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--cpu-size", type=int, default=384)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-apply-bench", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fp32-stored-p variant")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the torch.distributed + RCCL code path even with one rank (rehearsal)")
     return ap.parse_args()
 
 
@@ -70,10 +73,11 @@ def cpu_baseline(oia, args):
     code = o.codes(mask, 0)
     x0 = o.initial_field(mask, 0, 0.0, 1.0)
     threads = o.lib().oi_oracle_num_threads()
+    o.cg_fixed(code, x0, 5)  # first call pays page faults and thread start-up
     t0 = time.time()
-    o.cg_fixed(code, x0, 5)
-    per_iter = (time.time() - t0) / 5
-    iters = int(max(10, min(2000, args.cpu_seconds / max(per_iter, 1e-6))))
+    o.cg_fixed(code, x0, 10)
+    per_iter = (time.time() - t0) / 10
+    iters = int(max(10, min(20000, args.cpu_seconds / max(per_iter, 1e-6))))
     t0 = time.time()
     o.cg_fixed(code, x0, iters)
     dt = time.time() - t0
@@ -93,14 +97,25 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
 
-    import openimpala_amd as oia
-
+    use_dist = world > 1 or args.force_dist
     dist = None
     torch = None
     comm = None
-    if world > 1:
+    if use_dist:
+        # torch FIRST: it brings its own libamdhip64 / librccl; loaded first, the solver library
+        # binds to the same HIP runtime and RCCL instead of pulling a second copy into the process
         import torch
         import torch.distributed as dist
+        if args.force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ["OI_FORCE_COMM"] = "1"
+
+    import openimpala_amd as oia
+
+    if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         uid = torch.zeros(oia.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
@@ -166,6 +181,7 @@ def main():
         dt = float(tt.item())
     steps_done = min(args.steps, max(0, it_done - args.warmup)) if conv else args.steps
     value = n ** 3 * args.steps / dt / 1e6
+    alg_bytes_iter = sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL)
 
     # dominant kernel of the timed region, from the HIP events on the solver's stream
     main_k = max((k for k in ktimes if k in BYTES_PER_VOXEL), key=lambda k: ktimes[k][0])
@@ -185,9 +201,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": BYTES_PER_VOXEL[main_k] * n * n * nzl,
                 "ms_per_launch": ms_launch,
-                "bytes_per_voxel_iter": sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL),
-                "iteration_GBps": sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL) * n * n * nzl
-                / (dt / args.steps) / 1e9}
+                "bytes_per_voxel_iter": alg_bytes_iter,
+                "iteration_GBps": alg_bytes_iter * n * n * nzl / (dt / args.steps) / 1e9,
+                "survey_89B_model_frac": value * 1e6 * 89.0 / world / (HBM_PEAK_GBS * 1e9)}
     t.cg_finish()
 
     # ---- wall time to relative residual 1e-6 (second half of the BASELINE metric) ----
@@ -214,6 +230,41 @@ def main():
         solve = {"eps": 1e-6, "converged": bool(done), "iterations": its, "relres": rel, "seconds": s1,
                  "mvoxel_iters_per_s": n ** 3 * its / s1 / 1e6 if s1 > 0 else None}
 
+    # ---- variant: search direction p STORED as fp32 (x, r, q and all arithmetic fp64) ----
+    variants = None
+    if not args.no_variants and args.kernel == "fused":
+        t.destroy()
+        buf2, _ = make_structure(oia, args, shape, z0, nzl)
+        kw2 = dict(kw, p_storage=oia.STORE_F32)
+        if comm is not None:
+            t = oia.TortuosityMI355(buf2, 1, oia.Direction.X, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0,
+                                    nz_global=n, **kw2)
+        else:
+            t = oia.TortuosityMI355(buf2, 1, oia.Direction.X, 0.0, 1.0, shape=shape, **kw2)
+        buf2.free()
+        t.cg_begin()
+        t.cg_iterate(args.warmup)
+        t.sync()
+        t.reset_kernel_times()
+        barrier()
+        v0 = time.perf_counter()
+        t.cg_iterate(args.steps)
+        t.sync()
+        barrier()
+        vdt = time.perf_counter() - v0
+        vk = t.kernel_times()
+        if dist is not None:
+            tt = torch.tensor([vdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            vdt = float(tt.item())
+        t.cg_finish()
+        variants = {"p_stored_fp32": {
+            "note": "search direction kept as fp32 in HBM; x, r, q and every operation fp64; r stays the exact "
+                    "recurrence residual of x (tests/test_gpu_parity.py::test_fp32_stored_search_direction)",
+            "value": n ** 3 * args.steps / vdt / 1e6, "unit": "Mvoxel-iters/s", "ms_per_step": vdt / args.steps * 1e3,
+            "bytes_per_voxel_iter": 65.0,
+            "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in vk.items()}}}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(oia, args)
@@ -232,7 +283,7 @@ def main():
             "apply_roofline": apply_info,
             "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in ktimes.items()},
             "steps_effective": steps_done, "relres_after_timed_region": relres,
-            "time_to_1e-6": solve,
+            "time_to_1e-6": solve, "variants": variants,
             "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
                         "flood_sweeps": st.flood_sweeps},
             "device_bytes": st.bytes_device,

@@ -47,6 +47,7 @@ typedef struct oi_comm oi_comm; /* replaces MPI_COMM_WORLD / amrex::ParallelDesc
 
 enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1 };
 enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2 };
+enum { OI_STORE_F64 = 0, OI_STORE_F32 = 1 };
 
 /* Options.  `eps` / `maxiter` are the reference's hypre.eps / hypre.maxiter
  * (TortuosityHypre.cpp:142-149: 1e-9 / 200).  The reference's 200 counts
@@ -62,6 +63,10 @@ typedef struct oi_tort_opts {
   int kernel;         /* OI_KERNEL_* */
   int profile;        /* 1: bracket every kernel launch with HIP events (oi_tort_kernel_times) */
   int device;         /* HIP device ordinal; -1 = the calling thread's current device */
+  int p_storage;      /* OI_STORE_F64 (default) | OI_STORE_F32: keep the CG search direction p in fp32
+                         in HBM (8 B/voxel-iter less traffic).  x, r, q and ALL arithmetic stay fp64; r
+                         remains the exact recurrence residual of x, only the search direction is
+                         perturbed at the 1e-7 level (fused kernel only). */
 } oi_tort_opts;
 
 void oi_tort_default_opts(oi_tort_opts* opts);
@@ -156,6 +161,8 @@ oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_
 /* process-wide tuning of the fused CG kernel: rows per LDS tile (4 or 8) and planes per
  * block (0 = automatic).  Affects launches made after the call. */
 void oi_tort_set_tuning(int fused_tile_rows, int fused_planes_per_block);
+/* rows per LDS tile (8, 16 or 32) of the stand-alone stencil apply */
+void oi_tort_set_apply_tuning(int tile_rows);
 
 /* per-kernel HIP-event timings gathered while opts.profile = 1.  names: fixed list,
  * see oi_kernel_name().  Returns the number of kernels written (<= cap). */

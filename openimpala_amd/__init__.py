@@ -32,6 +32,7 @@ OI_OK, OI_BAD_ARG, OI_NO_PERCOLATION, OI_NOT_CONVERGED, OI_FLUX_NOT_CONSERVED = 
 OI_HIP_ERROR, OI_RCCL_ERROR, OI_NO_DEVICE, OI_IO_ERROR = 5, 6, 7, 8
 PRECOND_NONE, PRECOND_JACOBI = 0, 1
 KERNEL_AUTO, KERNEL_UNFUSED, KERNEL_FUSED = 0, 1, 2
+STORE_F64, STORE_F32 = 0, 1
 COMM_ID_BYTES = 128
 
 # every symbol include/openimpala_amd.h declares (checked by the CPU test-suite)
@@ -40,7 +41,7 @@ ABI_SYMBOLS = (
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_kernel_times "
-    "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_comm_unique_id oi_comm_create "
+    "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_read_dat oi_free_host"
@@ -63,7 +64,7 @@ class OpenImpalaError(RuntimeError):
 class Opts(C.Structure):
     _fields_ = [("eps", C.c_double), ("maxiter", C.c_int), ("precond", C.c_int), ("remspot_passes", C.c_int),
                 ("verbose", C.c_int), ("check_every", C.c_int), ("kernel", C.c_int), ("profile", C.c_int),
-                ("device", C.c_int)]
+                ("device", C.c_int), ("p_storage", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -127,6 +128,8 @@ def lib():
     L.oi_tort_reset_kernel_times.restype = None
     L.oi_tort_set_tuning.argtypes = [i, i]
     L.oi_tort_set_tuning.restype = None
+    L.oi_tort_set_apply_tuning.argtypes = [i]
+    L.oi_tort_set_apply_tuning.restype = None
     L.oi_comm_unique_id.argtypes = [vp]
     L.oi_comm_create.argtypes = [pp, vp, i, i, i]
     L.oi_comm_create_local.argtypes = [pp, i, i]
@@ -173,8 +176,11 @@ def default_opts(**kw):
     return o
 
 
-def set_tuning(fused_by=8, fused_zchunk=0):
-    lib().oi_tort_set_tuning(fused_by, fused_zchunk)
+def set_tuning(fused_tile_rows=16, fused_zchunk=0, apply_tile_rows=32):
+    """Rows per LDS tile (8, 16 or 32) of the fused CG kernel / of the stand-alone apply, and
+    planes per block of the z-march (0 = auto)."""
+    lib().oi_tort_set_tuning(fused_tile_rows, fused_zchunk)
+    lib().oi_tort_set_apply_tuning(apply_tile_rows)
 
 
 # ------------------------------------------------------------------------------------------

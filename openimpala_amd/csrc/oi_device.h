@@ -72,18 +72,21 @@ void launch_update_p(const Geom& g, const uint8_t* code, const double* r, double
 int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, const double* p, const double* q,
                      int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);
 // fused: x += alpha_{k-1} p_in ; p_out = z + beta_k p_in ; q = A p_out ; partials {p_out.q}
-int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const double* p_in,
-                   double* p_out, double* q, int jacobi, const double* hist, int k, double* partials,
+// p_in / p_out are double* or, with p_f32 != 0, float* (fp32 STORAGE of the search direction)
+int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
+                   void* p_out, int p_f32, double* q, int jacobi, const double* hist, int k, double* partials,
                    const Ctrl* ctrl, hipStream_t s);
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
-void set_fused_tuning(int by, int zchunk);
+void set_fused_tuning(int tile_rows, int zchunk);
+void set_apply_tuning(int tile_rows);
 // r -= alpha q; partials {rr, rz}
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi,
                     const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);
 // x += alpha_k p  (deferred update flush of the fused variant)
-void launch_axpy_hist(const Geom& g, double* x, const double* p, const double* hist, int k, hipStream_t s);
+void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k,
+                      hipStream_t s);
 // dst[slot..slot+ncomp) = sum of partials (deterministic order); optional convergence test on
 // dst[check_rr_index]: sets ctrl->done = iter_done when <= tol2
 void launch_finalize(const double* partials, int nblocks, int ncomp, double* dst, Ctrl* ctrl, int check,

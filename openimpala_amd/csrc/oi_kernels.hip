@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __rest
   const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;
   const double z1 = (jacobi && c1) ? r1 / (double)c1 : r1;
   st2(r + e, r0, r1);
-  st2(p + e, z0, z1);
+  if (p) st2(p + e, z0, z1);  // the fused variant forms p_0 = z_0 itself
   rr += r0 * r0; rr += r1 * r1;
   rz += r0 * z0; rz += r1 * z1;
   OI_PAIR_LOOP_END
@@ -443,66 +443,133 @@ void launch_update_p(const Geom& g, const uint8_t* code, const double* r, double
   hipLaunchKernelGGL(k_update_p, dim3(blocks), dim3(256), 0, s, g, code, r, p, jacobi, hist, k, ctrl);
 }
 
-template <bool WITH_X>
+// Flat streams in BLOCKED form: every block owns one contiguous chunk and keeps four
+// independent 16-byte loads per array in flight (tools/stream_bench.hip: +4..6 % over a
+// grid-stride loop on MI355X).
+template <bool WITH_X, bool JACOBI>
 __global__ void __launch_bounds__(256) k_update_xr(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     double* __restrict__ r, const double* __restrict__ p,
-                                                    const double* __restrict__ q, int jacobi,
-                                                    const double* __restrict__ hist, int k,
-                                                    double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+                                                    const double* __restrict__ q, const double* __restrict__ hist,
+                                                    int k, double* __restrict__ partials,
+                                                    const Ctrl* __restrict__ ctrl) {
   if (ctrl->done) return;
   const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
   double rr = 0.0, rz = 0.0;
-  OI_PAIR_LOOP_BEGIN
-  (void)i; (void)j;
-  const double2 rv = ld2(r + e), qv = ld2(q + e);
-  if (WITH_X) {
-    const double2 xv = ld2(x + e), pv = ld2(p + e);
-    st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+  constexpr int U = 4;
+  const long long npairs = (long long)g.nzl * g.plane / 2;
+  const long long per = (npairs + gridDim.x - 1) / gridDim.x;
+  const long long b0 = per * blockIdx.x, b1 = min(b0 + per, npairs);
+  auto body = [&](long long t) {
+    const long long e = g.plane + 2 * t;
+    const double2 rv = ld2(r + e), qv = ld2(q + e);
+    if (WITH_X) {
+      const double2 xv = ld2(x + e), pv = ld2(p + e);
+      st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+    }
+    const double r0 = rv.x - alpha * qv.x, r1 = rv.y - alpha * qv.y;
+    st2(r + e, r0, r1);
+    double z0 = r0, z1 = r1;
+    if (JACOBI) {
+      const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+      if (cc & 0xff) z0 = r0 / (double)(cc & 0xff);
+      if (cc >> 8) z1 = r1 / (double)(cc >> 8);
+    }
+    rr += r0 * r0; rr += r1 * r1;
+    rz += r0 * z0; rz += r1 * z1;
+  };
+  long long t = b0 + threadIdx.x;
+  for (; t + (U - 1) * 256 < b1; t += U * 256) {
+    double2 rv[U], qv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { rv[u] = ld2(r + g.plane + 2 * (t + u * 256)); qv[u] = ld2(q + g.plane + 2 * (t + u * 256)); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long e = g.plane + 2 * (t + u * 256);
+      if (WITH_X) {
+        const double2 xv = ld2(x + e), pv = ld2(p + e);
+        st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+      }
+      const double r0 = rv[u].x - alpha * qv[u].x, r1 = rv[u].y - alpha * qv[u].y;
+      st2(r + e, r0, r1);
+      double z0 = r0, z1 = r1;
+      if (JACOBI) {
+        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        if (cc & 0xff) z0 = r0 / (double)(cc & 0xff);
+        if (cc >> 8) z1 = r1 / (double)(cc >> 8);
+      }
+      rr += r0 * r0; rr += r1 * r1;
+      rz += r0 * z0; rz += r1 * z1;
+    }
   }
-  const double r0 = rv.x - alpha * qv.x, r1 = rv.y - alpha * qv.y;
-  st2(r + e, r0, r1);
-  const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;
-  const double z1 = (jacobi && c1) ? r1 / (double)c1 : r1;
-  rr += r0 * r0; rr += r1 * r1;
-  rz += r0 * z0; rz += r1 * z1;
-  OI_PAIR_LOOP_END
+  for (; t < b1; t += 256) body(t);
   __shared__ double red[4];
   const double a = block_sum(rr, red);
   const double b = block_sum(rz, red);
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = b; }
 }
 
+template <bool WITH_X>
+static int launch_update_any(const Geom& g, const uint8_t* code, double* x, double* r, const double* p,
+                             const double* q, int jacobi, const double* hist, int k, double* partials,
+                             const Ctrl* ctrl, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 1024, 2048);
+  if (jacobi)
+    hipLaunchKernelGGL((k_update_xr<WITH_X, true>), dim3(blocks), dim3(256), 0, s, g, code, x, r, p, q, hist, k,
+                       partials, ctrl);
+  else
+    hipLaunchKernelGGL((k_update_xr<WITH_X, false>), dim3(blocks), dim3(256), 0, s, g, code, x, r, p, q, hist, k,
+                       partials, ctrl);
+  return blocks;
+}
+
 int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, const double* p, const double* q,
                      int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s) {
-  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
-  hipLaunchKernelGGL(k_update_xr<true>, dim3(blocks), dim3(256), 0, s, g, code, x, r, p, q, jacobi, hist, k,
-                     partials, ctrl);
-  return blocks;
+  return launch_update_any<true>(g, code, x, r, p, q, jacobi, hist, k, partials, ctrl, s);
 }
 
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi, const double* hist,
                     int k, double* partials, const Ctrl* ctrl, hipStream_t s) {
-  const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
-  hipLaunchKernelGGL(k_update_xr<false>, dim3(blocks), dim3(256), 0, s, g, code, (double*)nullptr, r,
-                     (const double*)nullptr, q, jacobi, hist, k, partials, ctrl);
-  return blocks;
+  return launch_update_any<false>(g, code, nullptr, r, nullptr, q, jacobi, hist, k, partials, ctrl, s);
 }
 
-__global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ x, const double* __restrict__ p,
+// typed loads/stores of the search direction: p may be STORED as fp32 (opts.p_storage),
+// all arithmetic stays fp64
+template <typename PT> struct PIo;
+template <> struct PIo<double> {
+  static __device__ __forceinline__ double2 ld_pair(const double* p) { return ld2(p); }
+  static __device__ __forceinline__ void st_pair(double* p, double a, double b) { st2(p, a, b); }
+  static __device__ __forceinline__ double rnd(double v) { return v; }
+};
+template <> struct PIo<float> {
+  static __device__ __forceinline__ double2 ld_pair(const float* p) {
+    const float2 f = *reinterpret_cast<const float2*>(p);
+    return make_double2((double)f.x, (double)f.y);
+  }
+  static __device__ __forceinline__ void st_pair(float* p, double a, double b) {
+    *reinterpret_cast<float2*>(p) = make_float2((float)a, (float)b);
+  }
+  // the value the next iteration will read back: the stencil, p.q and the x update all use it
+  static __device__ __forceinline__ double rnd(double v) { return (double)(float)v; }
+};
+
+template <typename PT>
+__global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ x, const PT* __restrict__ p,
                                                     const double* __restrict__ hist, int k) {
   const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
   const long long npairs = (long long)g.nzl * g.plane / 2;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;
        t += (long long)gridDim.x * blockDim.x) {
     const long long e = g.plane + 2 * t;
-    const double2 xv = ld2(x + e), pv = ld2(p + e);
+    const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + e);
     st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
   }
 }
 
-void launch_axpy_hist(const Geom& g, double* x, const double* p, const double* hist, int k, hipStream_t s) {
+void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k,
+                      hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
-  hipLaunchKernelGGL(k_axpy_hist, dim3(blocks), dim3(256), 0, s, g, x, p, hist, k);
+  if (p_f32) hipLaunchKernelGGL(k_axpy_hist<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, hist, k);
+  else hipLaunchKernelGGL(k_axpy_hist<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, hist, k);
 }
 
 // --------------------------------------------------------------------------------------
@@ -510,31 +577,34 @@ void launch_axpy_hist(const Geom& g, double* x, const double* p, const double* h
 //     x     += alpha_{k-1} * p_in            (deferred solution update)
 //     p_out  = z + beta_k * p_in             (z = r or r/code)
 //     q      = A p_out,   partial p_out.q
-// A block owns a BX x BY column of voxels and marches over a chunk of z planes.  Every
-// thread owns one x-pair; the p_out values of planes g-1, g, g+1 of its pair live in
-// registers (z reuse), plane g of the whole tile incl. a one-voxel halo ring lives in a
-// double-buffered LDS plane (x/y reuse; halo values are recomputed from r and p_in,
-// which the neighbouring tile's block pulls through the same XCD L2).  Compulsory HBM
-// traffic: r 8 + p_in 8 + code 1 + x 8+8 + p_out 8 + q 8 = 49 B/voxel.
-// LDS row: [pad | left halo | BX tile doubles | right halo | pad]: every access is a
+// A block of 8 waves owns a 128 x (8 R) column of voxels and marches over a chunk of z
+// planes.  Every thread owns R x-pairs (rows w, w+8, ...); the p_out values of planes
+// g-1, g, g+1 of its pairs live in registers (z reuse), plane g of the whole tile incl. a
+// one-voxel halo ring lives in a double-buffered LDS plane (x/y reuse; halo values are
+// recomputed from r and p_in, which the neighbouring tile's block pulls through the same
+// XCD L2).  Compulsory HBM traffic: r 8 + p_in 8 + code 1 + x 8+8 + p_out 8 + q 8 = 49
+// B/voxel (41 with p stored as fp32).
+// LDS row: [pad | left halo | 128 tile doubles | right halo | pad]: every access is a
 // conflict-free 16-byte ds_read/ds_write_b128.
+// PURE = true turns the kernel into the stand-alone stencil apply q = A v (v passed as
+// `r`; no p/x traffic: 8 + 1 + 8 = 17 B/voxel), partial v.q.
 // --------------------------------------------------------------------------------------
 constexpr int kBX = 128;            // tile width in voxels = 64 lanes x 2
 constexpr int kLP = kBX + 4;        // LDS row pitch in doubles
+constexpr int kNW = 8;              // waves per block
 
-// PURE = true turns the kernel into the stand-alone stencil apply q = A v (v passed as
-// `r`; no p/x traffic: 8 + 1 + 8 = 17 B/voxel), partial v.q.
-template <int BY, bool PURE>
-__global__ void __launch_bounds__(64 * BY) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
-                                                      const double* __restrict__ r, const double* __restrict__ p_in,
-                                                      double* __restrict__ p_out, double* __restrict__ q, int jacobi,
-                                                      const double* __restrict__ hist, int k, int zchunk, int tiles_x,
-                                                      int tiles_y, int nzc, double* __restrict__ partials,
-                                                      const Ctrl* __restrict__ ctrl) {
-  static_assert(BY >= 4, "waves 0,1 load the y halo rows, wave 2 the x halo columns");
+template <int R, bool PURE, typename PT>
+__global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+                                                       const double* __restrict__ r, const PT* __restrict__ p_in,
+                                                       PT* __restrict__ p_out, double* __restrict__ q, int jacobi,
+                                                       const double* __restrict__ hist, int k, int zchunk,
+                                                       int tiles_x, int tiles_y, int nzc,
+                                                       double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+  constexpr int BY = kNW * R;
+  static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (ctrl && ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
-  __shared__ double red[BY];
+  __shared__ double red[kNW];
 
   // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2), so
   // give every XCD one contiguous range of logical tiles (x fastest, then y, then z chunk).
@@ -549,46 +619,52 @@ __global__ void __launch_bounds__(64 * BY) k_fused_a(Geom g, const uint8_t* __re
     alpha_prev = safe_div(hist[H_STRIDE * (k - 1) + H_RZ], hist[H_STRIDE * (k - 1) + H_PQ]);
   }
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // w = row inside the tile
-  const int i = tx * kBX + 2 * lane, j = ty * BY + w;
-  const bool own = (i < g.pitch) && (j < g.ny);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = tx * kBX + 2 * lane, j0 = ty * BY;
+  const bool in_x = i < g.pitch;
   const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);  // output planes [gs, ge)
-  const long long rowoff = (long long)j * g.pitch + i;
 
   // halo duty: wave 0 -> row j0-1, wave 1 -> row j0+BY (pairs); wave 2, lanes < 2*BY -> x halos
-  const int j0 = ty * BY;
   const int hrow = (w == 0) ? j0 - 1 : j0 + BY;
-  const bool yhalo = (w < 2) && (i < g.pitch) && hrow >= 0 && hrow < g.ny;
+  const bool yhalo = (w < 2) && in_x && hrow >= 0 && hrow < g.ny;
   const int xh_row = j0 + (lane >> 1);
   const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
   const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
 
-  // p_new of one plane for this thread's own pair
-  auto pnew_pair = [&](int gz, double2& pin) -> double2 {
-    pin = make_double2(0.0, 0.0);
-    if (!own) return make_double2(0.0, 0.0);
-    const long long e = (long long)gz * g.plane + rowoff;
-    const double2 rv = ld2(r + e);
-    if (PURE) return rv;
-    pin = ld2(p_in + e);
-    double z0 = rv.x, z1 = rv.y;
-    if (jacobi) {
-      const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
-      if (cc & 0xff) z0 = rv.x / (double)(cc & 0xff);
-      if (cc >> 8) z1 = rv.y / (double)(cc >> 8);
-    }
-    return make_double2(z0 + beta * pin.x, z1 + beta * pin.y);
-  };
   auto pnew_at = [&](long long e) -> double {
     double z = r[e];
     if (PURE) return z;
     if (jacobi) { const unsigned c = code[e]; if (c) z = z / (double)c; }
-    return z + beta * p_in[e];
+    return PIo<PT>::rnd(z + beta * (double)p_in[e]);
   };
-  // stage plane gz (own pair value pn) plus the halo ring into LDS buffer b
-  auto stage = [&](int b, int gz, double2 pn) {
+  // p_new of plane gz for this thread's R pairs (and the p_in values for the x update)
+  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      pin[rr_] = make_double2(0.0, 0.0);
+      pn[rr_] = make_double2(0.0, 0.0);
+      if (in_x && j < g.ny) {
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const double2 rv = ld2(r + e);
+        if (PURE) { pn[rr_] = rv; continue; }
+        pin[rr_] = PIo<PT>::ld_pair(p_in + e);
+        double z0 = rv.x, z1 = rv.y;
+        if (jacobi) {
+          const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+          if (cc & 0xff) z0 = rv.x / (double)(cc & 0xff);
+          if (cc >> 8) z1 = rv.y / (double)(cc >> 8);
+        }
+        pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin[rr_].x), PIo<PT>::rnd(z1 + beta * pin[rr_].y));
+      }
+    }
+  };
+  // stage plane gz (own pair values) plus the halo ring into LDS buffer b
+  auto stage = [&](int b, int gz, const double2 (&pn)[R]) {
     double* T = tile[b];
-    *reinterpret_cast<double2*>(&T[(w + 1) * kLP + 2 + 2 * lane]) = pn;
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_)
+      *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (yhalo) {
@@ -603,63 +679,89 @@ __global__ void __launch_bounds__(64 * BY) k_fused_a(Geom g, const uint8_t* __re
     }
   };
 
-  double2 pin_cur, pin_nxt, pin_tmp;
-  double2 pn_prev = pnew_pair(gs - 1, pin_tmp);
-  double2 pn_cur = pnew_pair(gs, pin_cur);
-  if (!PURE && gs == 1 && own) st2(p_out + rowoff, pn_prev.x, pn_prev.y);  // lo ghost plane of p stays current
+  double2 pn_prev[R], pn_cur[R], pn_nxt[R], pin_cur[R], pin_nxt[R];
+  load_plane(gs - 1, pn_prev, pin_nxt);
+  load_plane(gs, pn_cur, pin_cur);
+  if (!PURE && gs == 1) {  // lo ghost plane of p stays current
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      if (in_x && j < g.ny) PIo<PT>::st_pair(p_out + (long long)j * g.pitch + i, pn_prev[rr_].x, pn_prev[rr_].y);
+    }
+  }
   stage(gs & 1, gs, pn_cur);
   __syncthreads();
 
   double pq = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    const double2 pn_nxt = pnew_pair(gz + 1, pin_nxt);
+    load_plane(gz + 1, pn_nxt, pin_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
-    if (own) {
-      const double* T = tile[gz & 1];
-      const int base = (w + 1) * kLP + 2 + 2 * lane;
-      const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
-      const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
-      const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
-      const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
-      const long long e = (long long)gz * g.plane + rowoff;
-      const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
-      const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
-      const double s0 = ((((lf.y + pn_cur.y) + ym.x) + yp.x) + pn_prev.x) + pn_nxt.x;
-      const double s1 = ((((pn_cur.x + rt.x) + ym.y) + yp.y) + pn_prev.y) + pn_nxt.y;
-      const double q0 = c0 ? (double)c0 * pn_cur.x - s0 : 0.0;
-      const double q1 = c1 ? (double)c1 * pn_cur.y - s1 : 0.0;
-      st2(q + e, q0, q1);
-      if (!PURE) {
-        st2(p_out + e, pn_cur.x, pn_cur.y);
-        if (k > 0) {
-          const double2 xv = ld2(x + e);
-          st2(x + e, xv.x + alpha_prev * pin_cur.x, xv.y + alpha_prev * pin_cur.y);
+    const double* T = tile[gz & 1];
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      if (in_x && j < g.ny) {
+        const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
+        const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
+        const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
+        const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
+        const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
+        const double2 pc = pn_cur[rr_];
+        const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
+        const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + pn_prev[rr_].y) + pn_nxt[rr_].y;
+        const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
+        const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
+        st2(q + e, q0, q1);
+        if (!PURE) {
+          PIo<PT>::st_pair(p_out + e, pc.x, pc.y);
+          if (k > 0) {
+            const double2 xv = ld2(x + e);
+            st2(x + e, xv.x + alpha_prev * pin_cur[rr_].x, xv.y + alpha_prev * pin_cur[rr_].y);
+          }
+          if (gz + 1 == ge && ge == g.nzl + 1)  // hi ghost plane of p stays current
+            PIo<PT>::st_pair(p_out + e + g.plane, pn_nxt[rr_].x, pn_nxt[rr_].y);
         }
+        pq += pc.x * q0; pq += pc.y * q1;
       }
-      pq += pn_cur.x * q0; pq += pn_cur.y * q1;
     }
-    if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && own)  // hi ghost plane of p stays current
-      st2(p_out + (long long)ge * g.plane + rowoff, pn_nxt.x, pn_nxt.y);
-    pn_prev = pn_cur; pn_cur = pn_nxt; pin_cur = pin_nxt;
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) { pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; pin_cur[rr_] = pin_nxt[rr_]; }
     __syncthreads();
   }
   const double t = block_sum(pq, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
-static int g_fused_by = 8;       // tile rows (4 or 8)
+// Defaults from the 1024^3 sweep in profiles/r01/tile_sweep.txt: 16-row tiles for the CG
+// kernel (32 rows need 190 VGPRs -> one block per CU), 32-row tiles for the stand-alone apply.
+static int g_fused_rows = 2;     // R: rows per thread (tile height 8 R)
+static int g_pure_rows = 4;
 static int g_fused_zchunk = 0;   // planes per block, 0 = auto
 
-void set_fused_tuning(int by, int zchunk) {
-  if (by == 4 || by == 8) g_fused_by = by;
+void set_fused_tuning(int tile_rows, int zchunk) {
+  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_fused_rows = tile_rows / 8;
   g_fused_zchunk = zchunk > 0 ? zchunk : 0;
 }
+void set_apply_tuning(int tile_rows) {
+  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_pure_rows = tile_rows / 8;
+}
 
-template <bool PURE>
-static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const double* r, const double* p_in,
-                        double* p_out, double* q, int jacobi, const double* hist, int k, double* partials,
-                        const Ctrl* ctrl, hipStream_t s) {
-  const int by = g_fused_by;
+template <int R, bool PURE, typename PT>
+static void launch_tiled_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
+                           void* p_out, double* q, int jacobi, const double* hist, int k, int zchunk, int tiles_x,
+                           int tiles_y, int nzc, double* partials, const Ctrl* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL((k_fused_a<R, PURE, PT>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
+                     (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+}
+
+template <bool PURE, typename PT>
+static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
+                        double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
+                        hipStream_t s) {
+  const int R = PURE ? g_pure_rows : g_fused_rows, by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
   int zchunk = g_fused_zchunk;
@@ -679,24 +781,28 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
     nzc = (g.nzl + zchunk - 1) / zchunk;
   }
   const int blocks = (int)(cols * nzc);
-  if (by == 8)
-    hipLaunchKernelGGL((k_fused_a<8, PURE>), dim3(blocks), dim3(512), 0, s, g, code, x, r, p_in, p_out, q, jacobi,
-                       hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  if (R == 4)
+    launch_tiled_r<4, PURE, PT>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc,
+                                partials, ctrl, s);
+  else if (R == 2)
+    launch_tiled_r<2, PURE, PT>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc,
+                                partials, ctrl, s);
   else
-    hipLaunchKernelGGL((k_fused_a<4, PURE>), dim3(blocks), dim3(256), 0, s, g, code, x, r, p_in, p_out, q, jacobi,
-                       hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+    launch_tiled_r<1, PURE, PT>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc,
+                                partials, ctrl, s);
   return blocks;
 }
 
-int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const double* p_in,
-                   double* p_out, double* q, int jacobi, const double* hist, int k, double* partials,
-                   const Ctrl* ctrl, hipStream_t s) {
-  return launch_tiled<false>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s);
+int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
+                   int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
+                   hipStream_t s) {
+  if (p_f32) return launch_tiled<false, float>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s);
+  return launch_tiled<false, double>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s);
 }
 
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s) {
-  return launch_tiled<true>(g, code, nullptr, v, nullptr, nullptr, q, 0, nullptr, 0, partials, ctrl, s);
+  return launch_tiled<true, double>(g, code, nullptr, v, nullptr, nullptr, q, 0, nullptr, 0, partials, ctrl, s);
 }
 
 // --------------------------------------------------------------------------------------

@@ -67,7 +67,10 @@ struct oi_tort {
   // device memory
   uint64_t *open = nullptr, *active = nullptr /* reach_lo, then the mask */, *rhi = nullptr;
   uint8_t* code = nullptr;
-  double *x = nullptr, *r = nullptr, *q = nullptr, *p[2] = {nullptr, nullptr};
+  double *x = nullptr, *r = nullptr, *q = nullptr;
+  void* p[2] = {nullptr, nullptr};  // search direction: fp64, or fp32 storage when p_f32
+  bool p_f32 = false;
+  size_t p_elem = sizeof(double);
   double* partials = nullptr;
   double* hist = nullptr;
   Ctrl* ctrl = nullptr;
@@ -203,11 +206,12 @@ extern "C" void oi_tort_default_opts(oi_tort_opts* o) {
   o->kernel = OI_KERNEL_AUTO;
   o->profile = 0;
   o->device = -1;
+  o->p_storage = OI_STORE_F64;
 }
 
 // exchange one ghost plane pair of an array with `elem` bytes per voxel-slot
 static oi_status exchange_planes(oi_tort* h, void* base, size_t plane_bytes) {
-  if (!h->comm || h->comm->size == 1) return OI_OK;
+  if (!h->comm) return OI_OK;
   char* b = (char*)base;
   const Geom& g = h->g;
   return h->comm->exchange(b + plane_bytes * 1, b + plane_bytes * 0, b + plane_bytes * (size_t)g.nzl,
@@ -319,8 +323,10 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->x, (size_t)g.nvec));
   OIC(dmalloc(h, &h->r, (size_t)g.nvec));
   OIC(dmalloc(h, &h->q, (size_t)g.nvec));
-  OIC(dmalloc(h, &h->p[0], (size_t)g.nvec));
-  if (h->fused) OIC(dmalloc(h, &h->p[1], (size_t)g.nvec));
+  for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
+    HIPC(hipMalloc(&h->p[b], (size_t)g.nvec * h->p_elem));
+    h->bytes_device += (size_t)g.nvec * h->p_elem;
+  }
   h->vectors_ready = true;
   h->st.t_setup_s = now_s() - t2;
   h->st.bytes_device = (double)h->bytes_device;
@@ -347,11 +353,19 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   OIC(ensure_device(comm ? comm->device : o.device, &device));
   std::unique_ptr<oi_tort, void (*)(oi_tort*)> h(new oi_tort(), oi_tort_destroy);
   h->opts = o;
-  h->comm = (comm && comm->size > 1) ? comm : nullptr;
+  // a one-rank communicator is dropped unless OI_FORCE_COMM is set (single-GPU rehearsal of
+  // the collective code path)
+  h->comm = (comm && (comm->size > 1 || getenv("OI_FORCE_COMM"))) ? comm : nullptr;
   h->device = device;
   h->phase_id = phase_id;
   h->jacobi = o.precond == OI_PRECOND_JACOBI;
   h->fused = o.kernel != OI_KERNEL_UNFUSED;
+  h->p_f32 = o.p_storage == OI_STORE_F32;
+  h->p_elem = h->p_f32 ? sizeof(float) : sizeof(double);
+  if (h->p_f32 && !h->fused) {
+    oi::set_error("fp32 storage of the search direction needs the fused kernel");
+    return OI_BAD_ARG;
+  }
   Geom& g = h->g;
   g.nx = nx; g.ny = ny; g.nz = nz; g.z0 = z0; g.nzl = nzl; g.dir = dir;
   g.pitch = (nx + 1) & ~1;
@@ -429,11 +443,11 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * h->hist_cap, s));
   HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, s));
   HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
-  HIPC(hipMemsetAsync(h->p[0], 0, sizeof(double) * g.nvec, s));
-  if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, sizeof(double) * g.nvec, s));
+  HIPC(hipMemsetAsync(h->p[0], 0, h->p_elem * g.nvec, s));
+  if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * g.nvec, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
   int nb;
-  { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, h->p[0], h->jacobi, h->partials, s); }
+  { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, h->fused ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
   // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
   OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
   if (h->fused) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
@@ -448,11 +462,12 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
   hipStream_t s = h->stream;
   int nb;
   if (h->fused) {
-    double* p_in = h->p[(k + 1) & 1];
-    double* p_out = h->p[k & 1];
+    void* p_in = h->p[(k + 1) & 1];
+    void* p_out = h->p[k & 1];
     {
       PROF(K_FUSED_A);
-      nb = launch_fused_a(g, h->code, h->x, h->r, p_in, p_out, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s);
+      nb = launch_fused_a(g, h->code, h->x, h->r, p_in, p_out, h->p_f32 ? 1 : 0, h->q, h->jacobi, h->hist, k, h->partials,
+                          h->ctrl, s);
     }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     { PROF(K_UPDATE_R); nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
@@ -461,14 +476,15 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
   } else {
     if (k > 0) {
       PROF(K_UPDATE_P);
-      launch_update_p(g, h->code, h->r, h->p[0], h->jacobi, h->hist, k, h->ctrl, s);
+      launch_update_p(g, h->code, h->r, (double*)h->p[0], h->jacobi, h->hist, k, h->ctrl, s);
     }
     OIC(exchange_planes(h, h->p[0], sizeof(double) * g.plane));
-    { PROF(K_APPLY); nb = launch_apply(g, h->code, h->p[0], h->q, h->partials, h->ctrl, s); }
+    { PROF(K_APPLY); nb = launch_apply(g, h->code, (double*)h->p[0], h->q, h->partials, h->ctrl, s); }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     {
       PROF(K_UPDATE_XR);
-      nb = launch_update_xr(g, h->code, h->x, h->r, h->p[0], h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s);
+      nb = launch_update_xr(g, h->code, h->x, h->r, (double*)h->p[0], h->q, h->jacobi, h->hist, k, h->partials, h->ctrl,
+                            s);
     }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
   }
@@ -503,7 +519,7 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
   if (h->fused && K > 0) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
     PROF(K_AXPY);
-    launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->hist, K - 1, h->stream);
+    launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->hist, K - 1, h->stream);
   }
   double rr = 0.0;
   HIPC(hipMemcpyAsync(h->h_scal, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -712,7 +728,7 @@ extern "C" oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes) {
   return OI_OK;
 }
 
-// q = A v with either stencil kernel; uses p[0] / q as scratch, so only outside a solve
+// q = A v with either stencil kernel; uses r / q as scratch, so only outside a solve
 extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q, int variant) {
   if (!h || !v || !q) return OI_BAD_ARG;
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
@@ -725,12 +741,12 @@ extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q,
   oi_status rc = OI_OK;
   do {
     if (hipMemcpyAsync(dense, v, n * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipMemsetAsync(h->p[0], 0, sizeof(double) * g.nvec, h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
-    launch_pitch_copy_in(g, dense, h->p[0], h->stream);
-    rc = exchange_planes(h, h->p[0], sizeof(double) * g.plane);
+        hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+    launch_pitch_copy_in(g, dense, h->r, h->stream);
+    rc = exchange_planes(h, h->r, sizeof(double) * g.plane);
     if (rc != OI_OK) break;
-    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
-    else launch_apply_tiled(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
+    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
+    else launch_apply_tiled(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
     launch_pitch_copy_out(g, h->q, dense, h->stream);
     if (hipMemcpyAsync(q, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) rc = OI_HIP_ERROR;
@@ -747,14 +763,14 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   // a smooth non-trivial field: the ramp (p = x0); one untimed launch warms the code path
-  launch_init_field(g, h->active, h->p[0], h->stream);
+  launch_init_field(g, h->active, h->r, h->stream);
   hipEvent_t a, b;
   HIPC(hipEventCreate(&a));
   HIPC(hipEventCreate(&b));
   for (int i = -1; i < reps; ++i) {
     if (i == 0) HIPC(hipEventRecord(a, h->stream));
-    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
-    else launch_apply_tiled(g, h->code, h->p[0], h->q, h->partials, nullptr, h->stream);
+    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
+    else launch_apply_tiled(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
   }
   HIPC(hipEventRecord(b, h->stream));
   HIPC(hipEventSynchronize(b));
@@ -981,4 +997,7 @@ extern "C" const char* oi_status_string(oi_status s) {
   return "?";
 }
 extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
-extern "C" void oi_tort_set_tuning(int fused_by, int fused_zchunk) { oi::set_fused_tuning(fused_by, fused_zchunk); }
+extern "C" void oi_tort_set_tuning(int fused_tile_rows, int fused_zchunk) {
+  oi::set_fused_tuning(fused_tile_rows, fused_zchunk);
+}
+extern "C" void oi_tort_set_apply_tuning(int tile_rows) { oi::set_apply_tuning(tile_rows); }

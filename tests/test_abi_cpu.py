@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     # sizes as the C compiler lays the structs out (natural alignment, no packing)
     assert oia.Opts.__dict__ is not None
     import ctypes as C
-    assert C.sizeof(oia.Opts) == 40
+    assert C.sizeof(oia.Opts) == 48
     assert C.sizeof(oia.Stats) == 8 + 7 * 8 + 3 * 8 + 8 + 5 * 8 + 8
 
 

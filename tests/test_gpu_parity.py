@@ -83,9 +83,13 @@ def test_mask_codes_apply_bit_exact(shape, direction):
     rng = np.random.default_rng(5)
     v = np.where(mask > 0, rng.standard_normal(shape), 0.0)  # vectors vanish on inactive cells
     want = o.apply(code, v)
-    for variant in VARIANTS:
-        got = t.apply(v, variant)
-        assert np.array_equal(got, want), f"variant {variant}"
+    assert np.array_equal(t.apply(v, oia.KERNEL_UNFUSED), want)
+    try:
+        for rows in (8, 16, 32):  # LDS tile heights of the z-marching kernel
+            oia.set_tuning(rows, 0, rows)
+            assert np.array_equal(t.apply(v, oia.KERNEL_FUSED), want), f"tile rows {rows}"
+    finally:
+        oia.set_tuning()
     t.destroy()
 
 
@@ -104,6 +108,40 @@ def test_solve_matches_oracle(sample, variant, jacobi):
         assert st.flux_in == pytest.approx(ref["flux_in"], rel=1e-8)
         np.testing.assert_allclose(t.solution(), ref["x"], rtol=0, atol=1e-8)
         t.destroy()
+
+
+@pytest.mark.parametrize("rows,zchunk", [(8, 0), (16, 7), (32, 0)])
+def test_fused_tile_shapes_solve(sample, goldens, rows, zchunk):
+    """Every tile height / z-chunk length of the fused kernel gives the golden answer
+    (zchunk 7: many short chunks, exercising the chunk-boundary halo planes)."""
+    g = goldens["phases"]["0"]
+    try:
+        oia.set_tuning(rows, zchunk, rows)
+        t = oia.TortuosityMI355(sample, 0, 1, g["vlo"], g["vhi"], eps=1e-10, kernel=oia.KERNEL_FUSED)
+        assert t.value() == pytest.approx(g["tau"][1], rel=1e-7)
+        assert t.stats().flux_in == pytest.approx(g["flux"][1], rel=1e-7)
+    finally:
+        oia.set_tuning()
+
+
+@pytest.mark.parametrize("jacobi", [False, True])
+def test_fp32_stored_search_direction(sample, goldens, jacobi):
+    """p kept in fp32 in HBM (x, r, q and all arithmetic fp64): same answer, same iteration
+    count to within a few, and r stays the TRUE residual of x (checked with the oracle)."""
+    g = goldens["phases"]["1"]
+    kw = dict(eps=1e-10, precond=oia.PRECOND_JACOBI if jacobi else oia.PRECOND_NONE)
+    t64 = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], **kw)
+    t32 = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], p_storage=oia.STORE_F32, **kw)
+    tau64, tau32 = t64.value(), t32.value()
+    assert tau32 == pytest.approx(g["tau"][0], rel=1e-7) and tau32 == pytest.approx(tau64, rel=1e-8)
+    assert abs(t32.getSolverIterations() - t64.getSolverIterations()) <= 5
+    mask, _ = o.active_mask(sample, 1, 0)
+    code = o.codes(mask, 0)
+    x = t32.solution()
+    true_rel = np.linalg.norm(o.apply(code, x)) / o.bnorm(mask, 0, g["vlo"], g["vhi"])
+    assert true_rel <= 1.05e-10 and t32.getFinalRelativeResidualNorm() <= 1e-10
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TortuosityMI355(sample, 1, 0, p_storage=oia.STORE_F32, kernel=oia.KERNEL_UNFUSED)
 
 
 def test_known_answers_and_failure_semantics(goldens):

@@ -64,11 +64,12 @@ def test_slabs_match_single_domain(nranks, direction):
     np.testing.assert_allclose(x, ref["x"], rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("variant,jacobi", [(oia.KERNEL_UNFUSED, False), (oia.KERNEL_FUSED, True)])
-def test_slab_variants_on_sample(sample_phase, goldens, variant, jacobi):
+@pytest.mark.parametrize("variant,jacobi,pf32", [(oia.KERNEL_UNFUSED, False, 0), (oia.KERNEL_FUSED, True, 0),
+                                                 (oia.KERNEL_FUSED, False, 1)])
+def test_slab_variants_on_sample(sample_phase, goldens, variant, jacobi, pf32):
     g = goldens["phases"]["1"]
     sub = np.ascontiguousarray(sample_phase)
-    outs = run_slabs(sub, 1, 2, 4, g["vlo"], g["vhi"], eps=1e-10, kernel=variant,
+    outs = run_slabs(sub, 1, 2, 4, g["vlo"], g["vhi"], eps=1e-10, kernel=variant, p_storage=pf32,
                      precond=oia.PRECOND_JACOBI if jacobi else oia.PRECOND_NONE)
     assert outs[0]["tau"] == pytest.approx(g["tau"][2], rel=1e-7)
     assert outs[0]["st"]["flux_in"] == pytest.approx(g["flux"][2], rel=1e-7)

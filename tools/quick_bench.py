@@ -1,29 +1,24 @@
-"""Scratch timing helper used during development (not part of the contract)."""
+"""Scratch A/B timing helper used during development (not part of the contract).
+usage: quick_bench.py N [b|s] : sweeps tile rows / p storage on one structure."""
 import sys, time
+sys.path.insert(0, ".")
 import numpy as np
 import openimpala_amd as oia
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+kind = sys.argv[2] if len(sys.argv) > 2 else "s"
 shape = (n, n, n)
-t0 = time.time()
-buf = oia.gen_bernoulli_device(shape, 20251031, 0.5) if (len(sys.argv) < 3 or sys.argv[2] == "b") else oia.gen_spheres_device(shape, 7, 24 if n >= 512 else 8, 0.4)
-print("gen %.2fs" % (time.time() - t0), flush=True)
-for variant in (oia.KERNEL_FUSED, oia.KERNEL_UNFUSED):
-    t0 = time.time()
-    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-6, kernel=variant, profile=1)
-    st = t.stats()
-    print("variant", variant, "create %.2fs mask %.2fs sweeps %d vf %.4f avf %.4f nfree %d mem %.1f GB" % (time.time() - t0, st.t_mask_s, st.flood_sweeps, st.vf, st.active_vf, st.n_free, st.bytes_device / 1e9), flush=True)
-    for v in (oia.KERNEL_FUSED, oia.KERNEL_UNFUSED):
-        ms = t.bench_apply(20, v)
-        print("  apply variant %d: %.3f ms  %.1f GB/s (17 B/voxel)" % (v, ms, 17 * n ** 3 / ms / 1e6), flush=True)
-    t.reset_kernel_times()
-    t.cg_begin(); t.cg_iterate(20); t.sync()
-    t.reset_kernel_times()
-    t0 = time.time()
-    t.cg_iterate(100); t.sync()
-    dt = time.time() - t0
-    print("  100 iters %.3fs -> %.1f Mvoxel-iters/s ; state" % (dt, n ** 3 * 100 / dt / 1e6), t.cg_state(), flush=True)
-    for k, (ms, cnt) in t.kernel_times().items():
-        print("    %-12s %8.3f ms/launch x %d" % (k, ms / cnt, cnt))
-    t.cg_finish()
-    t.destroy()
+buf = oia.gen_bernoulli_device(shape, 20251031, 0.5) if kind == "b" else oia.gen_spheres_device(shape, 20251031, 24 if n >= 512 else 8, 0.4)
+configs = [(16, 0, 0), (16, 0, 1), (8, 0, 0)]
+for rows, zchunk, pf32 in configs:
+    oia.set_tuning(rows, zchunk, 32)
+    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, kernel=oia.KERNEL_FUSED, profile=1, p_storage=pf32, maxiter=100000)
+    ms_apply = t.bench_apply(10, oia.KERNEL_FUSED)
+    t.cg_begin(); t.cg_iterate(10); t.sync(); t.reset_kernel_times()
+    t0 = time.time(); t.cg_iterate(50); t.sync(); dt = time.time() - t0
+    kt = t.kernel_times()
+    fa = kt["fused_a"][0] / kt["fused_a"][1]; ur = kt["update_r"][0] / kt["update_r"][1]
+    bpv = 41 if pf32 else 49
+    print("rows %2d zchunk %4d p_f32 %d | apply %.3f ms (%.0f GB/s) | fused_a %.3f ms (%.0f GB/s @%dB) update_r %.3f ms | %.2f ms/iter %.0f Mvox-it/s" % (
+        rows, zchunk, pf32, ms_apply, 17 * n ** 3 / ms_apply / 1e6, fa, bpv * n ** 3 / fa / 1e6, bpv, ur, dt / 50 * 1e3, n ** 3 * 50 / dt / 1e6), flush=True)
+    t.cg_finish(); t.destroy()
