@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 # compulsory HBM bytes per voxel of each kernel
-BYTES_PER_VOXEL = {"fused_a": 49.0, "update_r": 24.0, "apply": 17.0, "update_p": 24.0, "update_xr": 48.0}
+BYTES_PER_VOXEL = {"cg1": 65.0, "fused_a": 49.0, "update_r": 24.0, "apply": 17.0, "update_p": 24.0, "update_xr": 48.0}
 
 
 def parse():
@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024, help="voxels per edge")
     ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli"])
-    ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
+    ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused"])
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
@@ -136,7 +136,7 @@ def main():
     t_gen = time.time()
     buf, desc = make_structure(oia, args, shape, z0, nzl)
     t_gen = time.time() - t_gen
-    kernel = oia.KERNEL_FUSED if args.kernel == "fused" else oia.KERNEL_UNFUSED
+    kernel = {"fused1": oia.KERNEL_FUSED1, "fused": oia.KERNEL_FUSED, "unfused": oia.KERNEL_UNFUSED}[args.kernel]
     precond = oia.PRECOND_JACOBI if args.precond == "jacobi" else oia.PRECOND_NONE
     t_create = time.time()
     # eps = 1e-300 during the timed region: every one of the K steps does full work
@@ -232,7 +232,7 @@ def main():
 
     # ---- variant: search direction p STORED as fp32 (x, r, q and all arithmetic fp64) ----
     variants = None
-    if not args.no_variants and args.kernel == "fused":
+    if not args.no_variants and args.kernel != "unfused":
         t.destroy()
         buf2, _ = make_structure(oia, args, shape, z0, nzl)
         kw2 = dict(kw, p_storage=oia.STORE_F32)
@@ -262,7 +262,7 @@ def main():
             "note": "search direction kept as fp32 in HBM; x, r, q and every operation fp64; r stays the exact "
                     "recurrence residual of x (tests/test_gpu_parity.py::test_fp32_stored_search_direction)",
             "value": n ** 3 * args.steps / vdt / 1e6, "unit": "Mvoxel-iters/s", "ms_per_step": vdt / args.steps * 1e3,
-            "bytes_per_voxel_iter": 65.0,
+            "bytes_per_voxel_iter": alg_bytes_iter - 8.0,
             "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in vk.items()}}}
 
     cpu = None

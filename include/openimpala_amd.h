@@ -46,7 +46,9 @@ typedef struct oi_tort oi_tort; /* replaces an OpenImpala::TortuosityHypre objec
 typedef struct oi_comm oi_comm; /* replaces MPI_COMM_WORLD / amrex::ParallelDescriptor for this path */
 
 enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1 };
-enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2 };
+/* UNFUSED: apply / p-update / x,r-update kernels (89 B/voxel-iter); FUSED: two kernels (73 B);
+ * FUSED1: ONE kernel per iteration with a single reduction (65 B), see DESIGN.md section 4 */
+enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2, OI_KERNEL_FUSED1 = 3 };
 enum { OI_STORE_F64 = 0, OI_STORE_F32 = 1 };
 
 /* Options.  `eps` / `maxiter` are the reference's hypre.eps / hypre.maxiter
@@ -163,6 +165,8 @@ oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_
 void oi_tort_set_tuning(int fused_tile_rows, int fused_planes_per_block);
 /* rows per LDS tile (8, 16 or 32) of the stand-alone stencil apply */
 void oi_tort_set_apply_tuning(int tile_rows);
+/* rows per LDS tile (8, 16 or 32) of the single-kernel CG iteration */
+void oi_tort_set_cg1_tuning(int tile_rows);
 
 /* per-kernel HIP-event timings gathered while opts.profile = 1.  names: fixed list,
  * see oi_kernel_name().  Returns the number of kernels written (<= cap). */

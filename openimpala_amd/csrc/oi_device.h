@@ -39,7 +39,7 @@ struct Ctrl {
 
 enum KernelId {
   K_PACK = 0, K_SEED, K_FLOOD, K_MASK, K_CODES, K_INIT, K_RESID0, K_APPLY, K_UPDATE_P, K_UPDATE_XR,
-  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_COUNT
+  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_CG1, K_COUNT
 };
 
 // maximum number of per-block partial sums any reducing kernel writes
@@ -81,6 +81,15 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
                        const Ctrl* ctrl, hipStream_t s);
 void set_fused_tuning(int tile_rows, int zchunk);
 void set_apply_tuning(int tile_rows);
+// single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
+int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
+               double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
+               double* partials, const Ctrl* ctrl, hipStream_t s);
+void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
+                      hipStream_t s);
+void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);
+void set_cg1_tuning(int tile_rows);
+constexpr int kRec1Stride = 8;  // doubles per iteration record; [0] = r.r
 // r -= alpha q; partials {rr, rz}
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi,
                     const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);

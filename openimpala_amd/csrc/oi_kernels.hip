@@ -806,6 +806,265 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 }
 
 // --------------------------------------------------------------------------------------
+// Single-kernel CG iteration ("cg1").  Kernel k turns the state after k-1 iterations into
+// the state after k iterations plus the next search direction and its image:
+//     x_k  = x_{k-1} + alpha_{k-1} p_{k-1}
+//     r_k  = r_{k-1} - alpha_{k-1} q_{k-1}
+//     p_k  = z_k + beta_k p_{k-1}            (z = r or r/code)
+//     q_k  = A p_k
+//     partials { r_k.r_k, r_k.z_k, p_k.q_k, z_k.q_k, q_k.D^-1 q_k }
+// One reduction per iteration: alpha_k = rz_k / pq and, because r_{k+1} = r_k - alpha_k q_k,
+//     rz_{k+1} = rz_k - 2 alpha_k (z_k.q_k) + alpha_k^2 (q_k.D^-1 q_k)      (exact arithmetic)
+// gives beta_{k+1} = rz_{k+1} / rz_k BEFORE r_{k+1} exists; the next kernel forms r_{k+1}
+// and reports its exact norms, so the extrapolation never spans more than one step
+// (D'Azevedo/Eijkhout/Romine-style rearrangement; measured on the 100^3 sample: same
+// iteration counts as textbook CG down to 1e-11, r stays the true residual of x).
+// Same z-marching LDS-tiled structure as k_fused_a; r_k and p_k on the halo ring are
+// recomputed from r_{k-1}, q_{k-1}, p_{k-1}, which is why r, q and p are all
+// double-buffered (a neighbouring block may already have overwritten its tile).
+// Compulsory HBM traffic: reads r 8 + q 8 + p 8 + x 8 + code 1, writes r 8 + q 8 + p 8 + x 8
+// = 65 B/voxel-iteration in ONE launch (57 with p stored as fp32).
+// rec[k] = { rr, rz, pq, zq, qdq, alpha_k, beta_{k+1}, - }.
+// --------------------------------------------------------------------------------------
+enum { R1_RR = 0, R1_RZ, R1_PQ, R1_ZQ, R1_QDQ, R1_ALPHA, R1_BETA, R1_STRIDE = 8 };
+
+template <int R, typename PT, bool JACOBI>
+__global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+                                                   const double* __restrict__ r_in, double* __restrict__ r_out,
+                                                   const double* __restrict__ q_in, double* __restrict__ q_out,
+                                                   const PT* __restrict__ p_in, PT* __restrict__ p_out,
+                                                   const double* __restrict__ rec, int k, int zchunk, int tiles_x,
+                                                   int tiles_y, int nzc, double* __restrict__ partials,
+                                                   const Ctrl* __restrict__ ctrl) {
+  constexpr int BY = kNW * R;
+  static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
+  if (ctrl->done) return;
+  __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
+  __shared__ double red[kNW];
+
+  const int ntiles = tiles_x * tiles_y * nzc;
+  int L = blockIdx.x;
+  if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
+
+  double beta = 0.0, alpha_prev = 0.0;
+  if (k > 0) {
+    alpha_prev = rec[R1_STRIDE * (k - 1) + R1_ALPHA];
+    beta = rec[R1_STRIDE * (k - 1) + R1_BETA];
+  }
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = tx * kBX + 2 * lane, j0 = ty * BY;
+  const bool in_x = i < g.pitch;
+  const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);
+
+  const int hrow = (w == 0) ? j0 - 1 : j0 + BY;
+  const bool yhalo = (w < 2) && in_x && hrow >= 0 && hrow < g.ny;
+  const int xh_row = j0 + (lane >> 1);
+  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
+
+  auto pnew_at = [&](long long e) -> double {
+    double z = r_in[e] - alpha_prev * q_in[e];
+    if (JACOBI) { const unsigned c = code[e]; if (c) z = z / (double)c; }
+    return PIo<PT>::rnd(z + beta * (double)p_in[e]);
+  };
+  // mode 0: a halo plane owned by another block (nothing stored); 1: an output plane of this
+  // block (r_k, p_k stored, x updated at once: keeps p_{k-1} out of the register budget);
+  // 2: a ghost plane of the slab, kept current by the block that marches over it (r_k, p_k)
+  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&rn)[R], int mode) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      pn[rr_] = make_double2(0.0, 0.0);
+      rn[rr_] = make_double2(0.0, 0.0);
+      if (in_x && j < g.ny) {
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const double2 rv = ld2(r_in + e), qv = ld2(q_in + e);
+        const double2 pin = PIo<PT>::ld_pair(p_in + e);
+        const double r0 = rv.x - alpha_prev * qv.x, r1 = rv.y - alpha_prev * qv.y;
+        rn[rr_] = make_double2(r0, r1);
+        double z0 = r0, z1 = r1;
+        if (JACOBI) {
+          const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+          if (cc & 0xff) z0 = r0 / (double)(cc & 0xff);
+          if (cc >> 8) z1 = r1 / (double)(cc >> 8);
+        }
+        pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
+        if (mode != 0) {
+          st2(r_out + e, r0, r1);
+          PIo<PT>::st_pair(p_out + e, pn[rr_].x, pn[rr_].y);
+          if (mode == 1 && k > 0) {
+            const double2 xv = ld2(x + e);
+            st2(x + e, xv.x + alpha_prev * pin.x, xv.y + alpha_prev * pin.y);
+          }
+        }
+      }
+    }
+  };
+  auto stage = [&](int b, int gz, const double2 (&pn)[R]) {
+    double* T = tile[b];
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_)
+      *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+    if (w < 2) {
+      double2 h = make_double2(0.0, 0.0);
+      if (yhalo) {
+        const long long e = (long long)gz * g.plane + (long long)hrow * g.pitch + i;
+        h.x = pnew_at(e); h.y = pnew_at(e + 1);
+      }
+      *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+    } else if (w == 2 && lane < 2 * BY) {
+      double h = 0.0;
+      if (xhalo) h = pnew_at((long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i);
+      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    }
+  };
+
+  double2 pn_prev[R], pn_cur[R], pn_nxt[R], rn_cur[R], rn_nxt[R];
+  load_plane(gs - 1, pn_prev, rn_nxt, gs == 1 ? 2 : 0);
+  load_plane(gs, pn_cur, rn_cur, 1);
+  stage(gs & 1, gs, pn_cur);
+  __syncthreads();
+
+  double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
+  for (int gz = gs; gz < ge; ++gz) {
+    load_plane(gz + 1, pn_nxt, rn_nxt, gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0));
+    if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
+    const double* T = tile[gz & 1];
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      if (in_x && j < g.ny) {
+        const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
+        const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
+        const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
+        const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
+        const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
+        const double2 pc = pn_cur[rr_], rc = rn_cur[rr_];
+        const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
+        const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + pn_prev[rr_].y) + pn_nxt[rr_].y;
+        const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
+        const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
+        st2(q_out + e, q0, q1);
+        double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
+        if (JACOBI) {
+          if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
+          if (c1) { z1 = rc.y / (double)c1; d1 = q1 / (double)c1; }
+        }
+        s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
+        s_rz += rc.x * z0; s_rz += rc.y * z1;
+        s_pq += pc.x * q0; s_pq += pc.y * q1;
+        s_zq += z0 * q0; s_zq += z1 * q1;
+        s_qdq += q0 * d0; s_qdq += q1 * d1;
+      }
+    }
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) { pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; rn_cur[rr_] = rn_nxt[rr_]; }
+    __syncthreads();
+  }
+  const double t0 = block_sum(s_rr, red);
+  const double t1 = block_sum(s_rz, red);
+  const double t2 = block_sum(s_pq, red);
+  const double t3 = block_sum(s_zq, red);
+  const double t4 = block_sum(s_qdq, red);
+  if (threadIdx.x == 0) {
+    double* o = partials + 5 * (long long)blockIdx.x;
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
+  }
+}
+
+static int g_cg1_rows = 2;
+void set_cg1_tuning(int tile_rows) {
+  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_cg1_rows = tile_rows / 8;
+}
+
+template <int R, typename PT>
+static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
+                         const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
+                         const double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, double* partials,
+                         const Ctrl* ctrl, hipStream_t s) {
+  if (jacobi)
+    hipLaunchKernelGGL((k_cg1<R, PT, true>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
+                       (const PT*)p_in, (PT*)p_out, rec, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  else
+    hipLaunchKernelGGL((k_cg1<R, PT, false>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
+                       (const PT*)p_in, (PT*)p_out, rec, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+}
+
+int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
+               double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
+               double* partials, const Ctrl* ctrl, hipStream_t s) {
+  const int R = g_cg1_rows, by = kNW * R;
+  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)tiles_x * tiles_y;
+  const int max_blocks = kMaxPartials;  // five partial sums per block, partials holds 8 per block
+  long long want = (4096 + cols - 1) / cols;
+  if (want < 1) want = 1;
+  int zchunk = g_fused_zchunk > 0 ? g_fused_zchunk : (int)((g.nzl + want - 1) / want);
+  if (g_fused_zchunk <= 0 && zchunk < 64) zchunk = 64;
+  if (zchunk > g.nzl) zchunk = g.nzl;
+  int nzc = (g.nzl + zchunk - 1) / zchunk;
+  if (cols * nzc > max_blocks) {
+    const int maxc = (int)(max_blocks / cols) > 0 ? (int)(max_blocks / cols) : 1;
+    zchunk = (g.nzl + maxc - 1) / maxc;
+    nzc = (g.nzl + zchunk - 1) / zchunk;
+  }
+  const int blocks = (int)(cols * nzc);
+#define OI_CG1(RR)                                                                                              \
+  do {                                                                                                          \
+    if (p_f32) launch_cg1_r<RR, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k, \
+                                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                       \
+    else launch_cg1_r<RR, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,    \
+                                  zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                            \
+  } while (0)
+  if (R == 4) OI_CG1(4);
+  else if (R == 2) OI_CG1(2);
+  else OI_CG1(1);
+#undef OI_CG1
+  return blocks;
+}
+
+// after the 5 sums of kernel k are in rec[k] (all-reduced in multi-rank runs): convergence
+// test on the exact ||r_k||, alpha_k, and beta_{k+1} from the one-step extrapolation
+__device__ __forceinline__ void cg1_scalars(double* rk, Ctrl* ctrl, int k) {
+  if (!ctrl->done && rk[R1_RR] <= ctrl->tol2) { ctrl->done = k + 1; }
+  const double alpha = safe_div(rk[R1_RZ], rk[R1_PQ]);
+  double rz_next = rk[R1_RZ] - 2.0 * alpha * rk[R1_ZQ] + alpha * alpha * rk[R1_QDQ];
+  if (!(rz_next > 0.0)) rz_next = 0.0;  // cancellation at exact convergence: restart direction
+  rk[R1_ALPHA] = alpha;
+  rk[R1_BETA] = safe_div(rz_next, rk[R1_RZ]);
+}
+
+__global__ void __launch_bounds__(256) k_finalize1(const double* __restrict__ partials, int nblocks, double* rk,
+                                                    Ctrl* ctrl, int k, int with_scalars) {
+  if (ctrl->done) return;
+  __shared__ double red[4];
+  for (int c = 0; c < 5; ++c) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += partials[(long long)b * 5 + c];
+    const double t = block_sum(v, red);
+    if (threadIdx.x == 0) rk[c] = t;
+  }
+  if (threadIdx.x == 0 && with_scalars) cg1_scalars(rk, ctrl, k);
+}
+
+__global__ void k_scalars1(double* rk, Ctrl* ctrl, int k) {
+  if (!ctrl->done) cg1_scalars(rk, ctrl, k);
+}
+
+void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(256), 0, s, partials, nblocks, rec_k, ctrl, k, with_scalars);
+}
+void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s) {
+  hipLaunchKernelGGL(k_scalars1, dim3(1), dim3(1), 0, s, rec_k, ctrl, k);
+}
+
+// --------------------------------------------------------------------------------------
 // Deterministic final sums: one block adds the per-block partials in a fixed order.
 // --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ partials, int nblocks, int ncomp,

@@ -49,7 +49,7 @@ static double now_s() {
 
 static const char* kKernelNames[K_COUNT] = {
     "pack_open", "seed", "flood_sweep", "mask_and", "codes", "init_field", "residual0", "apply",
-    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate"};
+    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate", "cg1"};
 
 struct ProfRec {
   int kid;
@@ -68,6 +68,8 @@ struct oi_tort {
   uint64_t *open = nullptr, *active = nullptr /* reach_lo, then the mask */, *rhi = nullptr;
   uint8_t* code = nullptr;
   double *x = nullptr, *r = nullptr, *q = nullptr;
+  double *r2 = nullptr, *q2 = nullptr;  // second buffers of the single-kernel variant
+  double* rec = nullptr;                // its per-iteration scalar records
   void* p[2] = {nullptr, nullptr};  // search direction: fp64, or fp32 storage when p_f32
   bool p_f32 = false;
   size_t p_elem = sizeof(double);
@@ -85,7 +87,8 @@ struct oi_tort {
   size_t bytes_device = 0;
 
   // state
-  bool fused = true;
+  bool fused = true;   // fused two-kernel iteration or single-kernel iteration (double-buffered p)
+  bool cg1 = false;    // single-kernel iteration
   bool jacobi = false;
   bool percolates = false;
   bool vectors_ready = false;
@@ -184,7 +187,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1],
+  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec,
                  h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
   for (void* d : dev)
     if (d) (void)hipFree(d);
@@ -231,7 +234,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->counters, 8));
   OIC(dmalloc(h, &h->changed, 1));
   OIC(dmalloc(h, &h->scal, 8));
-  OIC(dmalloc(h, &h->partials, (size_t)2 * kMaxPartials));
+  OIC(dmalloc(h, &h->partials, (size_t)8 * kMaxPartials));
   OIC(dmalloc(h, &h->ctrl, 1));
   HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
   HIPC(hipHostMalloc((void**)&h->h_counters, 8 * sizeof(unsigned long long)));
@@ -323,6 +326,11 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->x, (size_t)g.nvec));
   OIC(dmalloc(h, &h->r, (size_t)g.nvec));
   OIC(dmalloc(h, &h->q, (size_t)g.nvec));
+  if (h->cg1) {
+    OIC(dmalloc(h, &h->r2, (size_t)g.nvec));
+    OIC(dmalloc(h, &h->q2, (size_t)g.nvec));
+    OIC(dmalloc(h, &h->rec, (size_t)kRec1Stride * h->hist_cap));
+  }
   for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
     HIPC(hipMalloc(&h->p[b], (size_t)g.nvec * h->p_elem));
     h->bytes_device += (size_t)g.nvec * h->p_elem;
@@ -360,6 +368,7 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->phase_id = phase_id;
   h->jacobi = o.precond == OI_PRECOND_JACOBI;
   h->fused = o.kernel != OI_KERNEL_UNFUSED;
+  h->cg1 = o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_AUTO;  // fastest variant is the default
   h->p_f32 = o.p_storage == OI_STORE_F32;
   h->p_elem = h->p_f32 ? sizeof(float) : sizeof(double);
   if (h->p_f32 && !h->fused) {
@@ -447,10 +456,19 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * g.nvec, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
   int nb;
-  { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, h->fused ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
-  // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
-  OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
-  if (h->fused) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+  if (h->cg1) {
+    // kernel 0 reads buffer 1: r_{-1} := r_0 with alpha_{-1} = 0, q_{-1} = p_{-1} = 0
+    HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * g.nvec, s));
+    HIPC(hipMemsetAsync(h->q2, 0, sizeof(double) * g.nvec, s));
+    HIPC(hipMemsetAsync(h->rec, 0, sizeof(double) * kRec1Stride * h->hist_cap, s));
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, s); }
+    OIC(exchange_planes(h, h->r2, sizeof(double) * g.plane));
+  } else {
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, h->fused ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
+    // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
+    OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
+    if (h->fused) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+  }
   h->iters_issued = 0;
   h->iters_done = 0;
   h->cg_active = true;
@@ -461,7 +479,24 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
   const Geom& g = h->g;
   hipStream_t s = h->stream;
   int nb;
-  if (h->fused) {
+  if (h->cg1) {
+    const int in = (k + 1) & 1, out = k & 1;
+    double* rb[2] = {h->r, h->r2};
+    double* qb[2] = {h->q, h->q2};
+    {
+      PROF(K_CG1);
+      nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], h->p_f32 ? 1 : 0,
+                      h->jacobi ? 1 : 0, h->rec, k, h->partials, h->ctrl, s);
+    }
+    double* rk = h->rec + (size_t)kRec1Stride * k;
+    const bool multi = h->comm != nullptr;
+    { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, multi ? 0 : 1, s); }
+    if (multi) {
+      OIC(h->comm->allreduce_sum_f64(rk, 5, s));
+      launch_scalars1(rk, h->ctrl, k, s);
+      OIC(exchange_planes(h, qb[out], sizeof(double) * g.plane));  // the ONE plane exchange per iteration
+    }
+  } else if (h->fused) {
     void* p_in = h->p[(k + 1) & 1];
     void* p_out = h->p[k & 1];
     {
@@ -495,8 +530,9 @@ extern "C" oi_status oi_tort_cg_iterate(oi_tort* h, int n) {
   if (!h || n < 0) return OI_BAD_ARG;
   if (!h->cg_active) return OI_BAD_ARG;
   HIPC(hipSetDevice(h->device));
+  const int limit = h->maxiter + (h->cg1 ? 1 : 0);  // kernel k of the single-kernel variant completes iteration k
   for (int i = 0; i < n; ++i) {
-    if (h->iters_issued >= h->maxiter) break;
+    if (h->iters_issued >= limit) break;
     OIC(cg_one_iteration(h, h->iters_issued));
     ++h->iters_issued;
   }
@@ -515,16 +551,18 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
   HIPC(hipSetDevice(h->device));
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
-  const int K = done ? done - 1 : h->iters_issued;  // iterations whose x/r updates are in effect
-  if (h->fused && K > 0) {
+  // iterations whose x/r updates are in effect
+  const int K = done ? done - 1 : (h->cg1 ? std::max(0, h->iters_issued - 1) : h->iters_issued);
+  if (h->fused && !h->cg1 && K > 0) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
     PROF(K_AXPY);
     launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->hist, K - 1, h->stream);
   }
   double rr = 0.0;
-  HIPC(hipMemcpyAsync(h->h_scal, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const double* rr_src = h->cg1 ? h->rec + (size_t)kRec1Stride * K : h->hist + H_STRIDE * K + H_RR;
+  HIPC(hipMemcpyAsync(h->h_scal, rr_src, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
-  rr = h->h_scal[0];
+  rr = (h->cg1 && h->iters_issued == 0) ? std::numeric_limits<double>::quiet_NaN() : h->h_scal[0];
   h->iters_done = K;
   h->st.iterations = K;
   h->st.final_relres = h->bnorm > 0.0 ? std::sqrt(rr) / h->bnorm : std::sqrt(rr);
@@ -555,8 +593,9 @@ extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* 
   HIPC(hipSetDevice(h->device));
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
-  const int K = done ? done - 1 : h->iters_issued;
-  HIPC(hipMemcpyAsync(h->h_scal, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const int K = done ? done - 1 : (h->cg1 ? std::max(0, h->iters_issued - 1) : h->iters_issued);
+  const double* rr_src = h->cg1 ? h->rec + (size_t)kRec1Stride * K : h->hist + H_STRIDE * K + H_RR;
+  HIPC(hipMemcpyAsync(h->h_scal, rr_src, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
   if (iterations_done) *iterations_done = K;
   if (relres) *relres = h->bnorm > 0.0 ? std::sqrt(h->h_scal[0]) / h->bnorm : std::sqrt(h->h_scal[0]);
@@ -581,7 +620,8 @@ static oi_status solve(oi_tort* h) {
   // initial check (converged before iterating)
   rc = poll_ctrl(h);
   if (rc == OI_OK && h->h_ctrl->done) stop = true;
-  while (rc == OI_OK && !stop && h->iters_issued < h->maxiter) {
+  const int limit = h->maxiter + (h->cg1 ? 1 : 0);
+  while (rc == OI_OK && !stop && h->iters_issued < limit) {
     rc = oi_tort_cg_iterate(h, batch);
     if (rc != OI_OK) break;
     const int slot = nb & 1;
@@ -1001,3 +1041,4 @@ extern "C" void oi_tort_set_tuning(int fused_tile_rows, int fused_zchunk) {
   oi::set_fused_tuning(fused_tile_rows, fused_zchunk);
 }
 extern "C" void oi_tort_set_apply_tuning(int tile_rows) { oi::set_apply_tuning(tile_rows); }
+extern "C" void oi_tort_set_cg1_tuning(int tile_rows) { oi::set_cg1_tuning(tile_rows); }

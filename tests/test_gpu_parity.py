@@ -20,7 +20,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 TIF = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")
-VARIANTS = [oia.KERNEL_FUSED, oia.KERNEL_UNFUSED]
+VARIANTS = [oia.KERNEL_FUSED, oia.KERNEL_UNFUSED, oia.KERNEL_FUSED1]
 
 
 @pytest.fixture(scope="module")
@@ -120,6 +120,31 @@ def test_fused_tile_shapes_solve(sample, goldens, rows, zchunk):
         t = oia.TortuosityMI355(sample, 0, 1, g["vlo"], g["vhi"], eps=1e-10, kernel=oia.KERNEL_FUSED)
         assert t.value() == pytest.approx(g["tau"][1], rel=1e-7)
         assert t.stats().flux_in == pytest.approx(g["flux"][1], rel=1e-7)
+    finally:
+        oia.set_tuning()
+
+
+@pytest.mark.parametrize("rows,zchunk,jacobi,pf32", [(8, 0, False, 0), (16, 5, True, 0), (32, 0, False, 1)])
+def test_single_kernel_iteration(sample, goldens, rows, zchunk, jacobi, pf32):
+    """KERNEL_FUSED1: one launch and one reduction per CG iteration (beta from the one-step
+    extrapolation of r.z).  Same answer, same iteration count to within a few, and r is
+    still the true residual of x."""
+    g = goldens["phases"]["1"]
+    try:
+        oia.set_tuning(16, zchunk, 32, rows)
+        kw = dict(eps=1e-10, precond=oia.PRECOND_JACOBI if jacobi else oia.PRECOND_NONE)
+        ref = oia.TortuosityMI355(sample, 1, 2, g["vlo"], g["vhi"], kernel=oia.KERNEL_FUSED, **kw)
+        ref.value()
+        t = oia.TortuosityMI355(sample, 1, 2, g["vlo"], g["vhi"], kernel=oia.KERNEL_FUSED1, p_storage=pf32, **kw)
+        tau = t.value()
+        st = t.stats()
+        assert st.converged and tau == pytest.approx(g["tau"][2], rel=1e-7)
+        assert st.flux_in == pytest.approx(g["flux"][2], rel=1e-7)
+        assert abs(st.iterations - ref.getSolverIterations()) <= 5
+        mask, _ = o.active_mask(sample, 1, 2)
+        code = o.codes(mask, 2)
+        true_rel = np.linalg.norm(o.apply(code, t.solution())) / o.bnorm(mask, 2, g["vlo"], g["vhi"])
+        assert true_rel <= 1.05e-10
     finally:
         oia.set_tuning()
 

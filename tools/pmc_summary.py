@@ -21,6 +21,21 @@ def short(name):
     return name.strip()
 
 
+def bench_name(kernel):
+    """rocprof kernel name -> the kernel key bench.py uses"""
+    if kernel.startswith("k_cg1"):
+        return "cg1"
+    if kernel.startswith("k_fused_a"):
+        return "apply" if ", true" in kernel else "fused_a"
+    if kernel.startswith("k_update_xr"):
+        return "update_r" if kernel.startswith("k_update_xr<false") else "update_xr"
+    if kernel.startswith("k_apply"):
+        return "apply_direct"
+    if kernel.startswith("k_update_p"):
+        return "update_p"
+    return None
+
+
 def main(out):
     stats = find(os.path.join(out, "trace"), "*kernel_stats.csv")
     if stats:
@@ -30,6 +45,7 @@ def main(out):
             print("%-64s calls %6s  avg %10.1f us  total %8.2f ms  %5.1f%%" % (
                 short(r["Name"])[:64], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
                 float(r["Percentage"])))
+    traffic = defaultdict(float)
     for tag, counter, scale in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
         f = find(os.path.join(out, tag), "*counter_collection.csv")
         if not f:
@@ -44,6 +60,19 @@ def main(out):
         print(f"== {counter} per launch (KiB -> bytes, x{scale:g} gfx950 correction) ==")
         for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:10]:
             print("%-64s launches %6d  %14.0f bytes/launch" % (k[:64], n, v / n * 1024.0 * scale))
+        for k, (v, n) in acc.items():
+            if bench_name(k):
+                traffic[bench_name(k)] += v / n * 1024.0 * scale
+    if traffic:
+        import json
+        tagname = os.environ.get("OI_PMC_KEY", "1024:1")
+        js = {f"{k}:{tagname}": {"hbm_bytes_per_launch": v, "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
+                                 "separate passes, KiB -> bytes, mean over launches"} for k, v in traffic.items()}
+        with open(os.path.join(out, "pmc_summary.json"), "w") as f:
+            json.dump(js, f, indent=1)
+        print("== HBM bytes per launch (FETCH x2 + WRITE) ==")
+        for k, v in sorted(traffic.items()):
+            print("%-12s %14.0f" % (k, v))
 
 
 if __name__ == "__main__":

@@ -8,11 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --no-solve --no-cpu-baseline "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -20 $out/trace.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-variants "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -20 $out/trace.err; exit 1; }
 echo trace-done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-apply-bench "$@" > $out/bench_fetch.json 2> $out/fetch.err || { tail -20 $out/fetch.err; exit 1; }
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-variants "$@" > $out/bench_fetch.json 2> $out/fetch.err || { tail -20 $out/fetch.err; exit 1; }
 echo fetch-done
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-apply-bench "$@" > $out/bench_write.json 2> $out/write.err || { tail -20 $out/write.err; exit 1; }
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-variants "$@" > $out/bench_write.json 2> $out/write.err || { tail -20 $out/write.err; exit 1; }
 echo write-done
 python3 $R/tools/pmc_summary.py $out > $out/summary.txt
 cat $out/summary.txt
