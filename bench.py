@@ -23,8 +23,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
-# compulsory HBM bytes per voxel of each kernel
-BYTES_PER_VOXEL = {"cg1": 65.0, "fused_a": 49.0, "update_r": 24.0, "apply": 17.0, "update_p": 24.0, "update_xr": 48.0}
+# compulsory HBM bytes per voxel of each kernel; cg1: 57 B on odd and
+# 65 + 8 B on even iterations (x is touched every second iteration) = 61 B on average
+BYTES_PER_VOXEL = {"cg1": 61.0, "fused_a": 49.0, "update_r": 24.0, "apply": 17.0, "update_p": 24.0, "update_xr": 48.0}
 
 
 def parse():
@@ -262,7 +263,7 @@ def main():
             "note": "search direction kept as fp32 in HBM; x, r, q and every operation fp64; r stays the exact "
                     "recurrence residual of x (tests/test_gpu_parity.py::test_fp32_stored_search_direction)",
             "value": n ** 3 * args.steps / vdt / 1e6, "unit": "Mvoxel-iters/s", "ms_per_step": vdt / args.steps * 1e3,
-            "bytes_per_voxel_iter": alg_bytes_iter - 8.0,
+            "bytes_per_voxel_iter": alg_bytes_iter - (10.0 if args.kernel == "fused1" else 8.0),
             "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in vk.items()}}}
 
     cpu = None

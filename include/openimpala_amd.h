@@ -165,8 +165,9 @@ oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_
 void oi_tort_set_tuning(int fused_tile_rows, int fused_planes_per_block);
 /* rows per LDS tile (8, 16 or 32) of the stand-alone stencil apply */
 void oi_tort_set_apply_tuning(int tile_rows);
-/* rows per LDS tile (8, 16 or 32) of the single-kernel CG iteration */
-void oi_tort_set_cg1_tuning(int tile_rows);
+/* single-kernel CG iteration: rows per LDS tile (8, 16, 32; <= 0 automatic) and whether x is
+ * updated every second iteration with both pending terms (1, default) or every iteration (0) */
+void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
 
 /* per-kernel HIP-event timings gathered while opts.profile = 1.  names: fixed list,
  * see oi_kernel_name().  Returns the number of kernels written (<= cap). */

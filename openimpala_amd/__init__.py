@@ -130,7 +130,7 @@ def lib():
     L.oi_tort_set_tuning.restype = None
     L.oi_tort_set_apply_tuning.argtypes = [i]
     L.oi_tort_set_apply_tuning.restype = None
-    L.oi_tort_set_cg1_tuning.argtypes = [i]
+    L.oi_tort_set_cg1_tuning.argtypes = [i, i]
     L.oi_tort_set_cg1_tuning.restype = None
     L.oi_comm_unique_id.argtypes = [vp]
     L.oi_comm_create.argtypes = [pp, vp, i, i, i]
@@ -178,12 +178,13 @@ def default_opts(**kw):
     return o
 
 
-def set_tuning(fused_tile_rows=16, fused_zchunk=0, apply_tile_rows=32, cg1_tile_rows=16):
+def set_tuning(fused_tile_rows=16, fused_zchunk=0, apply_tile_rows=32, cg1_tile_rows=0, cg1_x_every_second=1):
     """Rows per LDS tile (8, 16 or 32) of the fused CG kernel / the stand-alone apply / the
-    single-kernel CG iteration, and planes per block of the z-march (0 = auto)."""
+    single-kernel CG iteration (0 = automatic), planes per block of the z-march (0 = auto),
+    and whether the single-kernel iteration touches x only every second iteration."""
     lib().oi_tort_set_tuning(fused_tile_rows, fused_zchunk)
     lib().oi_tort_set_apply_tuning(apply_tile_rows)
-    lib().oi_tort_set_cg1_tuning(cg1_tile_rows)
+    lib().oi_tort_set_cg1_tuning(cg1_tile_rows, cg1_x_every_second)
 
 
 # ------------------------------------------------------------------------------------------

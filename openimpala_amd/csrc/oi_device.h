@@ -88,7 +88,11 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);
-void set_cg1_tuning(int tile_rows);
+void set_cg1_tuning(int tile_rows);  // <= 0: automatic
+void set_cg1_xskip(int on);
+int cg1_xskip();
+void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, hipStream_t s);
+constexpr int kRec1Alpha = 5;
 constexpr int kRec1Stride = 8;  // doubles per iteration record; [0] = r.r
 // r -= alpha q; partials {rr, rz}
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi,

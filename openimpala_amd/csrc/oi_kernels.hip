@@ -565,6 +565,25 @@ __global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ 
   }
 }
 
+template <typename PT>
+__global__ void __launch_bounds__(256) k_axpy_ptr(Geom g, double* __restrict__ x, const PT* __restrict__ p,
+                                                   const double* __restrict__ alpha_ptr) {
+  const double alpha = *alpha_ptr;
+  const long long npairs = (long long)g.nzl * g.plane / 2;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long e = g.plane + 2 * t;
+    const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + e);
+    st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+  }
+}
+
+void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, hipStream_t s) {
+  const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
+  if (p_f32) hipLaunchKernelGGL(k_axpy_ptr<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, alpha_ptr);
+  else hipLaunchKernelGGL(k_axpy_ptr<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, alpha_ptr);
+}
+
 void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k,
                       hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
@@ -828,30 +847,35 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 // --------------------------------------------------------------------------------------
 enum { R1_RR = 0, R1_RZ, R1_PQ, R1_ZQ, R1_QDQ, R1_ALPHA, R1_BETA, R1_STRIDE = 8 };
 
-template <int R, typename PT, bool JACOBI>
-__global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+template <int R, int NW, typename PT, bool JACOBI>
+__global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                    const double* __restrict__ r_in, double* __restrict__ r_out,
                                                    const double* __restrict__ q_in, double* __restrict__ q_out,
                                                    const PT* __restrict__ p_in, PT* __restrict__ p_out,
-                                                   const double* __restrict__ rec, int k, int zchunk, int tiles_x,
-                                                   int tiles_y, int nzc, double* __restrict__ partials,
+                                                   const double* __restrict__ rec, int k, int xskip, int zchunk,
+                                                   int tiles_x, int tiles_y, int nzc, double* __restrict__ partials,
                                                    const Ctrl* __restrict__ ctrl) {
-  constexpr int BY = kNW * R;
+  constexpr int BY = NW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
-  __shared__ double red[kNW];
+  __shared__ double red[NW];
 
   const int ntiles = tiles_x * tiles_y * nzc;
   int L = blockIdx.x;
   if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
   const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
 
-  double beta = 0.0, alpha_prev = 0.0;
+  double beta = 0.0, alpha_prev = 0.0, alpha_prev2 = 0.0;
   if (k > 0) {
     alpha_prev = rec[R1_STRIDE * (k - 1) + R1_ALPHA];
     beta = rec[R1_STRIDE * (k - 1) + R1_BETA];
   }
+  // x is touched every iteration (xskip = 0) or every second one (xskip = 1): an even kernel
+  // k >= 2 adds alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}; p_{k-2} is what the p_out buffer
+  // still holds at the very address this thread is about to overwrite with p_k
+  const bool do_x = xskip ? (k >= 2 && (k & 1) == 0) : (k > 0);
+  if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = tx * kBX + 2 * lane, j0 = ty * BY;
@@ -875,7 +899,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, cons
   auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&rn)[R], int mode) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
-      const int j = j0 + w + rr_ * kNW;
+      const int j = j0 + w + rr_ * NW;
       pn[rr_] = make_double2(0.0, 0.0);
       rn[rr_] = make_double2(0.0, 0.0);
       if (in_x && j < g.ny) {
@@ -893,11 +917,16 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, cons
         pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
         if (mode != 0) {
           st2(r_out + e, r0, r1);
-          PIo<PT>::st_pair(p_out + e, pn[rr_].x, pn[rr_].y);
-          if (mode == 1 && k > 0) {
+          if (mode == 1 && do_x) {
             const double2 xv = ld2(x + e);
-            st2(x + e, xv.x + alpha_prev * pin.x, xv.y + alpha_prev * pin.y);
+            double a0 = alpha_prev * pin.x, a1 = alpha_prev * pin.y;
+            if (xskip) {
+              const double2 pold = PIo<PT>::ld_pair(p_out + e);  // p_{k-2}
+              a0 = alpha_prev2 * pold.x + a0; a1 = alpha_prev2 * pold.y + a1;
+            }
+            st2(x + e, xv.x + a0, xv.y + a1);
           }
+          PIo<PT>::st_pair(p_out + e, pn[rr_].x, pn[rr_].y);
         }
       }
     }
@@ -906,7 +935,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, cons
     double* T = tile[b];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
-      *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+      *reinterpret_cast<double2*>(&T[(w + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (yhalo) {
@@ -934,9 +963,9 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, cons
     const double* T = tile[gz & 1];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
-      const int j = j0 + w + rr_ * kNW;
+      const int j = j0 + w + rr_ * NW;
       if (in_x && j < g.ny) {
-        const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
+        const int base = (w + rr_ * NW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
         const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
@@ -977,28 +1006,45 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, cons
   }
 }
 
-static int g_cg1_rows = 2;
+static int g_cg1_rows = 2;   // rows per thread
+static int g_cg1_waves = 8;  // waves per block: tile height = waves * rows
+static bool g_cg1_auto = true;
+static int g_cg1_xskip = 1;
+int cg1_xskip() { return g_cg1_xskip; }
+void set_cg1_xskip(int on) { g_cg1_xskip = on ? 1 : 0; }
 void set_cg1_tuning(int tile_rows) {
-  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_cg1_rows = tile_rows / 8;
+  g_cg1_auto = tile_rows <= 0;
+  // 8, 16: 8-wave blocks with 1 or 2 rows per thread; 32: 16-wave blocks x 2 rows (the
+  // 8-wave x 4-row form needs 194 VGPRs and fits only one block per CU); 33 selects it
+  if (tile_rows == 8) { g_cg1_rows = 1; g_cg1_waves = 8; }
+  else if (tile_rows == 16) { g_cg1_rows = 2; g_cg1_waves = 8; }
+  else if (tile_rows == 32) { g_cg1_rows = 2; g_cg1_waves = 16; }
+  else if (tile_rows == 33) { g_cg1_rows = 4; g_cg1_waves = 8; }
 }
 
-template <int R, typename PT>
+template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                          const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
                          const double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, double* partials,
                          const Ctrl* ctrl, hipStream_t s) {
   if (jacobi)
-    hipLaunchKernelGGL((k_cg1<R, PT, true>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
-                       (const PT*)p_in, (PT*)p_out, rec, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+    hipLaunchKernelGGL((k_cg1<R, NW, PT, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
+                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, partials,
+                       ctrl);
   else
-    hipLaunchKernelGGL((k_cg1<R, PT, false>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
-                       (const PT*)p_in, (PT*)p_out, rec, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+    hipLaunchKernelGGL((k_cg1<R, NW, PT, false>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
+                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, partials,
+                       ctrl);
 }
 
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
                double* partials, const Ctrl* ctrl, hipStream_t s) {
-  const int R = g_cg1_rows, by = kNW * R;
+  if (g_cg1_auto) {  // 1024^3 sweep (profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay off on large planes
+    g_cg1_rows = 2;
+    g_cg1_waves = (g.ny >= 256 && g.pitch >= 256) ? 16 : 8;
+  }
+  const int R = g_cg1_rows, NW = g_cg1_waves, by = NW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
   const int max_blocks = kMaxPartials;  // five partial sums per block, partials holds 8 per block
@@ -1014,16 +1060,17 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
     nzc = (g.nzl + zchunk - 1) / zchunk;
   }
   const int blocks = (int)(cols * nzc);
-#define OI_CG1(RR)                                                                                              \
-  do {                                                                                                          \
-    if (p_f32) launch_cg1_r<RR, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k, \
-                                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                       \
-    else launch_cg1_r<RR, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,    \
-                                  zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                            \
+#define OI_CG1(RR, WW)                                                                                             \
+  do {                                                                                                             \
+    if (p_f32) launch_cg1_r<RR, WW, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, \
+                                           k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                   \
+    else launch_cg1_r<RR, WW, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,   \
+                                      zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                           \
   } while (0)
-  if (R == 4) OI_CG1(4);
-  else if (R == 2) OI_CG1(2);
-  else OI_CG1(1);
+  if (R == 4) OI_CG1(4, 8);
+  else if (R == 2 && NW == 16) OI_CG1(2, 16);
+  else if (R == 2) OI_CG1(2, 8);
+  else OI_CG1(1, 8);
 #undef OI_CG1
   return blocks;
 }

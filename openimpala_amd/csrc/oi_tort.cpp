@@ -89,6 +89,7 @@ struct oi_tort {
   // state
   bool fused = true;   // fused two-kernel iteration or single-kernel iteration (double-buffered p)
   bool cg1 = false;    // single-kernel iteration
+  int xskip = 0;       // cg1: x touched every second iteration (frozen at cg_begin)
   bool jacobi = false;
   bool percolates = false;
   bool vectors_ready = false;
@@ -456,6 +457,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * g.nvec, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
   int nb;
+  h->xskip = h->cg1 ? cg1_xskip() : 0;
   if (h->cg1) {
     // kernel 0 reads buffer 1: r_{-1} := r_0 with alpha_{-1} = 0, q_{-1} = p_{-1} = 0
     HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * g.nvec, s));
@@ -553,6 +555,12 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
   const int done = h->h_ctrl->done;
   // iterations whose x/r updates are in effect
   const int K = done ? done - 1 : (h->cg1 ? std::max(0, h->iters_issued - 1) : h->iters_issued);
+  if (h->cg1 && h->xskip && (K & 1) && h->iters_issued > 0) {
+    // pairwise x updates: an odd final state still lacks alpha_{K-1} p_{K-1}
+    PROF(K_AXPY);
+    launch_axpy_ptr(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->rec + (size_t)kRec1Stride * (K - 1) + kRec1Alpha,
+                    h->stream);
+  }
   if (h->fused && !h->cg1 && K > 0) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
     PROF(K_AXPY);
@@ -1041,4 +1049,7 @@ extern "C" void oi_tort_set_tuning(int fused_tile_rows, int fused_zchunk) {
   oi::set_fused_tuning(fused_tile_rows, fused_zchunk);
 }
 extern "C" void oi_tort_set_apply_tuning(int tile_rows) { oi::set_apply_tuning(tile_rows); }
-extern "C" void oi_tort_set_cg1_tuning(int tile_rows) { oi::set_cg1_tuning(tile_rows); }
+extern "C" void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second) {
+  oi::set_cg1_tuning(tile_rows);
+  oi::set_cg1_xskip(x_every_second);
+}

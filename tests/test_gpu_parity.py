@@ -149,6 +149,29 @@ def test_single_kernel_iteration(sample, goldens, rows, zchunk, jacobi, pf32):
         oia.set_tuning()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("m", [1, 2, 5, 6])
+def test_iterate_after_m_steps_matches_oracle(sample, variant, m):
+    """Stop after exactly m iterations (odd and even m: the deferred / pairwise x updates of the
+    fused variants must have been flushed): the iterate equals the oracle's x_m."""
+    sub = np.ascontiguousarray(sample[:40, :48, :56])
+    mask, _ = o.active_mask(sub, 1, 0)
+    code = o.codes(mask, 0)
+    want, _, it, rel = o.cg(code, o.initial_field(mask, 0, -1.0, 1.0), o.bnorm(mask, 0, -1.0, 1.0), eps=1e-30, maxiter=m)
+    assert it == m
+    for xs in ((0, 1) if variant == oia.KERNEL_FUSED1 else (1,)):
+        try:
+            oia.set_tuning(16, 0, 32, 0, xs)
+            t = oia.TortuosityMI355(sub, 1, 0, -1.0, 1.0, eps=1e-30, maxiter=m, kernel=variant)
+            assert math.isnan(t.value()) and t.status == oia.OI_NOT_CONVERGED
+            st = t.stats()
+            assert st.iterations == m and st.final_relres == pytest.approx(rel, rel=1e-9)
+            np.testing.assert_allclose(t.solution(), want, rtol=0, atol=1e-11)
+            t.destroy()
+        finally:
+            oia.set_tuning()
+
+
 @pytest.mark.parametrize("jacobi", [False, True])
 def test_fp32_stored_search_direction(sample, goldens, jacobi):
     """p kept in fp32 in HBM (x, r, q and all arithmetic fp64): same answer, same iteration
