@@ -83,7 +83,9 @@ Volume load_volume(const std::filesystem::path& path, double threshold, const oi
     if (it == types.end()) throw std::runtime_error("unknown raw.data_type: " + type);
     st = oi_read_raw(path.c_str(), v.nx, v.ny, v.nz, it->second, threshold, &data);
   } else if (ext == ".h5" || ext == ".hdf5") {
-    throw std::runtime_error("HDF5 input is not built into this front end yet (convert to TIFF or RAW): " + path.string());
+    std::string ds = "image";  // Diffusion.cpp:181,205
+    in.query("hdf5_dataset", ds);
+    st = oi_read_hdf5(path.c_str(), ds.c_str(), threshold, &data, &v.nx, &v.ny, &v.nz);
   } else {
     throw std::runtime_error("Unsupported file extension for full domain load: " + ext);  // Diffusion.cpp:298-300
   }

@@ -222,6 +222,10 @@ enum {
 };
 oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
                       uint8_t** phase);
+/* HDF5Reader::threshold (HDF5Reader.cpp:111-187,333-402): rank-3 dataset `dataset` (e.g. "image"),
+ * dims (Z,Y,X) in C order; classic-format files, contiguous/compact/chunked, deflate + shuffle */
+oi_status oi_read_hdf5(const char* path, const char* dataset, double threshold, uint8_t** phase, int* nx, int* ny,
+                       int* nz);
 /* DatReader::threshold (DatReader.cpp:74-160,204-241): 3 x int32 header + uint16 voxels */
 oi_status oi_read_dat(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz);
 void oi_free_host(void* p);

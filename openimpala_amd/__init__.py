@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_read_dat oi_free_host"
+    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_read_hdf5 oi_read_dat oi_free_host"
 ).split()
 
 
@@ -148,6 +148,7 @@ def lib():
     L.oi_device_count.restype = i
     L.oi_read_tiff.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_raw.argtypes = [C.c_char_p, i, i, i, i, d, pp]
+    L.oi_read_hdf5.argtypes = [C.c_char_p, C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_dat.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_free_host.argtypes = [vp]
     L.oi_free_host.restype = None
@@ -552,6 +553,25 @@ class DatReader:
         nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
         _check(lib().oi_read_dat(self.filename.encode(), raw_threshold, C.byref(p), C.byref(nx), C.byref(ny),
                                  C.byref(nz)))
+        try:
+            n = nx.value * ny.value * nz.value
+            out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+        finally:
+            lib().oi_free_host(p)
+        return out.reshape(nz.value, ny.value, nx.value)
+
+
+class HDF5Reader:
+    """OpenImpala::HDF5Reader (src/io/HDF5Reader.{H,cpp}): rank-3 dataset, dims (Z, Y, X)."""
+
+    def __init__(self, filename, hdf5dataset="image"):
+        self.filename, self.dataset = filename, hdf5dataset
+
+    def threshold(self, raw_threshold=0.5):
+        p = C.c_void_p()
+        nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().oi_read_hdf5(self.filename.encode(), self.dataset.encode(), raw_threshold, C.byref(p),
+                                  C.byref(nx), C.byref(ny), C.byref(nz)))
         try:
             n = nx.value * ny.value * nz.value
             out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()

@@ -84,3 +84,35 @@ def test_slab_ranges_cover_the_volume():
         assert spans[0][0] == 0 and spans[-1][1] == nz
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert all(z1 > z0 for z0, z1 in spans)
+
+
+def test_hdf5_reader_sample_and_layouts(tmp_path):
+    """HDF5Reader: the bundled sample (dims 100^3, values {0,1}: tHDF5Reader.cpp:88-119) and
+    hand-written files covering nested groups, chunked layout, shuffle + deflate, dtypes."""
+    from h5write import write_h5
+    sample = os.path.join(GOLDEN, "SampleData_2Phase_3d.hdf5")
+    ph = oia.HDF5Reader(sample, "image").threshold(0.5)
+    raw = np.frombuffer(open(sample, "rb").read()[2048:2048 + 10 ** 6], np.uint8).reshape(100, 100, 100)
+    assert ph.shape == (100, 100, 100) and set(np.unique(ph)) == {0, 1}
+    assert np.array_equal(ph, (raw > 0.5).astype(np.uint8))
+    with pytest.raises(oia.OpenImpalaError):
+        oia.HDF5Reader(sample, "nope").threshold(0.5)
+    rng = np.random.default_rng(3)
+    vals = rng.integers(0, 4000, size=(9, 14, 21))
+    cases = [("u1", None, False, False), ("<u2", (4, 5, 8), False, False), ("<u2", (4, 5, 8), True, True),
+             (">i4", (3, 14, 21), True, False), ("<f4", (9, 7, 4), True, True), ("<f8", None, False, False),
+             ("<i2", (2, 2, 2), False, True)]
+    for n, (dt, chunks, gz, sh) in enumerate(cases):
+        a = (vals % 200 if dt == "u1" else vals - (1000 if "i" in dt else 0)).astype(dt)
+        p = tmp_path / f"c{n}.h5"
+        names = ("image",) if n % 2 == 0 else ("vol", "scan", "image")
+        write_h5(str(p), a, names=names, chunks=chunks, gzip=gz, shuffle=sh)
+        got = oia.HDF5Reader(str(p), "/".join(names)).threshold(100.0)
+        assert got.shape == a.shape
+        assert np.array_equal(got, (a.astype(np.float64) > 100.0).astype(np.uint8)), (dt, chunks, gz, sh)
+    write_h5(str(tmp_path / "r2.h5"), vals.astype("u1"))
+    bad = bytearray(open(tmp_path / "r2.h5", "rb").read())
+    bad[8] = 2  # pretend "latest format" superblock
+    open(tmp_path / "v2.h5", "wb").write(bytes(bad))
+    with pytest.raises(oia.OpenImpalaError):
+        oia.HDF5Reader(str(tmp_path / "v2.h5")).threshold(1.0)

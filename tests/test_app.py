@@ -76,3 +76,28 @@ solver_type = FlexGMRES
     assert r.returncode == 0, r.stderr
     lines = open(tmp_path / "res" / "p0.txt").read().splitlines()
     assert lines[4] == "VolumeFraction: 0.601691000" and lines[5].startswith("Tortuosity_Z: 1.69305")
+
+
+@pytest.mark.gpu
+def test_diffusion_hdf5_input(app, tmp_path):
+    """.hdf5 input (Diffusion.cpp:286-296) against the oracle on the same voxels."""
+    import numpy as np
+    from oracle import oracle as o
+    raw = np.frombuffer(open(os.path.join(GOLDEN, "SampleData_2Phase_3d.hdf5"), "rb").read()[2048:2048 + 10 ** 6],
+                        np.uint8).reshape(100, 100, 100)
+    ref = o.tortuosity((raw > 0.5).astype(np.uint8), 1, 2, -1.0, 1.0, eps=1e-10)
+    text = f"""
+filename = SampleData_2Phase_3d.hdf5
+hdf5_dataset = image
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+calculation_method = flow_through
+direction = Z
+hypre.eps = 1e-10
+verbose = 0
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(tmp_path / "res" / "results.txt").read().splitlines()
+    assert float(lines[4].split(": ")[1]) == pytest.approx(raw.mean(), abs=1e-9)
+    assert float(lines[5].split(": ")[1]) == pytest.approx(ref["tau"], rel=1e-7)
