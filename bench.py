@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=384)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-apply-bench", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-stored-p variant")
     ap.add_argument("--force-dist", action="store_true",

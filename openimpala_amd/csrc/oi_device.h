@@ -84,7 +84,7 @@ void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
-               double* partials, const Ctrl* ctrl, hipStream_t s);
+               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, hipStream_t s);
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);

@@ -853,18 +853,22 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
                                                    const double* __restrict__ q_in, double* __restrict__ q_out,
                                                    const PT* __restrict__ p_in, PT* __restrict__ p_out,
                                                    const double* __restrict__ rec, int k, int xskip, int zchunk,
-                                                   int tiles_x, int tiles_y, int nzc, double* __restrict__ partials,
-                                                   const Ctrl* __restrict__ ctrl) {
+                                                   int tiles_x, int tiles_y, int nzc, int part, int partial_base,
+                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
   constexpr int BY = NW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
   __shared__ double red[NW];
 
-  const int ntiles = tiles_x * tiles_y * nzc;
+  // part 0: every z chunk; 1: only the first and last chunk of the slab (they produce the
+  // planes the neighbours wait for); 2: the interior chunks (run while the planes travel)
+  const int nsel = part == 0 ? nzc : (part == 1 ? min(2, nzc) : nzc - 2);
+  const int ntiles = tiles_x * tiles_y * nsel;
   int L = blockIdx.x;
   if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zsel = L / (tiles_x * tiles_y);
+  const int zc = part == 0 ? zsel : (part == 1 ? (zsel == 0 ? 0 : nzc - 1) : zsel + 1);
 
   double beta = 0.0, alpha_prev = 0.0, alpha_prev2 = 0.0;
   if (k > 0) {
@@ -1001,7 +1005,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   const double t3 = block_sum(s_zq, red);
   const double t4 = block_sum(s_qdq, red);
   if (threadIdx.x == 0) {
-    double* o = partials + 5 * (long long)blockIdx.x;
+    double* o = partials + 5 * ((long long)partial_base + blockIdx.x);
     o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
   }
 }
@@ -1025,21 +1029,25 @@ void set_cg1_tuning(int tile_rows) {
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                          const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
-                         const double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, double* partials,
-                         const Ctrl* ctrl, hipStream_t s) {
+                         const double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, int part,
+                         int partial_base, double* partials, const Ctrl* ctrl, hipStream_t s) {
   if (jacobi)
     hipLaunchKernelGGL((k_cg1<R, NW, PT, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
-                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, partials,
-                       ctrl);
+                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
+                       partial_base, partials, ctrl);
   else
     hipLaunchKernelGGL((k_cg1<R, NW, PT, false>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
-                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, partials,
-                       ctrl);
+                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
+                       partial_base, partials, ctrl);
 }
 
+// part: 0 = whole slab, 1 = boundary chunks, 2 = interior chunks (0 blocks when there are none).
+// `split` selects the chunking of a slab with neighbours: >= 4 chunks so that the interior
+// launch can hide the plane exchange.  Returns the number of blocks launched; they write
+// partials [partial_base, partial_base + blocks).
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
-               double* partials, const Ctrl* ctrl, hipStream_t s) {
+               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, hipStream_t s) {
   if (g_cg1_auto) {  // 1024^3 sweep (profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay off on large planes
     g_cg1_rows = 2;
     g_cg1_waves = (g.ny >= 256 && g.pitch >= 256) ? 16 : 8;
@@ -1048,10 +1056,19 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
   const int max_blocks = kMaxPartials;  // five partial sums per block, partials holds 8 per block
-  long long want = (4096 + cols - 1) / cols;
-  if (want < 1) want = 1;
-  int zchunk = g_fused_zchunk > 0 ? g_fused_zchunk : (int)((g.nzl + want - 1) / want);
-  if (g_fused_zchunk <= 0 && zchunk < 64) zchunk = 64;
+  int zchunk;
+  if (g_fused_zchunk > 0) {
+    zchunk = g_fused_zchunk;
+  } else if (split) {
+    zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
+    if (zchunk > 64) zchunk = 64;
+    if (zchunk < 16) zchunk = 16;
+  } else {
+    long long want = (4096 + cols - 1) / cols;
+    if (want < 1) want = 1;
+    zchunk = (int)((g.nzl + want - 1) / want);
+    if (zchunk < 64) zchunk = 64;
+  }
   if (zchunk > g.nzl) zchunk = g.nzl;
   int nzc = (g.nzl + zchunk - 1) / zchunk;
   if (cols * nzc > max_blocks) {
@@ -1059,13 +1076,16 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
     zchunk = (g.nzl + maxc - 1) / maxc;
     nzc = (g.nzl + zchunk - 1) / zchunk;
   }
-  const int blocks = (int)(cols * nzc);
+  const int nsel = part == 0 ? nzc : (part == 1 ? (nzc < 2 ? nzc : 2) : nzc - 2);
+  if (nsel <= 0) return 0;
+  const int blocks = (int)(cols * nsel);
 #define OI_CG1(RR, WW)                                                                                             \
   do {                                                                                                             \
     if (p_f32) launch_cg1_r<RR, WW, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, \
-                                           k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                   \
+                                           k, zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl,   \
+                                           s);                                                                     \
     else launch_cg1_r<RR, WW, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,   \
-                                      zchunk, tiles_x, tiles_y, nzc, partials, ctrl, s);                           \
+                                      zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl, s);      \
   } while (0)
   if (R == 4) OI_CG1(4, 8);
   else if (R == 2 && NW == 16) OI_CG1(2, 16);

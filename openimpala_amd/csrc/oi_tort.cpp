@@ -63,6 +63,8 @@ struct oi_tort {
   int phase_id = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t comm_stream = nullptr;         // ghost-plane exchange of the single-kernel variant
+  hipEvent_t ev_boundary = nullptr, ev_exchanged = nullptr;
 
   // device memory
   uint64_t *open = nullptr, *active = nullptr /* reach_lo, then the mask */, *rhi = nullptr;
@@ -195,6 +197,9 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   void* pin[] = {h->h_ctrl, h->h_counters, h->h_changed, h->h_scal};
   for (void* d : pin)
     if (d) (void)hipHostFree(d);
+  if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
+  if (h->ev_boundary) (void)hipEventDestroy(h->ev_boundary);
+  if (h->ev_exchanged) (void)hipEventDestroy(h->ev_exchanged);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -228,6 +233,11 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   const double t0 = now_s();
   HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   hipStream_t s = h->stream;
+  if (h->comm) {
+    HIPC(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&h->ev_boundary, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_exchanged, hipEventDisableTiming));
+  }
 
   OIC(dmalloc(h, &h->open, (size_t)g.nwords));
   OIC(dmalloc(h, &h->active, (size_t)g.nwords));
@@ -485,18 +495,42 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     const int in = (k + 1) & 1, out = k & 1;
     double* rb[2] = {h->r, h->r2};
     double* qb[2] = {h->q, h->q2};
-    {
-      PROF(K_CG1);
-      nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], h->p_f32 ? 1 : 0,
-                      h->jacobi ? 1 : 0, h->rec, k, h->partials, h->ctrl, s);
-    }
     double* rk = h->rec + (size_t)kRec1Stride * k;
-    const bool multi = h->comm != nullptr;
-    { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, multi ? 0 : 1, s); }
-    if (multi) {
+    const int pf = h->p_f32 ? 1 : 0, jac = h->jacobi ? 1 : 0;
+    if (!h->comm) {
+      {
+        PROF(K_CG1);
+        nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
+                        h->partials, h->ctrl, 0, 0, 0, s);
+      }
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 1, s); }
+    } else {
+      // slab with neighbours: the two boundary chunks first, their q planes travel on the comm
+      // stream (RCCL point-to-point over xGMI) while the interior chunks march on the solver stream
+      int nb_b, nb_i;
+      {
+        PROF(K_CG1);
+        nb_b = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
+                          h->partials, h->ctrl, 1, 1, 0, s);
+      }
+      HIPC(hipEventRecord(h->ev_boundary, s));
+      HIPC(hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
+      {
+        char* qbytes = (char*)qb[out];
+        const size_t pb = sizeof(double) * g.plane;
+        OIC(h->comm->exchange(qbytes + pb, qbytes, qbytes + pb * (size_t)g.nzl, qbytes + pb * (size_t)(g.nzl + 1), pb,
+                              h->comm_stream));  // the ONE plane exchange per iteration
+      }
+      HIPC(hipEventRecord(h->ev_exchanged, h->comm_stream));
+      {
+        PROF(K_CG1);
+        nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
+                          h->partials, h->ctrl, 1, 2, nb_b, s);
+      }
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s); }
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
       launch_scalars1(rk, h->ctrl, k, s);
-      OIC(exchange_planes(h, qb[out], sizeof(double) * g.plane));  // the ONE plane exchange per iteration
+      HIPC(hipStreamWaitEvent(s, h->ev_exchanged, 0));  // the next kernel reads the ghost planes of q
     }
   } else if (h->fused) {
     void* p_in = h->p[(k + 1) & 1];

@@ -116,3 +116,18 @@ def test_hdf5_reader_sample_and_layouts(tmp_path):
     open(tmp_path / "v2.h5", "wb").write(bytes(bad))
     with pytest.raises(oia.OpenImpalaError):
         oia.HDF5Reader(str(tmp_path / "v2.h5")).threshold(1.0)
+
+
+def test_tiff_reader_other_bundled_files():
+    """The reference's other TIFF fixtures: a 64^3 1-bit stack and a PHOTOMETRIC = 0 ("white is
+    zero") stack -- the reader works on raw bits and ignores PHOTOMETRIC like the reference
+    (TiffReader.cpp:419-426); voxel fractions from SURVEY.md section 8c."""
+    from oracle import oracle as o
+    sq = oia.TiffReader(os.path.join(GOLDEN, "SampleData_2Phase_squared.tif"))
+    ph = sq.threshold(0.5)
+    assert ph.shape == (64, 64, 64) and sq.bitsPerSample() == 1
+    assert ph.mean() == pytest.approx(0.399326, abs=5e-7)
+    assert np.array_equal(ph, o.read_tiff_phase(os.path.join(GOLDEN, "SampleData_2Phase_squared.tif")))
+    sp = oia.TiffReader(os.path.join(GOLDEN, "spheres.tif")).threshold(0.5)
+    assert sp.shape == (100, 100, 100) and sp.mean() == pytest.approx(0.888024, abs=5e-7)
+    assert np.array_equal(sp, o.read_tiff_phase(os.path.join(GOLDEN, "spheres.tif")))

@@ -271,3 +271,21 @@ def test_512_bernoulli_properties():
     assert t2.value() == pytest.approx(tau, rel=1e-6)
     assert t2.stats().flux_in == pytest.approx(8.0 * st.flux_in, rel=1e-6)
     t.destroy(); t2.destroy(); buf.free()
+
+
+@pytest.mark.parametrize("name,pid", [("SampleData_2Phase_squared.tif", 1), ("SampleData_2Phase_squared.tif", 0),
+                                      ("spheres.tif", 1), ("spheres.tif", 0)])
+def test_other_bundled_tiffs_match_oracle(name, pid):
+    """The reference's remaining TIFF fixtures, every direction, against the oracle (the minority
+    phase of spheres.tif does not percolate in every direction: NaN on both sides)."""
+    phase = oia.TiffReader(os.path.join(GOLDEN, name)).threshold(0.5)
+    for d in range(3):
+        ref = o.tortuosity(phase, pid, d, -1.0, 1.0, eps=1e-10)
+        t = oia.TortuosityMI355(phase, pid, d, -1.0, 1.0, eps=1e-10)
+        tau = t.value()
+        assert t.stats().n_active == ref["n_active"]
+        if ref["status"] == 0:
+            assert tau == pytest.approx(ref["tau"], rel=1e-7) and t.status == oia.OI_OK
+        else:
+            assert math.isnan(tau) and t.status == ref["status"]
+        t.destroy()

@@ -77,6 +77,23 @@ def test_slab_variants_on_sample(sample_phase, goldens, variant, jacobi, pf32):
     assert outs[0]["st"]["active_vf"] == pytest.approx(g["active_vf"], abs=5e-7)
 
 
+@pytest.mark.parametrize("xs", [0, 1])
+def test_slabs_split_launch_overlap_path(xs):
+    """Short z-chunks force boundary + interior launches on every slab (the interior launch
+    runs while the q planes travel on the comm stream)."""
+    phase = o.gen_spheres((40, 36, 44), 8, 5, 0.5)
+    ref = o.tortuosity(phase, 1, 2, -1.0, 1.0, eps=1e-11)
+    assert ref["status"] == 0
+    try:
+        oia.set_tuning(16, 3, 32, 8, xs)  # 3-plane chunks: 4-5 chunks per slab
+        outs = run_slabs(phase, 1, 2, 3, -1.0, 1.0, eps=1e-11)
+    finally:
+        oia.set_tuning()
+    assert outs[0]["tau"] == pytest.approx(ref["tau"], rel=1e-8)
+    x = np.concatenate([r["x"] for r in outs])
+    np.testing.assert_allclose(x, ref["x"], rtol=0, atol=1e-8)
+
+
 def test_slabs_thin_and_uneven():
     """nz not divisible by the rank count, slabs of one or two planes, flow along z."""
     phase = o.gen_bernoulli((7, 24, 30), 4, 0.7)
