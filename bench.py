@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024, help="voxels per edge")
-    ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli"])
+    ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli", "blobs"])
     ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused"])
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
@@ -52,6 +52,10 @@ def parse():
 def make_structure(oia, args, shape, z0, nzl):
     if args.structure == "bernoulli":
         return oia.gen_bernoulli_device(shape, 20251031, 0.5, z0, nzl), "Bernoulli(0.5), seed 20251031"
+    if args.structure == "blobs":  # config 5 geometry: correlated, porosity 0.2
+        spacing = 24 if shape[2] >= 512 else max(6, shape[2] // 20)
+        return (oia.gen_blobs_device(shape, 20251031, spacing, 0.2, z0, nzl),
+                f"interpolated lattice-noise blobs, spacing {spacing}, target porosity 0.2, seed 20251031")
     radius = 24 if shape[2] >= 512 else max(4, shape[2] // 24)
     return (oia.gen_spheres_device(shape, 20251031, radius, 0.4, z0, nzl),
             f"overlapping spheres r={radius}, target porosity 0.4, seed 20251031")

@@ -198,6 +198,13 @@ oi_status oi_gen_bernoulli_device(uint8_t* phase_dev, int nx, int ny, int nz_glo
 oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
                                 int nz_local, uint64_t seed, int nspheres, int radius_half_voxels);
 
+/* correlated low-porosity "blob" structure (config 5): integer trilinear interpolation of
+ * lattice noise with `spacing` voxels between lattice points; pore (1) where the value is
+ * below `level`.  oi_blobs_level returns the level that gives the wanted porosity. */
+oi_status oi_gen_blobs_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0, int nz_local,
+                              uint64_t seed, int spacing, uint64_t level);
+uint64_t oi_blobs_level(uint64_t seed, int spacing, double porosity);
+
 /* ---- device memory helpers for hosts without a GPU array library ---- */
 oi_status oi_dev_malloc(void** ptr, size_t bytes);
 oi_status oi_dev_free(void* ptr);

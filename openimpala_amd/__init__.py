@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
-    "oi_gen_spheres_device oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
+    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_read_hdf5 oi_read_dat oi_free_host"
 ).split()
 
@@ -141,6 +141,9 @@ def lib():
     L.oi_comm_size.argtypes = [vp]
     L.oi_gen_bernoulli_device.argtypes = [vp, i, i, i, i, i, u64, u64]
     L.oi_gen_spheres_device.argtypes = [vp, i, i, i, i, i, u64, i, i]
+    L.oi_gen_blobs_device.argtypes = [vp, i, i, i, i, i, u64, i, u64]
+    L.oi_blobs_level.argtypes = [u64, i, d]
+    L.oi_blobs_level.restype = u64
     L.oi_dev_malloc.argtypes = [pp, C.c_size_t]
     L.oi_dev_free.argtypes = [vp]
     L.oi_dev_upload.argtypes = [vp, vp, C.c_size_t]
@@ -245,6 +248,20 @@ def gen_spheres_device(shape, seed, radius, porosity, z0=0, nz_local=None):
     buf = DeviceBuffer(nx * ny * nzl)
     _check(lib().oi_gen_spheres_device(buf.ptr, nx, ny, nz, z0, nzl, seed, spheres_count(shape, radius, porosity),
                                        int(2 * radius)))
+    return buf
+
+
+def blobs_level(seed, spacing, porosity):
+    """Threshold level (0..65535) of the blob generator for a target porosity (host arithmetic)."""
+    return int(lib().oi_blobs_level(seed, spacing, porosity))
+
+
+def gen_blobs_device(shape, seed, spacing, porosity, z0=0, nz_local=None):
+    """Correlated low-porosity structure (BASELINE.json config 5) generated in HBM; pore = 1."""
+    nz, ny, nx = shape
+    nzl = nz if nz_local is None else nz_local
+    buf = DeviceBuffer(nx * ny * nzl)
+    _check(lib().oi_gen_blobs_device(buf.ptr, nx, ny, nz, z0, nzl, seed, spacing, blobs_level(seed, spacing, porosity)))
     return buf
 
 

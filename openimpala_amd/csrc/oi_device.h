@@ -112,6 +112,9 @@ void launch_gen_bernoulli(uint8_t* phase, int nx, int ny, int nz, int z0, int nz
                           uint64_t thr53, hipStream_t s);
 void launch_gen_spheres(uint8_t* phase, int nx, int ny, int nz, int z0, int nzl, const int* centres_dev,
                         const int* cell_start_dev, int ncx, int ncy, int ncz, int cell, int r2h, hipStream_t s);
+void launch_gen_blobs(uint8_t* phase, int nx, int ny, int z0, int nzl, uint64_t seed, int S, uint64_t level,
+                      hipStream_t s);
+uint64_t blob_value_host(uint64_t seed, int S, int i, int j, int k);
 void launch_sum_scalars(double* dst, const double* const* srcs, int nsrc, int n, hipStream_t s);
 // dense host-order (nx per row, nzl planes) <-> pitched/ghosted device vector
 void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipStream_t s);

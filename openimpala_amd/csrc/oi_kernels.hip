@@ -1246,6 +1246,48 @@ void launch_gen_bernoulli(uint8_t* phase, int nx, int ny, int nz, int z0, int nz
   hipLaunchKernelGGL(k_gen_bernoulli, dim3(blocks), dim3(256), 0, s, phase, nx, ny, z0, nzl, seed, thr53);
 }
 
+// Correlated "blob" structure (BASELINE.json config 5): integer trilinear interpolation of
+// 16-bit lattice noise with spacing S; pore where the value is below `level`.
+__host__ __device__ inline uint64_t blob_value(uint64_t seed, int S, int i, int j, int k) {
+  const int a = i / S, b = j / S, c = k / S;
+  const uint64_t w1[3] = {(uint64_t)(2 * (i % S) + 1), (uint64_t)(2 * (j % S) + 1), (uint64_t)(2 * (k % S) + 1)};
+  uint64_t num = 0;
+  for (int dc = 0; dc < 2; ++dc)
+    for (int db = 0; db < 2; ++db)
+      for (int da = 0; da < 2; ++da) {
+        const uint64_t key = ((uint64_t)(uint32_t)(a + da)) | ((uint64_t)(uint32_t)(b + db) << 21) |
+                             ((uint64_t)(uint32_t)(c + dc) << 42);
+        uint64_t z = seed * 0xD1342543DE82EF95ULL + key;
+        z += 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        const uint64_t v = (z ^ (z >> 31)) >> 48;
+        const uint64_t wx = da ? w1[0] : 2 * S - w1[0], wy = db ? w1[1] : 2 * S - w1[1],
+                       wz = dc ? w1[2] : 2 * S - w1[2];
+        num += wx * wy * wz * v;
+      }
+  return num;  // = value * (2S)^3
+}
+
+uint64_t blob_value_host(uint64_t seed, int S, int i, int j, int k) { return blob_value(seed, S, i, j, k); }
+
+__global__ void __launch_bounds__(256) k_gen_blobs(uint8_t* __restrict__ phase, int nx, int ny, int z0, int nzl,
+                                                    uint64_t seed, int S, uint64_t thr) {
+  const long long n = (long long)nx * ny * nzl;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n;
+       v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % nx), j = (int)((v / nx) % ny), kz = z0 + (int)(v / ((long long)nx * ny));
+    phase[v] = blob_value(seed, S, i, j, kz) < thr ? 1 : 0;
+  }
+}
+
+void launch_gen_blobs(uint8_t* phase, int nx, int ny, int z0, int nzl, uint64_t seed, int S, uint64_t level,
+                      hipStream_t s) {
+  const uint64_t thr = level * (uint64_t)(2 * S) * (2 * S) * (2 * S);
+  const int blocks = cap_blocks((long long)nx * ny * nzl, 256, 8192);
+  hipLaunchKernelGGL(k_gen_blobs, dim3(blocks), dim3(256), 0, s, phase, nx, ny, z0, nzl, seed, S, thr);
+}
+
 // spheres binned on the host into cells of edge `cell` half-voxels (>= radius); a voxel
 // tests the 27 cells around its own.
 __global__ void __launch_bounds__(256) k_gen_spheres(uint8_t* __restrict__ phase, int nx, int ny, int z0, int nzl,

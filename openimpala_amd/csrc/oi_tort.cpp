@@ -1042,6 +1042,33 @@ extern "C" oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, i
   return OI_OK;
 }
 
+extern "C" oi_status oi_gen_blobs_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0, int nz_local,
+                                         uint64_t seed, int spacing, uint64_t level) {
+  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1 || spacing < 2 || spacing > 512 || level > 65535) return OI_BAD_ARG;
+  (void)nz_global;
+  launch_gen_blobs(phase_dev, nx, ny, z0, nz_local, seed, spacing, level, nullptr);
+  HIPC(hipGetLastError());
+  HIPC(hipDeviceSynchronize());
+  return OI_OK;
+}
+
+// level (0..65535) whose blob structure has the wanted porosity: the quantile of the
+// interpolated noise over a fixed sample of voxels (host arithmetic, no device needed)
+extern "C" uint64_t oi_blobs_level(uint64_t seed, int spacing, double porosity) {
+  if (spacing < 2 || !(porosity > 0.0) || !(porosity < 1.0)) return 0;
+  const int n = 96;  // 96^3 sample stepping through several lattice cells
+  const int step = std::max(1, (8 * spacing) / n + 1);
+  std::vector<uint64_t> vals;
+  vals.reserve((size_t)n * n * n);
+  for (int k = 0; k < n; ++k)
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) vals.push_back(blob_value_host(seed, spacing, i * step, j * step + 1, k * step + 2));
+  const size_t q = (size_t)(porosity * vals.size());
+  std::nth_element(vals.begin(), vals.begin() + q, vals.end());
+  const uint64_t scale = (uint64_t)(2 * spacing) * (2 * spacing) * (2 * spacing);
+  return std::min<uint64_t>(65535, vals[q] / scale + 1);
+}
+
 extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
   if (!ptr) return OI_BAD_ARG;
   int device = 0;

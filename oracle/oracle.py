@@ -66,6 +66,7 @@ def lib():
         L.oi_oracle_set_threads.argtypes = [i]
         L.oi_oracle_gen_bernoulli.argtypes = [_u8p, i, i, i, u64, u64]
         L.oi_oracle_gen_spheres.argtypes = [_u8p, i, i, i, u64, i, i]
+        L.oi_oracle_gen_blobs.argtypes = [_u8p, i, i, i, u64, i, u64]
         L.oi_oracle_volume_fraction.argtypes = [_u8p, ll, i, C.POINTER(ll), C.POINTER(ll)]
         L.oi_oracle_remspot.argtypes = [_u8p, i, i, i]
         L.oi_oracle_active_mask.argtypes = [_u8p, i, i, i, i, i, _u8p]
@@ -122,6 +123,13 @@ def gen_spheres(shape, seed, radius, porosity):
     nx, ny, nz = _dims(out)
     lib().oi_oracle_gen_spheres(out, nx, ny, nz, seed, spheres_count(shape, radius, porosity),
                                 int(2 * radius))
+    return out
+
+
+def gen_blobs(shape, seed, spacing, level):
+    out = np.empty(shape, np.uint8)
+    nx, ny, nz = _dims(out)
+    lib().oi_oracle_gen_blobs(out, nx, ny, nz, seed, spacing, level)
     return out
 
 

@@ -243,6 +243,26 @@ def test_device_generators_match_oracle():
     assert np.array_equal(part.download(np.uint8, (9, 44, 48)), o.gen_spheres((40, 44, 48), 9, 6, 0.4)[13:22])
 
 
+def test_low_porosity_blobs_jacobi_pcg():
+    """BASELINE.json config 5 in miniature: a correlated structure at porosity 0.2 (iid noise
+    would not percolate), Jacobi-preconditioned CG, every kernel variant, against the oracle."""
+    shape = (96, 80, 112)
+    level = oia.blobs_level(11, 10, 0.2)
+    buf = oia.gen_blobs_device(shape, 11, 10, 0.2)
+    phase = buf.download(np.uint8, shape)
+    assert np.array_equal(phase, o.gen_blobs(shape, 11, 10, level))
+    part = oia.gen_blobs_device(shape, 11, 10, 0.2, z0=40, nz_local=7)
+    assert np.array_equal(part.download(np.uint8, (7, 80, 112)), phase[40:47])
+    assert 0.15 < phase.mean() < 0.25
+    ref = o.tortuosity(phase, 1, 0, eps=1e-10, jacobi=True)
+    assert ref["status"] == 0 and ref["tau"] > 2.0
+    for variant in VARIANTS:
+        t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-10, precond=oia.PRECOND_JACOBI, kernel=variant)
+        assert t.value() == pytest.approx(ref["tau"], rel=1e-8)
+        assert abs(t.getSolverIterations() - ref["iterations"]) <= 3
+        t.destroy()
+
+
 def test_512_bernoulli_properties():
     """BASELINE.json config 2 at full size: properties that do not need the oracle."""
     shape = (512, 512, 512)

@@ -190,6 +190,9 @@ def test_generators_are_deterministic_and_percolate():
     b = o.gen_bernoulli((24, 20, 28), 20251031, 0.5)
     assert np.array_equal(a, b) and 0.45 < a.mean() < 0.55
     assert not np.array_equal(a, o.gen_bernoulli((24, 20, 28), 7, 0.5))
+    bl = o.gen_blobs((40, 44, 48), 5, 8, 24000)
+    assert np.array_equal(bl, o.gen_blobs((40, 44, 48), 5, 8, 24000)) and 0.1 < bl.mean() < 0.35
+    assert np.all(o.gen_blobs((8, 8, 8), 5, 8, 65535) == 1) and np.all(o.gen_blobs((8, 8, 8), 5, 8, 0) == 0)
     s = o.gen_spheres((48, 48, 48), 3, 6, 0.4)
     assert 0.25 < s.mean() < 0.55
     r = o.tortuosity(s, 1, 0, eps=1e-10)
