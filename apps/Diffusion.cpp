@@ -167,11 +167,13 @@ int main(int argc, char* argv[]) {
     int tverbose = verbose;
     in.query("tortuosity.verbose", tverbose);
     in.query("tortuosity.remspot_passes", opts.remspot_passes);
-    std::string precond = "none", kernel = "auto";
+    std::string precond = "jacobi", kernel = "auto";  // Jacobi costs no extra traffic in the default kernel
     in.query("gpu.precond", precond);
     in.query("gpu.kernel", kernel);
     opts.precond = lower(precond) == "jacobi" ? OI_PRECOND_JACOBI : OI_PRECOND_NONE;
-    opts.kernel = lower(kernel) == "unfused" ? OI_KERNEL_UNFUSED : (lower(kernel) == "fused" ? OI_KERNEL_FUSED : OI_KERNEL_AUTO);
+    const std::string kl = lower(kernel);
+    opts.kernel = kl == "unfused" ? OI_KERNEL_UNFUSED
+                  : (kl == "fused" ? OI_KERNEL_FUSED : (kl == "fused1" ? OI_KERNEL_FUSED1 : OI_KERNEL_AUTO));
     in.query("gpu.device", opts.device);
 
     if (verbose > 0) std::cout << "Calculating Volume Fraction for Phase ID: " << phase_id << "\n";

@@ -1048,11 +1048,11 @@ static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double*
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
                double* partials, const Ctrl* ctrl, int split, int part, int partial_base, hipStream_t s) {
-  if (g_cg1_auto) {  // 1024^3 sweep (profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay off on large planes
-    g_cg1_rows = 2;
-    g_cg1_waves = (g.ny >= 256 && g.pitch >= 256) ? 16 : 8;
-  }
-  const int R = g_cg1_rows, NW = g_cg1_waves, by = NW * R;
+  // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
+  // off on large planes; locals only, handles may be driven from several host threads
+  const int R = g_cg1_auto ? 2 : g_cg1_rows;
+  const int NW = g_cg1_auto ? ((g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g_cg1_waves;
+  const int by = NW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
   const int max_blocks = kMaxPartials;  // five partial sums per block, partials holds 8 per block
@@ -1106,16 +1106,17 @@ __device__ __forceinline__ void cg1_scalars(double* rk, Ctrl* ctrl, int k) {
   rk[R1_BETA] = safe_div(rz_next, rk[R1_RZ]);
 }
 
-__global__ void __launch_bounds__(256) k_finalize1(const double* __restrict__ partials, int nblocks, double* rk,
+// one wave per component: lane l adds partials l, l+64, ... in order, then a shuffle tree --
+// a fixed summation order, no block barriers until the five sums are in place
+__global__ void __launch_bounds__(320) k_finalize1(const double* __restrict__ partials, int nblocks, double* rk,
                                                     Ctrl* ctrl, int k, int with_scalars) {
   if (ctrl->done) return;
-  __shared__ double red[4];
-  for (int c = 0; c < 5; ++c) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += partials[(long long)b * 5 + c];
-    const double t = block_sum(v, red);
-    if (threadIdx.x == 0) rk[c] = t;
-  }
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double v = 0.0;
+  for (int b = lane; b < nblocks; b += 64) v += partials[(long long)b * 5 + c];
+  v = wave_sum(v);
+  if (lane == 0) rk[c] = v;
+  __syncthreads();
   if (threadIdx.x == 0 && with_scalars) cg1_scalars(rk, ctrl, k);
 }
 
@@ -1125,7 +1126,7 @@ __global__ void k_scalars1(double* rk, Ctrl* ctrl, int k) {
 
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(256), 0, s, partials, nblocks, rec_k, ctrl, k, with_scalars);
+  hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(320), 0, s, partials, nblocks, rec_k, ctrl, k, with_scalars);
 }
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s) {
   hipLaunchKernelGGL(k_scalars1, dim3(1), dim3(1), 0, s, rec_k, ctrl, k);
