@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024, help="voxels per edge")
     ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli", "blobs"])
+    ap.add_argument("--direction", default="X", choices=["X", "Y", "Z"], help="flow axis (headline: X)")
     ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused"])
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
@@ -141,16 +142,17 @@ def main():
     t_gen = time.time()
     buf, desc = make_structure(oia, args, shape, z0, nzl)
     t_gen = time.time() - t_gen
+    direction = {"X": oia.Direction.X, "Y": oia.Direction.Y, "Z": oia.Direction.Z}[args.direction]
     kernel = {"fused1": oia.KERNEL_FUSED1, "fused": oia.KERNEL_FUSED, "unfused": oia.KERNEL_UNFUSED}[args.kernel]
     precond = oia.PRECOND_JACOBI if args.precond == "jacobi" else oia.PRECOND_NONE
     t_create = time.time()
     # eps = 1e-300 during the timed region: every one of the K steps does full work
     kw = dict(eps=1e-300, kernel=kernel, precond=precond, profile=1, maxiter=200000, device=local_rank)
     if comm is not None:
-        t = oia.TortuosityMI355(buf, 1, oia.Direction.X, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=n,
+        t = oia.TortuosityMI355(buf, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=n,
                                 **kw)
     else:
-        t = oia.TortuosityMI355(buf, 1, oia.Direction.X, 0.0, 1.0, shape=shape, **kw)
+        t = oia.TortuosityMI355(buf, 1, direction, 0.0, 1.0, shape=shape, **kw)
     t_create = time.time() - t_create
     buf.free()
     st = t.stats()
@@ -242,10 +244,10 @@ def main():
         buf2, _ = make_structure(oia, args, shape, z0, nzl)
         kw2 = dict(kw, p_storage=oia.STORE_F32)
         if comm is not None:
-            t = oia.TortuosityMI355(buf2, 1, oia.Direction.X, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0,
+            t = oia.TortuosityMI355(buf2, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0,
                                     nz_global=n, **kw2)
         else:
-            t = oia.TortuosityMI355(buf2, 1, oia.Direction.X, 0.0, 1.0, shape=shape, **kw2)
+            t = oia.TortuosityMI355(buf2, 1, direction, 0.0, 1.0, shape=shape, **kw2)
         buf2.free()
         t.cg_begin()
         t.cg_iterate(args.warmup)
@@ -280,7 +282,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{n}^3 two-phase {desc}; phase 1, X direction; matrix-free CG "
+            "config": {"workload": f"{n}^3 two-phase {desc}; phase 1, {args.direction} direction; matrix-free CG "
                                    f"({args.kernel}, precond {args.precond}); z-slabs over {world} GPU(s)",
                        "voxels": n ** 3, "active_vf": st.active_vf, "volume_fraction": st.vf,
                        "unknowns": st.n_free, "parallelism": f"z-slab x{world}"},
