@@ -7,8 +7,9 @@
 // results file (:718-728).  The solve behind it is the HIP library (C ABI), reached
 // through the TortuosityMI355 mirror of OpenImpala::TortuosityHypre.
 //
-// Scope: calculation_method = flow_through.  The homogenization / REV branches of the
-// reference are a different PDE (periodic cell problem) and are not part of this path.
+// Scope: calculation_method = flow_through (the hot path) and homogenization (first cut of
+// the "next" row: three periodic cell problems + D_eff tensor, single GPU).  The REV
+// sampling study (rev.do_study) is not implemented.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -142,9 +143,64 @@ int main(int argc, char* argv[]) {
       return 1;
     }
 
-    if (method != "flow_through") {
-      std::cerr << "calculation_method = " << method << ": only 'flow_through' (the TortuosityHypre path) is "
-                << "implemented by this build; the homogenization / REV study path is out of scope.\n";
+    bool rev_study = false;
+    in.query("rev.do_study", rev_study);
+    if (rev_study) std::cerr << "Warning: rev.do_study is not implemented by this build (REV sampling); ignored.\n";
+
+    if (method == "homogenization") {
+      // ---- Diffusion.cpp:509-589: three periodic cell problems chi_k, then the D_eff tensor ----
+      if (verbose >= 1) {
+        std::cout << "\n--- Full Domain Calculation (" << method << ") using phase " << phase_id << " ---\n";
+        std::cout << "\n--- Effective Diffusivity via Homogenization (Full Domain) ---\n";
+      }
+      (void)solver_from_string(solver_str);  // invalid names abort in the reference (:45-58)
+      oi_tort_opts hopts;
+      oi_tort_default_opts(&hopts);
+      if (!in.query("hypre.eps", hopts.eps)) in.query("hypre_eps", hopts.eps);
+      in.query("gpu.maxiter", hopts.maxiter);
+      in.query("gpu.device", hopts.device);
+      hopts.verbose = verbose;
+      oi_effdiff* eh = nullptr;
+      oi_status est = oi_effdiff_create(&eh, vol.phase.data(), vol.nx, vol.ny, vol.nz, phase_id, &hopts);
+      if (est != OI_OK) throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error());
+      bool all_converged = true;
+      const char* names[3] = {"X", "Y", "Z"};
+      for (int k = 0; k < 3 && all_converged; ++k) {
+        if (verbose >= 1) std::cout << "\n--- Solving for Full Domain chi_" << names[k] << " ---\n";
+        int conv = 0, iters = 0;
+        double rel = 0.0;
+        est = oi_effdiff_solve(eh, k, &conv, &iters, &rel);
+        if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
+        if (verbose >= 1)
+          std::cout << "  Solver iterations: " << iters << "\n  Final Relative Residual Norm: " << std::scientific << rel
+                    << std::defaultfloat << "\n  Solver Converged Status: " << (conv ? "Yes" : "No") << "\n";
+        if (!conv) all_converged = false;  // :545-548
+      }
+      if (all_converged) {
+        double D[9];
+        est = oi_effdiff_tensor(eh, D);
+        if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
+        std::cout << "Full Domain Effective Diffusivity Tensor D_eff / D_material:\n";  // :573-582
+        for (int r = 0; r < 3; ++r) {
+          std::cout << "  [";
+          for (int c = 0; c < 3; ++c) std::cout << std::scientific << std::setprecision(8) << D[3 * r + c] << (c == 2 ? "" : ", ");
+          std::cout << "]\n";
+        }
+        // the reference only prints the tensor; this build also leaves it in the results directory
+        std::ofstream tf(results_dir / "Deff_tensor.txt");
+        tf << "# D_eff / D_material (homogenization), phase " << phase_id << ", input " << filename << "\n";
+        for (int r = 0; r < 3; ++r)
+          tf << std::scientific << std::setprecision(9) << D[3 * r] << " " << D[3 * r + 1] << " " << D[3 * r + 2] << "\n";
+      } else {
+        std::cout << "Full domain D_eff calculation skipped due to chi_k non-convergence.\n";  // :587-589
+      }
+      oi_effdiff_destroy(eh);
+      const double secs_h = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+      std::cout << std::endl << "Total run time (seconds) = " << std::defaultfloat << secs_h << std::endl;
+      return 0;
+    }
+    if (method != "flow_through") {  // any other string falls through every branch of the reference
+      std::cerr << "calculation_method = " << method << ": expected 'homogenization' or 'flow_through'.\n";
       return 2;
     }
 

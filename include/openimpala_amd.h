@@ -146,6 +146,23 @@ oi_status oi_remspot(uint8_t* phase, int nx, int ny, int nz, int passes);
 /* change hypre.eps of an existing handle (takes effect at the next solve / cg_begin) */
 oi_status oi_tort_set_eps(oi_tort* h, double eps);
 
+/* ---- homogenization path (the reference's default calculation_method) ----
+ * One object serves the three cell problems chi_x, chi_y, chi_z of a periodic volume and the
+ * D_eff tensor built from them.  Replaces OpenImpala::EffectiveDiffusivityHypre
+ * (EffectiveDiffusivityHypre.cpp: ctor + generateActiveMask :213-323, solve :543-687,
+ * getChiSolution :689-; assembly EffDiffFillMtx.F90:42-264) and
+ * calculate_Deff_tensor_homogenization (Diffusion.cpp:60-167).  Single GPU in this version.
+ * opts: eps / maxiter = hypre.eps / hypre.maxiter (defaults 1e-9 / 1000, :120,152-154). */
+typedef struct oi_effdiff oi_effdiff;
+oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
+                            const oi_tort_opts* opts);
+/* solve(): *converged = 0 leaves chi_k = 0 exactly as the reference does (:641-645) */
+oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, int* iterations, double* relres);
+oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi);
+oi_status oi_effdiff_tensor(oi_effdiff* h, double* deff9 /* row-major 3x3, D_eff / D_material */);
+oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int* iterations3, double* relres3);
+void oi_effdiff_destroy(oi_effdiff* h);
+
 /* ---- stepping interface (bench / tests): the pieces of solve() individually ---- */
 oi_status oi_tort_cg_begin(oi_tort* h);              /* x0 = ramp, r0, p0; resets the iteration count */
 oi_status oi_tort_cg_iterate(oi_tort* h, int n);     /* enqueue n CG iterations (asynchronous) */

@@ -39,7 +39,8 @@ COMM_ID_BYTES = 128
 ABI_SYMBOLS = (
     "oi_tort_default_opts oi_tort_create oi_tort_create_device oi_tort_create_slab oi_tort_destroy "
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
-    "oi_volume_fraction oi_remspot oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
+    "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
+    "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
@@ -113,6 +114,13 @@ def lib():
     L.oi_tort_get_mask.argtypes = [vp, vp]
     L.oi_volume_fraction.argtypes = [vp, C.c_size_t, i, i64p, i64p]
     L.oi_remspot.argtypes = [vp, i, i, i, i]
+    L.oi_effdiff_create.argtypes = [pp, vp, i, i, i, i, C.POINTER(Opts)]
+    L.oi_effdiff_solve.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(d)]
+    L.oi_effdiff_get_chi.argtypes = [vp, i, vp]
+    L.oi_effdiff_tensor.argtypes = [vp, C.POINTER(d)]
+    L.oi_effdiff_info.argtypes = [vp, i64p, C.POINTER(i), C.POINTER(d)]
+    L.oi_effdiff_destroy.argtypes = [vp]
+    L.oi_effdiff_destroy.restype = None
     L.oi_tort_set_eps.argtypes = [vp, d]
     L.oi_tort_cg_begin.argtypes = [vp]
     L.oi_tort_cg_iterate.argtypes = [vp, i]
@@ -486,6 +494,48 @@ class TortuosityMI355:
     def destroy(self):
         if self._h:
             lib().oi_tort_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class EffectiveDiffusivityMI355:
+    """Mirror of OpenImpala::EffectiveDiffusivityHypre (src/props/EffectiveDiffusivityHypre.{H,cpp})
+    plus the tensor integrator of Diffusion.cpp:60-167.  One object serves all three directions."""
+
+    def __init__(self, phase, phase_id, verbose=0, **opts):
+        self._host = np.ascontiguousarray(phase, np.uint8)
+        nz, ny, nx = self._host.shape
+        self.shape = (nz, ny, nx)
+        self._h = C.c_void_p()
+        o = default_opts(verbose=verbose, **opts)
+        _check(lib().oi_effdiff_create(C.byref(self._h), self._host.ctypes.data_as(C.c_void_p), nx, ny, nz, phase_id,
+                                       C.byref(o)))
+
+    def solve(self, direction):
+        """EffectiveDiffusivityHypre::solve for chi_k -> (converged, iterations, relres)."""
+        conv, it, rel = C.c_int(), C.c_int(), C.c_double()
+        _check(lib().oi_effdiff_solve(self._h, int(direction), C.byref(conv), C.byref(it), C.byref(rel)))
+        return bool(conv.value), it.value, rel.value
+
+    def getChiSolution(self, direction):
+        out = np.empty(self.shape, np.float64)
+        _check(lib().oi_effdiff_get_chi(self._h, int(direction), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def tensor(self):
+        """D_eff / D_material, 3x3 (rows: derivative axis, columns: chi direction)."""
+        D = (C.c_double * 9)()
+        _check(lib().oi_effdiff_tensor(self._h, D))
+        return np.array(D[:]).reshape(3, 3)
+
+    def destroy(self):
+        if self._h:
+            lib().oi_effdiff_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

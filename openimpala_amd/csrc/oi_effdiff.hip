@@ -1,0 +1,392 @@
+// oi_effdiff.hip -- homogenization path (the reference's default calculation_method):
+// periodic cell problems chi_k and the D_eff tensor, on the same HBM layout and CG
+// building blocks as the tortuosity path.  First cut of SURVEY 8f-3: single GPU,
+// unfused iteration (periodic apply + the flat vector kernels of oi_kernels.hip).
+//
+// Replaces OpenImpala::EffectiveDiffusivityHypre (src/props/EffectiveDiffusivityHypre.cpp:
+// ctor/generateActiveMask :213-323, solve :543-687, getChiSolution :689-) with its Fortran
+// assembly kernel effdiff_fillmtx (src/props/EffDiffFillMtx.F90:42-264) and the tensor
+// integrator calculate_Deff_tensor_homogenization (src/props/Diffusion.cpp:60-167).
+//
+// System restated from EffDiffFillMtx.F90 (dx = 1, fully periodic): active = phase == id;
+// row of an active cell: -1 towards every active neighbour, diagonal 6 regardless of the
+// neighbours (both branches of F90:126-205 add 1/dx^2), rhs_k = (D(+k) - D(-k)) / 2;
+// inactive cells: identity, rhs 0.  With vectors that vanish on inactive cells,
+// (A v)[m] = 6 v[m] - (sum of the six periodic neighbours): the tortuosity kernel form with
+// code = 6.  SPD (strictly diagonally dominant at every interface), so plain CG applies.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "oi_comm.h"
+#include "oi_device.h"
+
+using namespace oi;
+
+#define HIPC(call)                                                                       \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return OI_HIP_ERROR;                                                               \
+    }                                                                                    \
+  } while (0)
+#define OIC(call)                \
+  do {                           \
+    oi_status s_ = (call);       \
+    if (s_ != OI_OK) return s_;  \
+  } while (0)
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w) t += lds[w];
+  return t;
+}
+
+// element index of (plane g incl. ghosts, row j, column i) with periodic wrap in x and y
+__device__ __forceinline__ long long eidx(const Geom& g, int gz, int j, int i) {
+  i = i < 0 ? i + g.nx : (i >= g.nx ? i - g.nx : i);
+  j = j < 0 ? j + g.ny : (j >= g.ny ? j - g.ny : j);
+  return (long long)gz * g.plane + (long long)j * g.pitch + i;
+}
+
+// phase bytes -> code 6 (active) / 0 on the owned planes; count of active cells
+__global__ void __launch_bounds__(256) k_ed_codes(Geom g, const uint8_t* __restrict__ phase, int phase_id,
+                                                   uint8_t* __restrict__ code, unsigned long long* n_active) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  unsigned long long cnt = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
+    const bool act = phase[v] == (uint8_t)phase_id;
+    code[(long long)gz * g.plane + (long long)j * g.pitch + i] = act ? 6 : 0;
+    cnt += act;
+  }
+  __shared__ double red[4];
+  const double t = block_sum((double)cnt, red);
+  if (threadIdx.x == 0 && t != 0.0) atomicAdd(n_active, (unsigned long long)t);
+}
+
+// r = b_k = (D(+k) - D(-k)) / 2 on active cells (EffDiffFillMtx.F90:208-217 + :131-201), p = r,
+// chi = 0; partial r.r.  Needs the periodic ghost planes of `code`.
+__global__ void __launch_bounds__(256) k_ed_rhs(Geom g, const uint8_t* __restrict__ code, int dir_k,
+                                                 double* __restrict__ chi, double* __restrict__ r,
+                                                 double* __restrict__ p, double* __restrict__ partials) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  double rr = 0.0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    double b = 0.0;
+    if (code[e]) {
+      const int di = dir_k == 0, dj = dir_k == 1, dk = dir_k == 2;
+      const double dm = code[eidx(g, gz - dk, j - dj, i - di)] ? 1.0 : 0.0;
+      const double dp = code[eidx(g, gz + dk, j + dj, i + di)] ? 1.0 : 0.0;
+      b = (dp - dm) * 0.5;
+    }
+    chi[e] = 0.0;
+    r[e] = b;
+    p[e] = b;
+    rr += b * b;
+  }
+  __shared__ double red[4];
+  const double t = block_sum(rr, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = t; partials[2 * blockIdx.x + 1] = t; }  // {r.r, r.z}
+}
+
+// q = A v (periodic), partial v.q; same summation order as the oracle
+__global__ void __launch_bounds__(256) k_ed_apply(Geom g, const uint8_t* __restrict__ code,
+                                                   const double* __restrict__ v, double* __restrict__ q,
+                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->done) return;
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  double pq = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % g.nx), j = (int)((t / g.nx) % g.ny), gz = 1 + (int)(t / ((long long)g.nx * g.ny));
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    double out = 0.0;
+    if (code[e]) {
+      const double c = v[e];
+      const double s = ((((v[eidx(g, gz, j, i - 1)] + v[eidx(g, gz, j, i + 1)]) + v[eidx(g, gz, j - 1, i)]) +
+                         v[eidx(g, gz, j + 1, i)]) + v[e - g.plane]) + v[e + g.plane];
+      out = 6.0 * c - s;
+      pq += c * out;
+    }
+    q[e] = out;
+  }
+  __shared__ double red[4];
+  const double t = block_sum(pq, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// D[row][col] partial sums: over active cells, (row == col) - d chi_col / d x_row  (Diffusion.cpp:108-140)
+__global__ void __launch_bounds__(256) k_ed_tensor(Geom g, const uint8_t* __restrict__ code,
+                                                    const double* __restrict__ cx, const double* __restrict__ cy,
+                                                    const double* __restrict__ cz, double* __restrict__ partials) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double* chi[3] = {cx, cy, cz};
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % g.nx), j = (int)((t / g.nx) % g.ny), gz = 1 + (int)(t / ((long long)g.nx * g.ny));
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    if (!code[e]) continue;
+    const long long nb[6] = {eidx(g, gz, j, i - 1), eidx(g, gz, j, i + 1), eidx(g, gz, j - 1, i), eidx(g, gz, j + 1, i),
+                             e - g.plane, e + g.plane};
+#pragma unroll
+    for (int row = 0; row < 3; ++row)
+#pragma unroll
+      for (int col = 0; col < 3; ++col) {
+        const double grad = (chi[col][nb[2 * row + 1]] - chi[col][nb[2 * row]]) * 0.5;
+        s[3 * row + col] += (row == col ? 1.0 : 0.0) - grad;
+      }
+  }
+  __shared__ double red[4];
+  for (int c = 0; c < 9; ++c) {
+    const double t = block_sum(s[c], red);
+    if (threadIdx.x == 0) partials[9 * blockIdx.x + c] = t;
+  }
+}
+
+int nblocks(long long items, int cap) {
+  long long b = (items + 255) / 256;
+  return (int)std::max<long long>(1, std::min<long long>(b, cap));
+}
+
+}  // namespace
+
+struct oi_effdiff {
+  Geom g{};
+  oi_tort_opts opts{};
+  int device = 0, phase_id = 0;
+  hipStream_t stream = nullptr;
+  uint8_t* code = nullptr;
+  double *chi[3] = {nullptr, nullptr, nullptr}, *r = nullptr, *p = nullptr, *q = nullptr;
+  double *partials = nullptr, *hist = nullptr, *scal = nullptr;
+  Ctrl* ctrl = nullptr;
+  unsigned long long* counter = nullptr;
+  int maxiter = 0;
+  long long n_active = 0;
+  bool solved[3] = {false, false, false};
+  int iters[3] = {0, 0, 0};
+  double relres[3] = {0, 0, 0};
+};
+
+extern "C" void oi_effdiff_destroy(oi_effdiff* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* dev[] = {h->code, h->chi[0], h->chi[1], h->chi[2], h->r, h->p, h->q, h->partials, h->hist, h->scal, h->ctrl, h->counter};
+  for (void* d : dev)
+    if (d) (void)hipFree(d);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// periodic images of the first / last owned plane into the ghost planes (FillBoundary with a
+// periodic geometry, Diffusion.cpp:306-309)
+static oi_status wrap_z(oi_effdiff* h, void* base, size_t plane_bytes) {
+  char* b = (char*)base;
+  const size_t nzl = (size_t)h->g.nzl;
+  HIPC(hipMemcpyAsync(b, b + plane_bytes * nzl, plane_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPC(hipMemcpyAsync(b + plane_bytes * (nzl + 1), b + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, h->stream));
+  return OI_OK;
+}
+
+extern "C" oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
+                                       const oi_tort_opts* opts) {
+  if (!out) return OI_BAD_ARG;
+  *out = nullptr;
+  if (!phase || nx < 1 || ny < 1 || nz < 1) return OI_BAD_ARG;
+  oi_tort_opts o;
+  oi_tort_default_opts(&o);
+  if (opts) o = *opts;
+  if (!(o.eps > 0.0)) { oi::set_error("eps must be positive"); return OI_BAD_ARG; }  // EffectiveDiffusivityHypre.cpp:156
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    oi::set_error("no HIP device visible: this library has no CPU fallback");
+    return OI_NO_DEVICE;
+  }
+  if (o.device >= 0) HIPC(hipSetDevice(o.device));
+  std::unique_ptr<oi_effdiff, void (*)(oi_effdiff*)> h(new oi_effdiff(), oi_effdiff_destroy);
+  HIPC(hipGetDevice(&h->device));
+  h->opts = o;
+  h->phase_id = phase_id;
+  Geom& g = h->g;
+  g.nx = nx; g.ny = ny; g.nz = nz; g.z0 = 0; g.nzl = nz; g.dir = 0;
+  g.pitch = (nx + 1) & ~1;
+  g.W = (nx + 63) / 64;
+  g.plane = (long long)g.pitch * ny;
+  g.wplane = (long long)g.W * ny;
+  g.nvec = (long long)(nz + 2) * g.plane;
+  g.nwords = 0;
+  g.vlo = 0; g.vhi = 0;
+  // the reference's default budget is 1000 multigrid-preconditioned iterations (:120); CG on this
+  // well-conditioned system needs ~100, so the same default is generous
+  h->maxiter = o.maxiter > 0 ? o.maxiter : 1000 + 4 * (nx + ny + nz);
+  HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  hipStream_t s = h->stream;
+  HIPC(hipMalloc((void**)&h->code, (size_t)g.nvec));
+  for (int k = 0; k < 3; ++k) HIPC(hipMalloc((void**)&h->chi[k], sizeof(double) * g.nvec));
+  HIPC(hipMalloc((void**)&h->r, sizeof(double) * g.nvec));
+  HIPC(hipMalloc((void**)&h->p, sizeof(double) * g.nvec));
+  HIPC(hipMalloc((void**)&h->q, sizeof(double) * g.nvec));
+  HIPC(hipMalloc((void**)&h->partials, sizeof(double) * 9 * kMaxPartials));
+  HIPC(hipMalloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
+  HIPC(hipMalloc((void**)&h->scal, sizeof(double) * 16));
+  HIPC(hipMalloc((void**)&h->ctrl, sizeof(Ctrl)));
+  HIPC(hipMalloc((void**)&h->counter, sizeof(unsigned long long)));
+  HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
+  HIPC(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), s));
+  for (int k = 0; k < 3; ++k) HIPC(hipMemsetAsync(h->chi[k], 0, sizeof(double) * g.nvec, s));
+  const size_t n = (size_t)nx * ny * nz;
+  uint8_t* tmp = nullptr;
+  HIPC(hipMalloc((void**)&tmp, n));
+  HIPC(hipMemcpyAsync(tmp, phase, n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_ed_codes, dim3(nblocks((long long)n, 8192)), dim3(256), 0, s, g, tmp, phase_id, h->code, h->counter);
+  OIC(wrap_z(h.get(), h->code, (size_t)g.plane));
+  unsigned long long cnt = 0;
+  HIPC(hipMemcpyAsync(&cnt, h->counter, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipFree(tmp));
+  h->n_active = (long long)cnt;
+  *out = h.release();
+  return OI_OK;
+}
+
+// EffectiveDiffusivityHypre::solve (EffectiveDiffusivityHypre.cpp:543-687) for direction k.
+// *converged = 0 leaves chi_k = 0 as the reference does (:641-645).
+extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, int* iterations, double* relres) {
+  if (!h || dir_k < 0 || dir_k > 2) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  hipStream_t s = h->stream;
+  double* chi = h->chi[dir_k];
+  if (converged) *converged = 0;
+  if (h->n_active == 0) {  // :558-575: nothing to solve, chi = 0, reported as converged
+    HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));
+    HIPC(hipStreamSynchronize(s));
+    h->solved[dir_k] = true; h->iters[dir_k] = 0; h->relres[dir_k] = 0.0;
+    if (converged) *converged = 1;
+    if (iterations) *iterations = 0;
+    if (relres) *relres = 0.0;
+    return OI_OK;
+  }
+  HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * (h->maxiter + 2), s));
+  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, s));
+  HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * g.nvec, s));
+  HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
+  HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  const int nb0 = nblocks(n, 2048);
+  hipLaunchKernelGGL(k_ed_rhs, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, chi, h->r, h->p, h->partials);
+  Ctrl c;
+  c.done = 0; c.pad = 0; c.tol2 = std::numeric_limits<double>::infinity();  // set once ||b|| is known
+  HIPC(hipMemcpyAsync(h->ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+  launch_finalize(h->partials, nb0, 2, h->hist + H_RR, nullptr, 0, 0, s);
+  double bb = 0.0;
+  HIPC(hipMemcpyAsync(&bb, h->hist + H_RR, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  const double bnorm = std::sqrt(bb);
+  int K = 0;
+  double rel = 0.0;
+  bool conv = bnorm == 0.0;  // b = 0 (e.g. no interface along k): chi = 0 is exact
+  if (!conv) {
+    c.tol2 = (h->opts.eps * bnorm) * (h->opts.eps * bnorm);
+    HIPC(hipMemcpyAsync(h->ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+    const int batch = h->opts.check_every > 0 ? h->opts.check_every : 16;
+    int issued = 0;
+    Ctrl seen = c;
+    while (!seen.done && issued < h->maxiter) {
+      for (int b = 0; b < batch && issued < h->maxiter; ++b, ++issued) {
+        const int k = issued;
+        if (k > 0) launch_update_p(g, h->code, h->r, h->p, 0, h->hist, k, h->ctrl, s);
+        OIC(wrap_z(h, h->p, sizeof(double) * g.plane));
+        hipLaunchKernelGGL(k_ed_apply, dim3(nb0), dim3(256), 0, s, g, h->code, h->p, h->q, h->partials, h->ctrl);
+        launch_finalize(h->partials, nb0, 1, h->hist + H_STRIDE * k + H_PQ, h->ctrl, 0, 0, s);
+        const int nb = launch_update_xr(g, h->code, chi, h->r, h->p, h->q, 0, h->hist, k, h->partials, h->ctrl, s);
+        launch_finalize(h->partials, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, h->ctrl, 1, k + 2, s);
+      }
+      HIPC(hipMemcpyAsync(&seen, h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+      HIPC(hipStreamSynchronize(s));
+    }
+    K = seen.done ? seen.done - 1 : issued;
+    double rr = 0.0;
+    HIPC(hipMemcpyAsync(&rr, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    rel = std::sqrt(rr) / bnorm;
+    conv = seen.done != 0 && std::isfinite(rel) && rel <= h->opts.eps;  // :608-612
+    if (!conv) HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));  // :641
+  }
+  OIC(wrap_z(h, chi, sizeof(double) * g.plane));  // periodic ghost cells of chi for the tensor
+  HIPC(hipStreamSynchronize(s));
+  h->solved[dir_k] = true; h->iters[dir_k] = K; h->relres[dir_k] = rel;
+  if (converged) *converged = conv ? 1 : 0;
+  if (iterations) *iterations = K;
+  if (relres) *relres = rel;
+  return OI_OK;
+}
+
+// getChiSolution (EffectiveDiffusivityHypre.cpp:689-): nx*ny*nz doubles, x fastest
+extern "C" oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi_out) {
+  if (!h || dir_k < 0 || dir_k > 2 || !chi_out) return OI_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const size_t n = (size_t)g.nx * g.ny * g.nzl;
+  double* dense = nullptr;
+  HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
+  launch_pitch_copy_out(g, h->chi[dir_k], dense, h->stream);
+  hipError_t e = hipMemcpyAsync(chi_out, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dense);
+  HIPC(e);
+  return OI_OK;
+}
+
+// calculate_Deff_tensor_homogenization (Diffusion.cpp:60-167): row-major 3x3, D_eff / D_material
+extern "C" oi_status oi_effdiff_tensor(oi_effdiff* h, double* deff9) {
+  if (!h || !deff9) return OI_BAD_ARG;
+  if (!(h->solved[0] && h->solved[1] && h->solved[2])) {
+    oi::set_error("solve chi_x, chi_y and chi_z first");
+    return OI_BAD_ARG;
+  }
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  const int nb = nblocks(n, 2048);
+  hipLaunchKernelGGL(k_ed_tensor, dim3(nb), dim3(256), 0, h->stream, g, h->code, h->chi[0], h->chi[1], h->chi[2],
+                     h->partials);
+  launch_finalize(h->partials, nb, 9, h->scal, nullptr, 0, 0, h->stream);
+  double sums[9];
+  HIPC(hipMemcpyAsync(sums, h->scal, sizeof(sums), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  const double ntot = (double)g.nx * g.ny * g.nz;
+  for (int t = 0; t < 9; ++t) deff9[t] = sums[t] / ntot;  // :150-156
+  return OI_OK;
+}
+
+extern "C" oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int* iterations3, double* relres3) {
+  if (!h) return OI_BAD_ARG;
+  if (n_active) *n_active = h->n_active;
+  for (int k = 0; k < 3; ++k) {
+    if (iterations3) iterations3[k] = h->iters[k];
+    if (relres3) relres3[k] = h->relres[k];
+  }
+  return OI_OK;
+}

@@ -89,6 +89,10 @@ def lib():
                                        C.POINTER(ll), C.POINTER(ll)]
         L.oi_oracle_tau.argtypes = [d, i, d, d, i, i, i, i, d, d, C.POINTER(d), C.POINTER(i)]
         L.oi_oracle_tau.restype = d
+        L.oi_oracle_effdiff_fillmtx.argtypes = [_u8p, i, i, i, i, i, _f64p, _f64p]
+        L.oi_oracle_effdiff_solve.argtypes = [_u8p, i, i, i, i, i, d, i, _f64p, C.POINTER(i), C.POINTER(d)]
+        L.oi_oracle_effdiff_solve.restype = i
+        L.oi_oracle_effdiff_tensor.argtypes = [_u8p, i, i, i, i, _f64p, _f64p, _f64p, _f64p]
         L.oi_oracle_set_threads(cpu_budget())
         _lib = L
     return _lib
@@ -265,6 +269,47 @@ def tortuosity(phase, phase_id, direction, vlo=0.0, vhi=1.0, eps=1e-9, maxiter=1
     out.update(converged=ok, iterations=it, relres=rel, flux_in=fi, flux_out=fo, deff=deff, tau=t,
                status=st, x=x)
     return out
+
+
+# ---------------------------------------------------------------------------
+# homogenization path (EffectiveDiffusivityHypre + Diffusion.cpp tensor integrator)
+# ---------------------------------------------------------------------------
+def effdiff_fillmtx(phase, phase_id, dir_k):
+    p = np.ascontiguousarray(phase, np.uint8)
+    nx, ny, nz = _dims(p)
+    a = np.empty(7 * p.size)
+    rhs = np.empty(p.size)
+    lib().oi_oracle_effdiff_fillmtx(p, nx, ny, nz, phase_id, dir_k, a, rhs)
+    return a.reshape(-1, 7), rhs
+
+
+def effdiff_solve(phase, phase_id, dir_k, eps=1e-9, maxiter=100000):
+    p = np.ascontiguousarray(phase, np.uint8)
+    nx, ny, nz = _dims(p)
+    chi = np.empty(p.shape)
+    it, rel = C.c_int(), C.c_double()
+    ok = lib().oi_oracle_effdiff_solve(p, nx, ny, nz, phase_id, dir_k, eps, maxiter, chi, C.byref(it), C.byref(rel))
+    return chi, bool(ok), it.value, rel.value
+
+
+def effdiff_tensor(phase, phase_id, chis):
+    p = np.ascontiguousarray(phase, np.uint8)
+    nx, ny, nz = _dims(p)
+    D = np.empty(9)
+    lib().oi_oracle_effdiff_tensor(p, nx, ny, nz, phase_id, *[np.ascontiguousarray(c, np.float64) for c in chis], D)
+    return D.reshape(3, 3)
+
+
+def effective_diffusivity(phase, phase_id, eps=1e-9, maxiter=100000):
+    """Diffusion.cpp homogenization branch (:509-589): three chi_k solves, then the tensor."""
+    chis, its = [], []
+    for k in range(3):
+        chi, ok, it, rel = effdiff_solve(phase, phase_id, k, eps, maxiter)
+        if not ok:
+            return None, its
+        chis.append(chi)
+        its.append(it)
+    return effdiff_tensor(phase, phase_id, chis), its
 
 
 # ---------------------------------------------------------------------------

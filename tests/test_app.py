@@ -31,8 +31,8 @@ data_path = {GOLDEN}
 results_path = {tmp_path}/res
 verbose = 0
 """
-    # default calculation_method is homogenization (Diffusion.cpp:188): out of scope -> exit code 2
-    r = subprocess.run([app, _inputs(tmp_path, base)], capture_output=True, text=True)
+    # an unknown calculation_method matches no branch
+    r = subprocess.run([app, _inputs(tmp_path, base), "calculation_method=foo"], capture_output=True, text=True)
     assert r.returncode == 2 and "flow_through" in r.stderr
     # mandatory key missing (ParmParse::get aborts in the reference)
     r = subprocess.run([app, _inputs(tmp_path, "verbose = 0\n")], capture_output=True, text=True)
@@ -101,3 +101,24 @@ verbose = 0
     lines = open(tmp_path / "res" / "results.txt").read().splitlines()
     assert float(lines[4].split(": ")[1]) == pytest.approx(raw.mean(), abs=1e-9)
     assert float(lines[5].split(": ")[1]) == pytest.approx(ref["tau"], rel=1e-7)
+
+
+@pytest.mark.gpu
+def test_diffusion_default_method_is_homogenization(app, tmp_path):
+    """No calculation_method key: the reference's default branch (Diffusion.cpp:188,509-589) prints the
+    D_eff tensor; compared with the oracle's restatement."""
+    import numpy as np
+    from oracle import oracle as o
+    tif = os.path.join(GOLDEN, "SampleData_2Phase_squared.tif")
+    want, _ = o.effective_diffusivity(o.read_tiff_phase(tif), 1, eps=1e-10)
+    text = f"""
+filename = SampleData_2Phase_squared.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+hypre.eps = 1e-10
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Full Domain Effective Diffusivity Tensor D_eff / D_material:" in r.stdout
+    got = np.loadtxt(tmp_path / "res" / "Deff_tensor.txt")
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)

@@ -1,0 +1,80 @@
+"""Homogenization path (the reference's default calculation_method).
+
+The reference pins no number for it (tests/inputs/tEffectiveDiffusivity.inputs only asks for
+convergence, symmetry to 1e-7 and non-negative diagonals), so parity here is against the
+oracle's restatement of effdiff_fillmtx + the Diffusion.cpp tensor integrator (parity
+unpinned beyond those invariants)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+
+def test_oracle_rows_restate_effdiff_fillmtx(sample_phase):
+    sub = np.ascontiguousarray(sample_phase[:14, :12, :16])
+    for k in range(3):
+        a, rhs = o.effdiff_fillmtx(sub, 1, k)
+        act = sub.reshape(-1) == 1
+        assert np.all(a[act, 0] == 6.0) and np.all(a[~act, 0] == 1.0) and np.all(a[~act, 1:] == 0.0)
+        assert np.all(rhs[~act] == 0.0) and set(np.unique(rhs)) <= {-0.5, 0.0, 0.5}
+        # symmetric: -1 towards a neighbour iff both cells are active
+        nz, ny, nx = sub.shape
+        idx = np.arange(sub.size).reshape(sub.shape)
+        for s, (ax, sh) in enumerate([(2, 1), (2, -1), (1, 1), (1, -1), (0, 1), (0, -1)]):
+            nb = np.roll(idx, sh, axis=ax).reshape(-1)      # periodic neighbour (-x,+x,-y,+y,-z,+z)
+            assert np.array_equal(a[:, 1 + s] == -1.0, act & act[nb])
+        # the matrix-free CG solves exactly these rows
+        chi, ok, it, rel = o.effdiff_solve(sub, 1, k, eps=1e-12)
+        assert ok
+        x = chi.reshape(-1)
+        res = a[:, 0] * x - rhs
+        for s, (ax, sh) in enumerate([(2, 1), (2, -1), (1, 1), (1, -1), (0, 1), (0, -1)]):
+            res += a[:, 1 + s] * x[np.roll(idx, sh, axis=ax).reshape(-1)]
+        assert np.abs(res).max() < 1e-10
+
+
+def test_oracle_tensor_invariants(sample_phase):
+    D, its = o.effective_diffusivity(np.ones((8, 10, 12), np.uint8), 1)
+    np.testing.assert_allclose(D, np.eye(3), atol=1e-14)       # no interfaces: chi = 0, D = I
+    D, its = o.effective_diffusivity(np.ascontiguousarray(sample_phase[:40, :40, :40]), 1, eps=1e-10)
+    assert np.abs(D - D.T).max() < 1e-7 and np.all(np.diag(D) >= 0)   # tEffectiveDiffusivity's checks
+    lam = np.zeros((8, 8, 8), np.uint8)
+    lam[:, ::2, :] = 1                                                 # layers normal to y
+    D, _ = o.effective_diffusivity(lam, 1)
+    assert D[0, 0] == pytest.approx(0.5) and D[2, 2] == pytest.approx(0.5)  # along the layers: chi = 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,pid", [((40, 36, 44), 1), ((24, 30, 33), 0), ((16, 16, 130), 1)])
+def test_gpu_homogenization_matches_oracle(sample_phase, shape, pid):
+    import openimpala_amd as oia
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
+    want, its = o.effective_diffusivity(sub, pid, eps=1e-10)
+    h = oia.EffectiveDiffusivityMI355(sub, pid, eps=1e-10)
+    for k in range(3):
+        conv, it, rel = h.solve(k)
+        assert conv and rel <= 1e-10 and abs(it - its[k]) <= 2
+        chi, ok, _, _ = o.effdiff_solve(sub, pid, k, eps=1e-10)
+        np.testing.assert_allclose(h.getChiSolution(k), chi, rtol=0, atol=1e-9)
+    D = h.tensor()
+    np.testing.assert_allclose(D, want, rtol=0, atol=1e-9)
+    assert np.abs(D - D.T).max() < 1e-7 and np.all(np.diag(D) >= 0)
+    h.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_homogenization_edge_cases():
+    import openimpala_amd as oia
+    h = oia.EffectiveDiffusivityMI355(np.ones((6, 8, 10), np.uint8), 1)
+    assert all(h.solve(k)[0] for k in range(3))
+    np.testing.assert_allclose(h.tensor(), np.eye(3), atol=1e-14)
+    h = oia.EffectiveDiffusivityMI355(np.zeros((6, 8, 10), np.uint8), 1)   # no active cell
+    assert all(h.solve(k) == (True, 0, 0.0) for k in range(3))
+    np.testing.assert_allclose(h.tensor(), np.zeros((3, 3)), atol=0)
+    s = o.gen_spheres((32, 32, 32), 3, 5, 0.5)
+    h = oia.EffectiveDiffusivityMI355(s, 1, maxiter=2)                     # not converged -> chi = 0
+    conv, it, rel = h.solve(0)
+    assert not conv and it == 2 and np.all(h.getChiSolution(0) == 0.0)
+    with pytest.raises(oia.OpenImpalaError):
+        h.tensor()                                                          # chi_y, chi_z missing
