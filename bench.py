@@ -28,12 +28,32 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 BYTES_PER_VOXEL = {"cg1": 61.0, "fused_a": 49.0, "update_r": 24.0, "apply": 17.0, "update_p": 24.0, "update_xr": 48.0}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the C stdout when its first communicator comes up; the
+    driver wants exactly one JSON line there, so file descriptor 1 points at stderr meanwhile."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # C stdio buffers of every library in the process
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024, help="voxels per edge")
+    ap.add_argument("--nz", type=int, default=0, help="planes along z if not cubic (slab-size rehearsal)")
     ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli", "blobs"])
     ap.add_argument("--direction", default="X", choices=["X", "Y", "Z"], help="flow axis (headline: X)")
     ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused"])
@@ -122,13 +142,16 @@ def main():
     import openimpala_amd as oia
 
     if use_dist:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        uid = torch.zeros(oia.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(oia.Comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        comm = oia.Comm.create(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        with _StdoutToStderr():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            uid = torch.zeros(oia.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(oia.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = oia.Comm.create(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+            dist.barrier()
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -136,8 +159,10 @@ def main():
             torch.cuda.synchronize()
 
     n = args.size
-    shape = (n, n, n)
-    z0, z1 = oia.slab_range(n, world, rank)
+    nz = args.nz if args.nz > 0 else n
+    nvox = n * n * nz
+    shape = (nz, n, n)
+    z0, z1 = oia.slab_range(nz, world, rank)
     nzl = z1 - z0
     t_gen = time.time()
     buf, desc = make_structure(oia, args, shape, z0, nzl)
@@ -149,7 +174,7 @@ def main():
     # eps = 1e-300 during the timed region: every one of the K steps does full work
     kw = dict(eps=1e-300, kernel=kernel, precond=precond, profile=1, maxiter=200000, device=local_rank)
     if comm is not None:
-        t = oia.TortuosityMI355(buf, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=n,
+        t = oia.TortuosityMI355(buf, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=nz,
                                 **kw)
     else:
         t = oia.TortuosityMI355(buf, 1, direction, 0.0, 1.0, shape=shape, **kw)
@@ -187,7 +212,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     steps_done = min(args.steps, max(0, it_done - args.warmup)) if conv else args.steps
-    value = n ** 3 * args.steps / dt / 1e6
+    value = nvox * args.steps / dt / 1e6
     alg_bytes_iter = sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL)
 
     # dominant kernel of the timed region, from the HIP events on the solver's stream
@@ -235,7 +260,7 @@ def main():
         barrier()
         s1 = time.perf_counter() - s0
         solve = {"eps": 1e-6, "converged": bool(done), "iterations": its, "relres": rel, "seconds": s1,
-                 "mvoxel_iters_per_s": n ** 3 * its / s1 / 1e6 if s1 > 0 else None}
+                 "mvoxel_iters_per_s": nvox * its / s1 / 1e6 if s1 > 0 else None}
 
     # ---- variant: search direction p STORED as fp32 (x, r, q and all arithmetic fp64) ----
     variants = None
@@ -245,7 +270,7 @@ def main():
         kw2 = dict(kw, p_storage=oia.STORE_F32)
         if comm is not None:
             t = oia.TortuosityMI355(buf2, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0,
-                                    nz_global=n, **kw2)
+                                    nz_global=nz, **kw2)
         else:
             t = oia.TortuosityMI355(buf2, 1, direction, 0.0, 1.0, shape=shape, **kw2)
         buf2.free()
@@ -268,7 +293,7 @@ def main():
         variants = {"p_stored_fp32": {
             "note": "search direction kept as fp32 in HBM; x, r, q and every operation fp64; r stays the exact "
                     "recurrence residual of x (tests/test_gpu_parity.py::test_fp32_stored_search_direction)",
-            "value": n ** 3 * args.steps / vdt / 1e6, "unit": "Mvoxel-iters/s", "ms_per_step": vdt / args.steps * 1e3,
+            "value": nvox * args.steps / vdt / 1e6, "unit": "Mvoxel-iters/s", "ms_per_step": vdt / args.steps * 1e3,
             "bytes_per_voxel_iter": alg_bytes_iter - (10.0 if args.kernel == "fused1" else 8.0),
             "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in vk.items()}}}
 
@@ -282,9 +307,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{n}^3 two-phase {desc}; phase 1, {args.direction} direction; matrix-free CG "
+            "config": {"workload": f"{n}x{n}x{nz} two-phase {desc}; phase 1, {args.direction} direction; matrix-free CG "
                                    f"({args.kernel}, precond {args.precond}); z-slabs over {world} GPU(s)",
-                       "voxels": n ** 3, "active_vf": st.active_vf, "volume_fraction": st.vf,
+                       "voxels": nvox, "active_vf": st.active_vf, "volume_fraction": st.vf,
                        "unknowns": st.n_free, "parallelism": f"z-slab x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
             "apply_roofline": apply_info,
