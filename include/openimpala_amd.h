@@ -45,7 +45,9 @@ typedef enum oi_status {
 typedef struct oi_tort oi_tort; /* replaces an OpenImpala::TortuosityHypre object */
 typedef struct oi_comm oi_comm; /* replaces MPI_COMM_WORLD / amrex::ParallelDescriptor for this path */
 
-enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1 };
+/* MG: aggregation-multigrid V(1,1) cycle per PCG iteration (what SMG is to the reference's
+ * FlexGMRES): O(50) iterations instead of O(10 N); single GPU */
+enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1, OI_PRECOND_MG = 2 };
 /* UNFUSED: apply / p-update / x,r-update kernels (89 B/voxel-iter); FUSED: two kernels (73 B);
  * FUSED1: ONE kernel per iteration with a single reduction (65 B), see DESIGN.md section 4 */
 enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2, OI_KERNEL_FUSED1 = 3 };

@@ -39,7 +39,7 @@ struct Ctrl {
 
 enum KernelId {
   K_PACK = 0, K_SEED, K_FLOOD, K_MASK, K_CODES, K_INIT, K_RESID0, K_APPLY, K_UPDATE_P, K_UPDATE_XR,
-  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_CG1, K_COUNT
+  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_CG1, K_MG, K_COUNT
 };
 
 // maximum number of per-block partial sums any reducing kernel writes
@@ -79,6 +79,9 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
+// fine-level halves of the multigrid V-cycle on the LDS tile (see oi_kernels.hip)
+int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, const double* xc, int cnx, int cny,
+                   double omega, double scale, double* out, double* partials, const Ctrl* ctrl, hipStream_t s);
 void set_fused_tuning(int tile_rows, int zchunk);
 void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles

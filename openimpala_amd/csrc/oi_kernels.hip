@@ -825,6 +825,150 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 }
 
 // --------------------------------------------------------------------------------------
+// Fine-level halves of the multigrid V-cycle on the same z-marching LDS tile as the stencil
+// apply (17-18 B/voxel each instead of seven cache-served loads per voxel):
+//   MODE 1 (pre) :  v = w b / code                         out = b - A v
+//   MODE 2 (post):  v = w b / code + s * xc[parent]        out = v + w (b - A v) / code,
+//                   partial out.b  (= z.r of the preconditioned CG)
+// b vanishes on non-free cells; xc is the dense coarse correction of the 2x2x2 aggregates.
+// --------------------------------------------------------------------------------------
+template <int R, int MODE>
+__global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
+                                                       const double* __restrict__ b, const double* __restrict__ xc,
+                                                       int cnx, int cny, double omega, double scale,
+                                                       double* __restrict__ out, int zchunk, int tiles_x, int tiles_y,
+                                                       int nzc, double* __restrict__ partials,
+                                                       const Ctrl* __restrict__ ctrl) {
+  constexpr int BY = kNW * R;
+  static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
+  if (ctrl && ctrl->done) return;
+  __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
+  __shared__ double red[kNW];
+  const int ntiles = tiles_x * tiles_y * nzc;
+  int L = blockIdx.x;
+  if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = tx * kBX + 2 * lane, j0 = ty * BY;
+  const bool in_x = i < g.pitch;
+  const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);
+  const int hrow = (w == 0) ? j0 - 1 : j0 + BY;
+  const bool yhalo = (w < 2) && in_x && hrow >= 0 && hrow < g.ny;
+  const int xh_row = j0 + (lane >> 1);
+  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
+
+  // v at one voxel (ghost planes and the pad column hold code 0, so xc is never indexed for them)
+  auto vval = [&](double bv, unsigned c, int ii, int jj, int gz) -> double {
+    if (!c) return 0.0;
+    double v = omega * bv / (double)c;
+    if (MODE == 2) v += scale * xc[(long long)(ii >> 1) + (long long)cnx * ((long long)(jj >> 1) + (long long)cny * ((gz - 1) >> 1))];
+    return v;
+  };
+  auto v_at = [&](int ii, int jj, int gz) -> double {
+    const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
+    return vval(b[e], code[e], ii, jj, gz);
+  };
+  auto load_plane = [&](int gz, double2 (&vn)[R], double2 (&bn)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      vn[rr_] = make_double2(0.0, 0.0);
+      bn[rr_] = make_double2(0.0, 0.0);
+      if (in_x && j < g.ny) {
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const double2 bv = ld2(b + e);
+        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        bn[rr_] = bv;
+        vn[rr_] = make_double2(vval(bv.x, cc & 0xffu, i, j, gz), vval(bv.y, cc >> 8, i + 1, j, gz));
+      }
+    }
+  };
+  auto stage = [&](int bsel, int gz, const double2 (&vn)[R]) {
+    double* T = tile[bsel];
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_)
+      *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = vn[rr_];
+    if (w < 2) {
+      double2 h = make_double2(0.0, 0.0);
+      if (yhalo) { h.x = v_at(i, hrow, gz); h.y = v_at(i + 1, hrow, gz); }
+      *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+    } else if (w == 2 && lane < 2 * BY) {
+      double h = 0.0;
+      if (xhalo) h = v_at(xh_i, xh_row, gz);
+      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    }
+  };
+
+  double2 v_prev[R], v_cur[R], v_nxt[R], b_cur[R], b_nxt[R];
+  load_plane(gs - 1, v_prev, b_nxt);
+  load_plane(gs, v_cur, b_cur);
+  stage(gs & 1, gs, v_cur);
+  __syncthreads();
+  double dot = 0.0;
+  for (int gz = gs; gz < ge; ++gz) {
+    load_plane(gz + 1, v_nxt, b_nxt);
+    if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, v_nxt);
+    const double* T = tile[gz & 1];
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      if (in_x && j < g.ny) {
+        const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
+        const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
+        const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
+        const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
+        const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
+        const double2 vc = v_cur[rr_], bc = b_cur[rr_];
+        const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
+        const double s1 = ((((vc.x + rt.x) + ym.y) + yp.y) + v_prev[rr_].y) + v_nxt[rr_].y;
+        double o0 = 0.0, o1 = 0.0;
+        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE == 1 ? bc.x - av : vc.x + omega * (bc.x - av) / (double)c0; }
+        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE == 1 ? bc.y - av : vc.y + omega * (bc.y - av) / (double)c1; }
+        st2(out + e, o0, o1);
+        dot += o0 * bc.x; dot += o1 * bc.y;
+      }
+    }
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) { v_prev[rr_] = v_cur[rr_]; v_cur[rr_] = v_nxt[rr_]; b_cur[rr_] = b_nxt[rr_]; }
+    __syncthreads();
+  }
+  const double t = block_sum(dot, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// mode 1 = pre (out = b - A v), 2 = post (out = z, partial z.b); returns the number of partials
+int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, const double* xc, int cnx, int cny,
+                   double omega, double scale, double* out, double* partials, const Ctrl* ctrl, hipStream_t s) {
+  constexpr int R = 2;
+  const int by = kNW * R;
+  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)tiles_x * tiles_y;
+  long long want = (4096 + cols - 1) / cols;
+  if (want < 1) want = 1;
+  int zchunk = (int)((g.nzl + want - 1) / want);
+  if (zchunk < 64) zchunk = 64;
+  if (zchunk > g.nzl) zchunk = g.nzl;
+  int nzc = (g.nzl + zchunk - 1) / zchunk;
+  if (cols * nzc > kMaxPartials) {
+    const int maxc = (int)(kMaxPartials / cols) > 0 ? (int)(kMaxPartials / cols) : 1;
+    zchunk = (g.nzl + maxc - 1) / maxc;
+    nzc = (g.nzl + zchunk - 1) / zchunk;
+  }
+  const int blocks = (int)(cols * nzc);
+  if (mode == 1)
+    hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, xc, cnx, cny, omega, scale, out,
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  else
+    hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, xc, cnx, cny, omega, scale, out,
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  return blocks;
+}
+
+// --------------------------------------------------------------------------------------
 // Single-kernel CG iteration ("cg1").  Kernel k turns the state after k-1 iterations into
 // the state after k iterations plus the next search direction and its image:
 //     x_k  = x_{k-1} + alpha_{k-1} p_{k-1}

@@ -1,0 +1,452 @@
+// oi_mg.hip -- aggregation-multigrid V-cycle used as the preconditioner of the CG solve
+// (OI_PRECOND_MG).  What HYPRE's SMG buys the reference (TortuosityHypre.cpp:664-693: one
+// multigrid V-cycle per Krylov iteration, <= 200 iterations), rebuilt matrix-free for the
+// masked voxel operator:
+//
+//   * aggregates = 2x2x2 blocks of cells, piecewise-constant prolongation P, restriction P^T;
+//   * Galerkin coarse operators A_{l+1} = P^T A_l P are again 7-point operators whose entries
+//     are INTEGER link counts: w_x(I) = number of fine links crossing the +x face of block I,
+//     diag(I) = sum of the children's diagonals - 2 * (links inside the block); built level
+//     by level on the device, exact in fp32/fp64;
+//   * per level: one damped-Jacobi sweep from zero, residual, restriction, recursion, scaled
+//     coarse correction, one damped-Jacobi sweep; the first three coarse levels are visited
+//     twice (W-cycle: unsmoothed aggregation needs it), deeper ones once; the coarsest level
+//     (<= 512 cells) gets 16 sweeps.  Every step is a fixed symmetric linear map, so the cycle
+//     is an SPD preconditioner and plain PCG applies.
+//
+// Measured on the oracle prototype (profiles/r01/mg_prototype.txt): 32-61 PCG iterations to
+// 1e-6 against 474-1777 with Jacobi, independent of the grid size.  Single GPU (a slab
+// decomposition would need level agglomeration).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "oi_comm.h"
+#include "oi_device.h"
+#include "oi_mg.h"
+
+namespace oi {
+
+namespace {
+
+constexpr double kOmega = 0.8;   // Jacobi damping
+constexpr double kScale = 1.5;   // over-correction of the piecewise-constant coarse correction
+constexpr int kCoarsestSweeps = 16;
+constexpr long long kCoarsestCells = 512;
+constexpr int kWCycleLevels = 3;  // the first three coarse levels are visited twice (W-cycle), 0 = pure V-cycle
+
+inline int nblk(long long items, int cap = 8192) {
+  long long b = (items + 255) / 256;
+  return (int)std::max<long long>(1, std::min<long long>(b, cap));
+}
+
+struct LevelDev {  // by-value kernel argument
+  int nx, ny, nz;
+  const float *wx, *wy, *wz;  // link weight towards +x / +y / +z (0 = no link)
+  const double* diag;         // 0 = cell does not exist
+};
+
+__device__ __forceinline__ long long cidx(const LevelDev& L, int i, int j, int k) {
+  return (long long)i + (long long)L.nx * ((long long)j + (long long)L.ny * k);
+}
+
+// ------------------------------ hierarchy construction ------------------------------
+// level 1 from the fine codes: a fine cell is free iff code != 0; a fine link exists between
+// two free face neighbours; diag_fine = code (active neighbours incl. Dirichlet cells)
+__global__ void __launch_bounds__(256) k_mg_build1(Geom g, const uint8_t* __restrict__ code, int cnx, int cny, int cnz,
+                                                    float* __restrict__ wx, float* __restrict__ wy,
+                                                    float* __restrict__ wz, double* __restrict__ diag) {
+  const long long n = (long long)cnx * cny * cnz;
+  auto fr = [&](int i, int j, int k) -> int {  // free? (k is a global plane 0..nz-1)
+    if (i < 0 || j < 0 || k < 0 || i >= g.nx || j >= g.ny || k >= g.nz) return 0;
+    return code[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i] != 0;
+  };
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int I = (int)(v % cnx), J = (int)((v / cnx) % cny), K = (int)(v / ((long long)cnx * cny));
+    int lx = 0, ly = 0, lz = 0;
+    double d = 0.0;
+    for (int c = 0; c < 2; ++c)
+      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+          const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
+          if (!fr(i, j, k)) continue;
+          const int cd = code[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i];
+          // free neighbours inside the same block
+          const int inside = fr(a ? i - 1 : i + 1, j, k) + fr(i, b ? j - 1 : j + 1, k) + fr(i, j, c ? k - 1 : k + 1);
+          d += (double)(cd - inside);
+          if (a == 1) lx += fr(i + 1, j, k);
+          if (b == 1) ly += fr(i, j + 1, k);
+          if (c == 1) lz += fr(i, j, k + 1);
+        }
+    wx[v] = (float)lx; wy[v] = (float)ly; wz[v] = (float)lz; diag[v] = d;
+  }
+}
+
+// level l+1 from level l (l >= 1)
+__global__ void __launch_bounds__(256) k_mg_build(LevelDev F, int cnx, int cny, int cnz, float* __restrict__ wx,
+                                                   float* __restrict__ wy, float* __restrict__ wz,
+                                                   double* __restrict__ diag) {
+  const long long n = (long long)cnx * cny * cnz;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int I = (int)(v % cnx), J = (int)((v / cnx) % cny), K = (int)(v / ((long long)cnx * cny));
+    float lx = 0.f, ly = 0.f, lz = 0.f;
+    double d = 0.0;
+    for (int c = 0; c < 2; ++c)
+      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+          const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
+          if (i >= F.nx || j >= F.ny || k >= F.nz) continue;
+          const long long m = cidx(F, i, j, k);
+          d += F.diag[m];
+          // links towards +x/+y/+z: internal ones (a/b/c == 0) leave the diagonal twice,
+          // the ones on the block face become the coarse link
+          if (a == 0) d -= 2.0 * (double)F.wx[m]; else lx += F.wx[m];
+          if (b == 0) d -= 2.0 * (double)F.wy[m]; else ly += F.wy[m];
+          if (c == 0) d -= 2.0 * (double)F.wz[m]; else lz += F.wz[m];
+        }
+    wx[v] = lx; wy[v] = ly; wz[v] = lz; diag[v] = d;
+  }
+}
+// (a child on the far side of an odd-sized level has no +neighbour inside the block: its link
+//  weight towards + is a face link of the coarse block or 0 at the domain edge -- both handled
+//  because weights at the domain edge are 0 by construction.)
+
+// ------------------------------ coarse-level cycle kernels ------------------------------
+__device__ __forceinline__ double capply(const LevelDev& L, int i, int j, int k, long long m, double vc,
+                                         double vxm, double vxp, double vym, double vyp, double vzm, double vzp) {
+  double s = 0.0;
+  if (i > 0) s += (double)L.wx[m - 1] * vxm;
+  if (i < L.nx - 1) s += (double)L.wx[m] * vxp;
+  if (j > 0) s += (double)L.wy[m - L.nx] * vym;
+  if (j < L.ny - 1) s += (double)L.wy[m] * vyp;
+  if (k > 0) s += (double)L.wz[m - (long long)L.nx * L.ny] * vzm;
+  if (k < L.nz - 1) s += (double)L.wz[m] * vzp;
+  return L.diag[m] * vc - s;
+}
+
+// Coarse-level kernels: one thread per cell, grid = (x chunks, ny, nz) so no index division.
+#define OI_MG_CELL                                                        \
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z; \
+  if (i >= L.nx) return;                                                  \
+  const long long sy = L.nx, sz = (long long)L.nx * L.ny;                 \
+  const long long m = (long long)i + sy * j + sz * k;
+
+// x = w b / D (first Jacobi sweep from zero), r = b - A x
+__global__ void __launch_bounds__(256) k_mg_pre(LevelDev L, const double* __restrict__ b, double* __restrict__ x,
+                                                 double* __restrict__ r) {
+  OI_MG_CELL
+  auto xs = [&](long long mm) -> double { const double d = L.diag[mm]; return d > 0.0 ? kOmega * b[mm] / d : 0.0; };
+  double xc = 0.0, res = 0.0;
+  if (L.diag[m] > 0.0) {
+    xc = xs(m);
+    const double ax = capply(L, i, j, k, m, xc, i > 0 ? xs(m - 1) : 0.0, i < L.nx - 1 ? xs(m + 1) : 0.0,
+                             j > 0 ? xs(m - sy) : 0.0, j < L.ny - 1 ? xs(m + sy) : 0.0, k > 0 ? xs(m - sz) : 0.0,
+                             k < L.nz - 1 ? xs(m + sz) : 0.0);
+    res = b[m] - ax;
+  }
+  x[m] = xc;
+  r[m] = res;
+}
+
+// residual of the current iterate (second visit of a W-cycle): r = b - A x
+__global__ void __launch_bounds__(256) k_mg_resid(LevelDev L, const double* __restrict__ b, const double* __restrict__ x,
+                                                   double* __restrict__ r) {
+  OI_MG_CELL
+  double res = 0.0;
+  if (L.diag[m] > 0.0) {
+    const double ax = capply(L, i, j, k, m, x[m], i > 0 ? x[m - 1] : 0.0, i < L.nx - 1 ? x[m + 1] : 0.0,
+                             j > 0 ? x[m - sy] : 0.0, j < L.ny - 1 ? x[m + sy] : 0.0, k > 0 ? x[m - sz] : 0.0,
+                             k < L.nz - 1 ? x[m + sz] : 0.0);
+    res = b[m] - ax;
+  }
+  r[m] = res;
+}
+
+// y += x (correction of the second W-cycle visit)
+__global__ void __launch_bounds__(256) k_mg_add(long long n, double* __restrict__ y, const double* __restrict__ x) {
+  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (long long)gridDim.x * blockDim.x) y[m] += x[m];
+}
+
+// coarse right-hand side = P^T r (sum over the 2x2x2 children); L describes the COARSE level
+__global__ void __launch_bounds__(256) k_mg_restrict(int fnx, int fny, int fnz, const double* __restrict__ r, LevelDev L,
+                                                      double* __restrict__ bc) {
+  OI_MG_CELL
+  double s = 0.0;
+  for (int c = 0; c < 2; ++c)
+    for (int bb = 0; bb < 2; ++bb) {
+      const int fj = 2 * j + bb, fk = 2 * k + c;
+      if (fj >= fny || fk >= fnz) continue;
+      const long long row = (long long)fnx * ((long long)fj + (long long)fny * fk);
+      s += r[row + 2 * i];
+      if (2 * i + 1 < fnx) s += r[row + 2 * i + 1];
+    }
+  bc[m] = s;
+}
+
+// x_out = x2 + w (b - A x2) / D with x2 = x + kScale * P xc   (prolongation + post-smoothing)
+__global__ void __launch_bounds__(256) k_mg_post(LevelDev L, const double* __restrict__ b, const double* __restrict__ x,
+                                                  const double* __restrict__ xc, int cnx, int cny,
+                                                  double* __restrict__ xout) {
+  OI_MG_CELL
+  auto x2 = [&](int ii, int jj, int kk) -> double {
+    const long long mm = cidx(L, ii, jj, kk);
+    if (!(L.diag[mm] > 0.0)) return 0.0;
+    return x[mm] + kScale * xc[(long long)(ii >> 1) + (long long)cnx * ((long long)(jj >> 1) + (long long)cny * (kk >> 1))];
+  };
+  double out = 0.0;
+  const double d = L.diag[m];
+  if (d > 0.0) {
+    const double c = x2(i, j, k);
+    const double ax = capply(L, i, j, k, m, c, i > 0 ? x2(i - 1, j, k) : 0.0, i < L.nx - 1 ? x2(i + 1, j, k) : 0.0,
+                             j > 0 ? x2(i, j - 1, k) : 0.0, j < L.ny - 1 ? x2(i, j + 1, k) : 0.0,
+                             k > 0 ? x2(i, j, k - 1) : 0.0, k < L.nz - 1 ? x2(i, j, k + 1) : 0.0);
+    out = c + kOmega * (b[m] - ax) / d;
+  }
+  xout[m] = out;
+}
+
+// coarsest level: x_out = x_in + w (b - A x_in) / D   (first = 1: x_in = 0)
+__global__ void __launch_bounds__(256) k_mg_jacobi(LevelDev L, const double* __restrict__ b, const double* __restrict__ xin,
+                                                    double* __restrict__ xout, int first) {
+  OI_MG_CELL
+  const double d = L.diag[m];
+  double out = 0.0;
+  if (d > 0.0) {
+    if (first) {
+      out = kOmega * b[m] / d;
+    } else {
+      const double c = xin[m];
+      const double ax = capply(L, i, j, k, m, c, i > 0 ? xin[m - 1] : 0.0, i < L.nx - 1 ? xin[m + 1] : 0.0,
+                               j > 0 ? xin[m - sy] : 0.0, j < L.ny - 1 ? xin[m + sy] : 0.0, k > 0 ? xin[m - sz] : 0.0,
+                               k < L.nz - 1 ? xin[m + sz] : 0.0);
+      out = c + kOmega * (b[m] - ax) / d;
+    }
+  }
+  xout[m] = out;
+}
+
+// ------------------------------ fine-level cycle kernels ------------------------------
+// fine vectors live in the pitched / ghost-plane layout; b vanishes on non-free cells.
+// r1 = b - A (w b / code)
+__global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
+                                                      double* __restrict__ r1, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->done) return;
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  auto xs = [&](long long e) -> double { const unsigned c = code[e]; return c ? kOmega * b[e] / (double)c : 0.0; };
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    const unsigned c = code[e];
+    double res = 0.0;
+    if (c) {
+      const double s = ((((i > 0 ? xs(e - 1) : 0.0) + (i < g.nx - 1 ? xs(e + 1) : 0.0)) + (j > 0 ? xs(e - g.pitch) : 0.0)) +
+                        (j < g.ny - 1 ? xs(e + g.pitch) : 0.0)) + xs(e - g.plane) + xs(e + g.plane);
+      res = b[e] - ((double)c * xs(e) - s);
+    }
+    r1[e] = res;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const double* __restrict__ r1, int cnx, int cny, int cnz,
+                                                           double* __restrict__ bc) {
+  const long long n = (long long)cnx * cny * cnz;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int I = (int)(v % cnx), J = (int)((v / cnx) % cny), K = (int)(v / ((long long)cnx * cny));
+    double s = 0.0;
+    for (int c = 0; c < 2; ++c)
+      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+          const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
+          if (i < g.nx && j < g.ny && k < g.nz) s += r1[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i];
+        }
+    bc[v] = s;
+  }
+}
+
+// z = x2 + w (b - A x2) / code,  x2 = w b / code + kScale * P xc
+__global__ void __launch_bounds__(256) k_mg_fine_post(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
+                                                       const double* __restrict__ xc, int cnx, int cny,
+                                                       double* __restrict__ z, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->done) return;
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  auto x2 = [&](int i, int j, int gz) -> double {  // gz: plane incl. ghost offset; ghost planes hold code 0
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    const unsigned c = code[e];
+    if (!c) return 0.0;
+    return kOmega * b[e] / (double)c +
+           kScale * xc[(long long)(i >> 1) + (long long)cnx * ((long long)(j >> 1) + (long long)cny * ((gz - 1) >> 1))];
+  };
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    const unsigned c = code[e];
+    double out = 0.0;
+    if (c) {
+      const double xc0 = x2(i, j, gz);
+      const double s = ((((i > 0 ? x2(i - 1, j, gz) : 0.0) + (i < g.nx - 1 ? x2(i + 1, j, gz) : 0.0)) +
+                         (j > 0 ? x2(i, j - 1, gz) : 0.0)) + (j < g.ny - 1 ? x2(i, j + 1, gz) : 0.0)) +
+                       (gz > 1 ? x2(i, j, gz - 1) : 0.0) + (gz < g.nzl ? x2(i, j, gz + 1) : 0.0);
+      out = xc0 + kOmega * (b[e] - ((double)c * xc0 - s)) / (double)c;
+    }
+    z[e] = out;
+  }
+}
+
+// partial r.z over the owned planes
+__global__ void __launch_bounds__(256) k_mg_dot(Geom g, const double* __restrict__ a, const double* __restrict__ b,
+                                                 double* __restrict__ partials) {
+  const long long npairs = (long long)g.nzl * g.plane / 2;
+  double s = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += (long long)gridDim.x * blockDim.x) {
+    const long long e = g.plane + 2 * t;
+    const double2 av = *reinterpret_cast<const double2*>(a + e), bv = *reinterpret_cast<const double2*>(b + e);
+    s += av.x * bv.x; s += av.y * bv.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+int launch_dot(const Geom& g, const double* a, const double* b, double* partials, hipStream_t s);
+
+struct MgLevelHost {
+  int nx = 0, ny = 0, nz = 0;
+  long long n = 0;
+  float *wx = nullptr, *wy = nullptr, *wz = nullptr;
+  double *diag = nullptr, *b = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr, *xs = nullptr;
+  LevelDev dev() const { return LevelDev{nx, ny, nz, wx, wy, wz, diag}; }
+};
+
+struct MgHierarchy {
+  std::vector<MgLevelHost> levels;  // levels[0] = first COARSE level
+  size_t bytes = 0;
+};
+
+void mg_destroy(MgHierarchy* mg) {
+  if (!mg) return;
+  for (auto& L : mg->levels) {
+    void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.x, L.x2, L.r, L.xs};
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  }
+  delete mg;
+}
+
+#define MGC(call)                                                            \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      mg_destroy(mg);                                                        \
+      return nullptr;                                                        \
+    }                                                                        \
+  } while (0)
+
+MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, hipStream_t s, size_t* bytes_out) {
+  MgHierarchy* mg = new MgHierarchy();
+  int fx = g.nx, fy = g.ny, fz = g.nz;
+  for (int l = 0; l < 24; ++l) {
+    MgLevelHost L;
+    L.nx = (fx + 1) / 2; L.ny = (fy + 1) / 2; L.nz = (fz + 1) / 2;
+    L.n = (long long)L.nx * L.ny * L.nz;
+    MGC(hipMalloc((void**)&L.wx, sizeof(float) * L.n));
+    MGC(hipMalloc((void**)&L.wy, sizeof(float) * L.n));
+    MGC(hipMalloc((void**)&L.wz, sizeof(float) * L.n));
+    MGC(hipMalloc((void**)&L.diag, sizeof(double) * L.n));
+    MGC(hipMalloc((void**)&L.b, sizeof(double) * L.n));
+    MGC(hipMalloc((void**)&L.x, sizeof(double) * L.n));
+    MGC(hipMalloc((void**)&L.x2, sizeof(double) * L.n));
+    MGC(hipMalloc((void**)&L.r, sizeof(double) * L.n));
+    MGC(hipMalloc((void**)&L.xs, sizeof(double) * L.n));
+    mg->bytes += (size_t)L.n * (3 * sizeof(float) + 6 * sizeof(double));
+    if (l == 0) {
+      hipLaunchKernelGGL(k_mg_build1, dim3(nblk(L.n)), dim3(256), 0, s, g, code, L.nx, L.ny, L.nz, L.wx, L.wy, L.wz, L.diag);
+    } else {
+      hipLaunchKernelGGL(k_mg_build, dim3(nblk(L.n)), dim3(256), 0, s, mg->levels.back().dev(), L.nx, L.ny, L.nz, L.wx,
+                         L.wy, L.wz, L.diag);
+    }
+    mg->levels.push_back(L);
+    fx = L.nx; fy = L.ny; fz = L.nz;
+    if (L.n <= kCoarsestCells || (L.nx == 1 && L.ny == 1 && L.nz == 1)) break;
+  }
+  MGC(hipStreamSynchronize(s));
+  if (bytes_out) *bytes_out = mg->bytes;
+  return mg;
+}
+
+// z = M^-1 r on the fine level; `scratch` is a fine vector the caller does not need meanwhile
+static inline int bx_for(int nx) { return nx >= 256 ? 256 : (nx >= 128 ? 128 : 64); }
+static inline dim3 grid_for(const MgLevelHost& L) { return dim3((L.nx + bx_for(L.nx) - 1) / bx_for(L.nx), L.ny, L.nz); }
+
+// Approximate solve of level l: right-hand side in Ls[l].b, result in Ls[l].x2.
+// Levels above kWCycleLevels are visited twice per parent visit (W-cycle: the second visit
+// solves for the residual of the first), deeper levels once; every step is a fixed symmetric
+// linear map, so the whole cycle stays a valid CG preconditioner.
+static void coarse_cycle(MgHierarchy* mg, int l, hipStream_t s) {
+  auto& Ls = mg->levels;
+  const int nl = (int)Ls.size();
+  MgLevelHost& L = Ls[l];
+  const dim3 gr = grid_for(L), bl(bx_for(L.nx));
+  if (l == nl - 1) {  // coarsest: a fixed number of damped-Jacobi sweeps
+    double *in = L.x, *out = L.x2;
+    for (int it = 0; it < kCoarsestSweeps; ++it) {
+      hipLaunchKernelGGL(k_mg_jacobi, gr, bl, 0, s, L.dev(), L.b, in, out, it == 0 ? 1 : 0);
+      std::swap(in, out);
+    }
+    if (in != L.x2) (void)hipMemcpyAsync(L.x2, in, sizeof(double) * L.n, hipMemcpyDeviceToDevice, s);
+    return;
+  }
+  MgLevelHost& C = Ls[l + 1];
+  const dim3 grc = grid_for(C), blc(bx_for(C.nx));
+  hipLaunchKernelGGL(k_mg_pre, gr, bl, 0, s, L.dev(), L.b, L.x, L.r);
+  hipLaunchKernelGGL(k_mg_restrict, grc, blc, 0, s, L.nx, L.ny, L.nz, L.r, C.dev(), C.b);
+  coarse_cycle(mg, l + 1, s);
+  if (l + 1 < kWCycleLevels) {  // second visit of the child level
+    hipLaunchKernelGGL(k_mg_resid, grc, blc, 0, s, C.dev(), C.b, C.x2, C.r);
+    (void)hipMemcpyAsync(C.xs, C.x2, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(C.b, C.r, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
+    coarse_cycle(mg, l + 1, s);
+    hipLaunchKernelGGL(k_mg_add, dim3(nblk(C.n, 2048)), dim3(256), 0, s, C.n, C.x2, C.xs);
+  }
+  hipLaunchKernelGGL(k_mg_post, gr, bl, 0, s, L.dev(), L.b, L.x, C.x2, C.nx, C.ny, L.x2);
+}
+
+int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
+              double* partials, const Ctrl* ctrl, int tiled, hipStream_t s) {
+  auto& Ls = mg->levels;
+  const long long nfine = (long long)g.nzl * g.ny * g.nx;
+  MgLevelHost& C = Ls[0];
+  if (tiled) launch_mg_fine(1, g, code, r, nullptr, 0, 0, kOmega, kScale, scratch, partials, ctrl, s);
+  else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl);
+  hipLaunchKernelGGL(k_mg_fine_restrict, dim3(nblk(C.n)), dim3(256), 0, s, g, scratch, C.nx, C.ny, C.nz, C.b);
+  coarse_cycle(mg, 0, s);
+  if (kWCycleLevels > 0) {
+    const dim3 grc = grid_for(C), blc(bx_for(C.nx));
+    hipLaunchKernelGGL(k_mg_resid, grc, blc, 0, s, C.dev(), C.b, C.x2, C.r);
+    (void)hipMemcpyAsync(C.xs, C.x2, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(C.b, C.r, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
+    coarse_cycle(mg, 0, s);
+    hipLaunchKernelGGL(k_mg_add, dim3(nblk(C.n, 2048)), dim3(256), 0, s, C.n, C.x2, C.xs);
+  }
+  if (tiled)  // also leaves the per-block partial sums of z.r
+    return launch_mg_fine(2, g, code, r, C.x2, C.nx, C.ny, kOmega, kScale, z, partials, ctrl, s);
+  hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, C.x2, C.nx, C.ny, z, ctrl);
+  return launch_dot(g, r, z, partials, s);
+}
+
+int mg_levels(const MgHierarchy* mg) { return mg ? (int)mg->levels.size() + 1 : 0; }
+
+int launch_dot(const Geom& g, const double* a, const double* b, double* partials, hipStream_t s) {
+  const int blocks = nblk((long long)g.nzl * g.plane / 2, 2048);
+  hipLaunchKernelGGL(k_mg_dot, dim3(blocks), dim3(256), 0, s, g, a, b, partials);
+  return blocks;
+}
+
+}  // namespace oi

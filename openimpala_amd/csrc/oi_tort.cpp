@@ -23,6 +23,7 @@
 
 #include "oi_comm.h"
 #include "oi_device.h"
+#include "oi_mg.h"
 
 namespace oi {
 const char* last_error();
@@ -49,7 +50,7 @@ static double now_s() {
 
 static const char* kKernelNames[K_COUNT] = {
     "pack_open", "seed", "flood_sweep", "mask_and", "codes", "init_field", "residual0", "apply",
-    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate", "cg1"};
+    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate", "cg1", "mg_vcycle"};
 
 struct ProfRec {
   int kid;
@@ -72,6 +73,8 @@ struct oi_tort {
   double *x = nullptr, *r = nullptr, *q = nullptr;
   double *r2 = nullptr, *q2 = nullptr;  // second buffers of the single-kernel variant
   double* rec = nullptr;                // its per-iteration scalar records
+  double* z = nullptr;                  // preconditioned residual of the multigrid variant
+  oi::MgHierarchy* mg = nullptr;
   void* p[2] = {nullptr, nullptr};  // search direction: fp64, or fp32 storage when p_f32
   bool p_f32 = false;
   size_t p_elem = sizeof(double);
@@ -200,6 +203,8 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
   if (h->ev_boundary) (void)hipEventDestroy(h->ev_boundary);
   if (h->ev_exchanged) (void)hipEventDestroy(h->ev_exchanged);
+  if (h->mg) oi::mg_destroy(h->mg);
+  if (h->z) (void)hipFree(h->z);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -346,6 +351,15 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     HIPC(hipMalloc(&h->p[b], (size_t)g.nvec * h->p_elem));
     h->bytes_device += (size_t)g.nvec * h->p_elem;
   }
+  if (h->opts.precond == OI_PRECOND_MG) {
+    OIC(dmalloc(h, &h->z, (size_t)g.nvec));
+    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
+    size_t mg_bytes = 0;
+    h->mg = mg_setup(g, h->code, s, &mg_bytes);
+    if (!h->mg) return OI_HIP_ERROR;
+    h->bytes_device += mg_bytes;
+    if (h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] multigrid hierarchy: %d levels, %.1f MB\n", mg_levels(h->mg), mg_bytes / 1e6);
+  }
   h->vectors_ready = true;
   h->st.t_setup_s = now_s() - t2;
   h->st.bytes_device = (double)h->bytes_device;
@@ -380,6 +394,19 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->jacobi = o.precond == OI_PRECOND_JACOBI;
   h->fused = o.kernel != OI_KERNEL_UNFUSED;
   h->cg1 = o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_AUTO;  // fastest variant is the default
+  if (o.precond == OI_PRECOND_MG) {
+    // the V-cycle dominates an iteration, so the outer PCG uses the plain (unfused) kernels
+    if (comm && comm->size > 1) {
+      oi::set_error("the multigrid preconditioner is single-GPU in this version");
+      return OI_BAD_ARG;
+    }
+    if (o.kernel == OI_KERNEL_FUSED1) {
+      oi::set_error("the multigrid preconditioner runs on the two-kernel or unfused iteration (kernel = auto | fused | unfused)");
+      return OI_BAD_ARG;
+    }
+    h->fused = o.kernel != OI_KERNEL_UNFUSED;  // z = M^-1 r enters the fused kernel in place of r
+    h->cg1 = false;
+  }
   h->p_f32 = o.p_storage == OI_STORE_F32;
   h->p_elem = h->p_f32 ? sizeof(float) : sizeof(double);
   if (h->p_f32 && !h->fused) {
@@ -476,7 +503,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
     { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, s); }
     OIC(exchange_planes(h, h->r2, sizeof(double) * g.plane));
   } else {
-    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, h->fused ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
     // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
     OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
     if (h->fused) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
@@ -535,15 +562,39 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
   } else if (h->fused) {
     void* p_in = h->p[(k + 1) & 1];
     void* p_out = h->p[k & 1];
+    const double* zsrc = h->r;
+    if (h->mg) {  // preconditioned residual from the multigrid V-cycle, and r.z into hist[k]
+      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, getenv("OI_MG_PLAIN") ? 0 : 1, s); }
+      OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+      zsrc = h->z;
+    }
     {
       PROF(K_FUSED_A);
-      nb = launch_fused_a(g, h->code, h->x, h->r, p_in, p_out, h->p_f32 ? 1 : 0, h->q, h->jacobi, h->hist, k, h->partials,
+      nb = launch_fused_a(g, h->code, h->x, zsrc, p_in, p_out, h->p_f32 ? 1 : 0, h->q, h->jacobi, h->hist, k, h->partials,
                           h->ctrl, s);
     }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     { PROF(K_UPDATE_R); nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
     OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+  } else if (h->mg) {
+    // PCG with the multigrid V-cycle: z = M^-1 r, r.z, p = z + beta p, q = A p, x/r update
+    double* p = (double*)h->p[0];
+    { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, getenv("OI_MG_PLAIN") ? 0 : 1, s); }
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+    if (k > 0) {
+      PROF(K_UPDATE_P);
+      launch_update_p(g, h->code, h->z, p, 0, h->hist, k, h->ctrl, s);
+    } else {
+      HIPC(hipMemcpyAsync(p, h->z, sizeof(double) * g.nvec, hipMemcpyDeviceToDevice, s));
+    }
+    { PROF(K_APPLY); nb = launch_apply_tiled(g, h->code, p, h->q, h->partials, h->ctrl, s); }
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
+    {
+      PROF(K_UPDATE_XR);
+      nb = launch_update_xr(g, h->code, h->x, h->r, p, h->q, 0, h->hist, k, h->partials, h->ctrl, s);
+    }
+    OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
   } else {
     if (k > 0) {
       PROF(K_UPDATE_P);
@@ -648,7 +699,8 @@ extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* 
 static oi_status solve(oi_tort* h) {
   const double t0 = now_s();
   OIC(oi_tort_cg_begin(h));
-  int batch = h->opts.check_every > 0 ? h->opts.check_every : 32;
+  // multigrid iterations are few and expensive: look at the flag more often
+  int batch = h->opts.check_every > 0 ? h->opts.check_every : (h->mg ? 4 : 32);
   hipEvent_t ev[2];
   HIPC(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
   HIPC(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));

@@ -243,6 +243,37 @@ def test_device_generators_match_oracle():
     assert np.array_equal(part.download(np.uint8, (9, 44, 48)), o.gen_spheres((40, 44, 48), 9, 6, 0.4)[13:22])
 
 
+@pytest.mark.parametrize("pid,direction", [(1, 0), (0, 2), (1, 1)])
+def test_multigrid_preconditioned_cg(sample, goldens, pid, direction):
+    """OI_PRECOND_MG: one aggregation-multigrid V-cycle per PCG iteration (the role SMG plays for
+    the reference's FlexGMRES).  Same answer as the goldens, an order of magnitude fewer
+    iterations than CG, r still the true residual of x."""
+    g = goldens["phases"][str(pid)]
+    t = oia.TortuosityMI355(sample, pid, direction, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG)
+    tau = t.value()
+    st = t.stats()
+    assert t.status == oia.OI_OK and st.converged and st.final_relres <= 1e-10
+    assert tau == pytest.approx(g["tau"][direction], rel=1e-7)
+    assert st.flux_in == pytest.approx(g["flux"][direction], rel=1e-7)
+    assert st.iterations < 150          # plain CG needs 900-1500 here
+    mask, _ = o.active_mask(sample, pid, direction)
+    code = o.codes(mask, direction)
+    true_rel = np.linalg.norm(o.apply(code, t.solution())) / o.bnorm(mask, direction, g["vlo"], g["vhi"])
+    assert true_rel <= 1.05e-10
+    t.destroy()
+
+
+def test_multigrid_ragged_shapes_and_refusals():
+    phase = o.gen_spheres((37, 45, 51), 6, 5, 0.5)       # odd sizes: truncated aggregates on every level
+    for d in range(3):
+        ref = o.tortuosity(phase, 1, d, -1.0, 1.0, eps=1e-10)
+        t = oia.TortuosityMI355(phase, 1, d, -1.0, 1.0, eps=1e-10, precond=oia.PRECOND_MG)
+        assert t.value() == pytest.approx(ref["tau"], rel=1e-8) and t.getSolverIterations() < ref["iterations"] / 4
+        t.destroy()
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TortuosityMI355(phase, 1, 0, precond=oia.PRECOND_MG, kernel=oia.KERNEL_FUSED1)
+
+
 def test_low_porosity_blobs_jacobi_pcg():
     """BASELINE.json config 5 in miniature: a correlated structure at porosity 0.2 (iid noise
     would not percolate), Jacobi-preconditioned CG, every kernel variant, against the oracle."""
