@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
   const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
   const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
 
-  // v at one voxel (ghost planes and the pad column hold code 0, so xc is never indexed for them)
+  // v at one voxel (the pad column holds code 0 and ghost planes are skipped, so xc is never indexed for them)
   auto vval = [&](double bv, unsigned c, int ii, int jj, int gz) -> double {
     if (!c) return 0.0;
     double v = omega * bv / (double)c;
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       const int j = j0 + w + rr_ * kNW;
       vn[rr_] = make_double2(0.0, 0.0);
       bn[rr_] = make_double2(0.0, 0.0);
-      if (in_x && j < g.ny) {
+      if (in_x && j < g.ny && gz >= 1 && gz <= g.nzl) {  // ghost planes count as zero (slab-local cycle)
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const double2 bv = ld2(b + e);
         const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);

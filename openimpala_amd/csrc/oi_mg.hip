@@ -58,8 +58,8 @@ __global__ void __launch_bounds__(256) k_mg_build1(Geom g, const uint8_t* __rest
                                                     float* __restrict__ wx, float* __restrict__ wy,
                                                     float* __restrict__ wz, double* __restrict__ diag) {
   const long long n = (long long)cnx * cny * cnz;
-  auto fr = [&](int i, int j, int k) -> int {  // free? (k is a global plane 0..nz-1)
-    if (i < 0 || j < 0 || k < 0 || i >= g.nx || j >= g.ny || k >= g.nz) return 0;
+  auto fr = [&](int i, int j, int k) -> int {  // free? (k is an owned plane 0..nzl-1 of this slab)
+    if (i < 0 || j < 0 || k < 0 || i >= g.nx || j >= g.ny || k >= g.nzl) return 0;
     return code[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i] != 0;
   };
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const double* 
       for (int b = 0; b < 2; ++b)
         for (int a = 0; a < 2; ++a) {
           const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
-          if (i < g.nx && j < g.ny && k < g.nz) s += r1[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i];
+          if (i < g.nx && j < g.ny && k < g.nzl) s += r1[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i];
         }
     bc[v] = s;
   }
@@ -351,7 +351,7 @@ void mg_destroy(MgHierarchy* mg) {
 
 MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, hipStream_t s, size_t* bytes_out) {
   MgHierarchy* mg = new MgHierarchy();
-  int fx = g.nx, fy = g.ny, fz = g.nz;
+  int fx = g.nx, fy = g.ny, fz = g.nzl;  // the hierarchy covers the owned planes of this slab
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
     L.nx = (fx + 1) / 2; L.ny = (fy + 1) / 2; L.nz = (fz + 1) / 2;

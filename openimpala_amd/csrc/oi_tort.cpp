@@ -395,11 +395,8 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->fused = o.kernel != OI_KERNEL_UNFUSED;
   h->cg1 = o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_AUTO;  // fastest variant is the default
   if (o.precond == OI_PRECOND_MG) {
-    // the V-cycle dominates an iteration, so the outer PCG uses the plain (unfused) kernels
-    if (comm && comm->size > 1) {
-      oi::set_error("the multigrid preconditioner is single-GPU in this version");
-      return OI_BAD_ARG;
-    }
+    // with neighbours every slab runs the cycle on its own planes (block-Jacobi across slabs, no
+    // exchange inside the cycle); only z's ghost planes travel, in place of r's
     if (o.kernel == OI_KERNEL_FUSED1) {
       oi::set_error("the multigrid preconditioner runs on the two-kernel or unfused iteration (kernel = auto | fused | unfused)");
       return OI_BAD_ARG;
@@ -506,7 +503,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
     { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
     // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
     OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
-    if (h->fused) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+    if (h->fused && !h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
   }
   h->iters_issued = 0;
   h->iters_done = 0;
@@ -566,6 +563,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     if (h->mg) {  // preconditioned residual from the multigrid V-cycle, and r.z into hist[k]
       { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, getenv("OI_MG_PLAIN") ? 0 : 1, s); }
       OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+      OIC(exchange_planes(h, h->z, sizeof(double) * g.plane));
       zsrc = h->z;
     }
     {
@@ -576,7 +574,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     { PROF(K_UPDATE_R); nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
-    OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+    if (!h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
   } else if (h->mg) {
     // PCG with the multigrid V-cycle: z = M^-1 r, r.z, p = z + beta p, q = A p, x/r update
     double* p = (double*)h->p[0];
@@ -588,6 +586,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     } else {
       HIPC(hipMemcpyAsync(p, h->z, sizeof(double) * g.nvec, hipMemcpyDeviceToDevice, s));
     }
+    OIC(exchange_planes(h, p, sizeof(double) * g.plane));
     { PROF(K_APPLY); nb = launch_apply_tiled(g, h->code, p, h->q, h->partials, h->ctrl, s); }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     {
