@@ -74,6 +74,10 @@ struct RcclComm : oi_comm {
     NCCLC(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, nccl, s));
     return OI_OK;
   }
+  oi_status allreduce_sum_f32(float* dev, size_t n, hipStream_t s) override {
+    NCCLC(ncclAllReduce(dev, dev, n, ncclFloat, ncclSum, nccl, s));
+    return OI_OK;
+  }
   oi_status allreduce_sum_u64_host(unsigned long long* vals, int n, hipStream_t s) override {
     if (n > 8) return OI_BAD_ARG;
     HIPC(hipMemcpyAsync(scratch, vals, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, s));
@@ -111,6 +115,8 @@ struct LocalShared {
   const double** stage_ptrs_dev = nullptr;  // device array of the n staging pointers
   std::vector<unsigned long long> hu64;
   std::vector<int> hi32;
+  std::vector<float*> big;             // per-rank scratch of the large f32 all-reduce (grown on demand)
+  std::vector<size_t> big_cap;
   void barrier() {
     std::unique_lock<std::mutex> lk(m);
     const unsigned long long gen = generation;
@@ -126,6 +132,8 @@ struct LocalShared {
     for (auto e : ev_ready) (void)hipEventDestroy(e);
     for (auto e : ev_done) (void)hipEventDestroy(e);
     for (auto p : stage) (void)hipFree(p);
+    for (auto p : big)
+      if (p) (void)hipFree(p);
     if (stage_ptrs_dev) (void)hipFree((void*)stage_ptrs_dev);
   }
 };
@@ -170,6 +178,33 @@ struct LocalComm : oi_comm {
     sh->barrier();
     for (int r = 0; r < size; ++r)
       if (r != rank) HIPC(hipStreamWaitEvent(s, sh->ev_done[r], 0));
+    sh->barrier();
+    return OI_OK;
+  }
+  oi_status allreduce_sum_f32(float* dev, size_t n, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    if (size > oi::kMaxSumRanks) return OI_BAD_ARG;
+    if (sh->big_cap[rank] < n) {
+      HIPC(hipStreamSynchronize(s));
+      if (sh->big[rank]) HIPC(hipFree(sh->big[rank]));
+      sh->big[rank] = nullptr;
+      HIPC(hipMalloc((void**)&sh->big[rank], sizeof(float) * n));
+      sh->big_cap[rank] = n;
+    }
+    sh->send_lo[rank] = dev;
+    HIPC(hipEventRecord(sh->ev_ready[rank], s));
+    sh->barrier();
+    const float* src[oi::kMaxSumRanks] = {};
+    for (int r = 0; r < size; ++r) {
+      src[r] = (const float*)sh->send_lo[r];
+      if (r != rank) HIPC(hipStreamWaitEvent(s, sh->ev_ready[r], 0));
+    }
+    oi::launch_sum_f32_ranks(sh->big[rank], src, size, n, s);  // rank order: identical on all ranks
+    HIPC(hipEventRecord(sh->ev_done[rank], s));
+    sh->barrier();
+    for (int r = 0; r < size; ++r)
+      if (r != rank) HIPC(hipStreamWaitEvent(s, sh->ev_done[r], 0));  // everyone has read my input
+    HIPC(hipMemcpyAsync(dev, sh->big[rank], sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     sh->barrier();
     return OI_OK;
   }
@@ -254,6 +289,8 @@ oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device) {
   sh->ev_ready.resize(nranks);
   sh->ev_done.resize(nranks);
   sh->stage.resize(nranks);
+  sh->big.assign(nranks, nullptr);
+  sh->big_cap.assign(nranks, 0);
   for (int r = 0; r < nranks; ++r) {
     HIPC(hipEventCreateWithFlags(&sh->ev_ready[r], hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&sh->ev_done[r], hipEventDisableTiming));

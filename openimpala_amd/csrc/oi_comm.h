@@ -21,6 +21,9 @@ struct oi_comm {
                              size_t bytes, hipStream_t s) = 0;
   // in-place sum of n doubles resident on the device, asynchronous on `s`
   virtual oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) = 0;
+  // in-place sum of a (large) float array resident on the device, asynchronous on `s`: gathers the
+  // slab-partitioned right-hand side of the first replicated multigrid level
+  virtual oi_status allreduce_sum_f32(float* dev, size_t n, hipStream_t s) = 0;
   // host-value collectives for the (rare) setup steps; they synchronise `s`
   virtual oi_status allreduce_sum_u64_host(unsigned long long* vals, int n, hipStream_t s) = 0;
   virtual oi_status allreduce_max_i32_host(int* vals, int n, hipStream_t s) = 0;

@@ -79,9 +79,18 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
-// fine-level halves of the multigrid V-cycle on the LDS tile (see oi_kernels.hip)
-int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, const double* xc, int cnx, int cny,
-                   double omega, double scale, double* out, double* partials, const Ctrl* ctrl, hipStream_t s);
+// coarse correction handed to the fine-level post-smoother of the multigrid cycle: fp32 arrays in
+// the first coarse level's layout (cnx * cny cells per plane, planes csz apart, one ghost plane
+// first; z0c = global index of the first owned coarse plane); the correction is xc + xc2
+struct MgCoarse {
+  const float* xc;
+  const float* xc2;  // second W-cycle visit, may be null
+  int cnx, cny, z0c;
+  long long csz;
+};
+// fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
+int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
+                   double* out, double* partials, const Ctrl* ctrl, hipStream_t s);
 void set_fused_tuning(int tile_rows, int zchunk);
 void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
@@ -119,6 +128,9 @@ void launch_gen_blobs(uint8_t* phase, int nx, int ny, int z0, int nzl, uint64_t 
                       hipStream_t s);
 uint64_t blob_value_host(uint64_t seed, int S, int i, int j, int k);
 void launch_sum_scalars(double* dst, const double* const* srcs, int nsrc, int n, hipStream_t s);
+// dst[i] = srcs[0][i] + srcs[1][i] + ... in rank order (large-array sum of the in-process transport)
+constexpr int kMaxSumRanks = 16;
+void launch_sum_f32_ranks(float* dst, const float* const* srcs_host, int nsrc, size_t n, hipStream_t s);
 // dense host-order (nx per row, nzl planes) <-> pitched/ghosted device vector
 void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipStream_t s);
 void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipStream_t s);

@@ -10,6 +10,8 @@
 // CPU oracle, so single-kernel outputs are bit-identical to it.
 #include "oi_device.h"
 
+#include <algorithm>
+
 namespace oi {
 
 // --------------------------------------------------------------------------------------
@@ -830,12 +832,20 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 //   MODE 1 (pre) :  v = w b / code                         out = b - A v
 //   MODE 2 (post):  v = w b / code + s * xc[parent]        out = v + w (b - A v) / code,
 //                   partial out.b  (= z.r of the preconditioned CG)
-// b vanishes on non-free cells; xc is the dense coarse correction of the 2x2x2 aggregates.
+// b vanishes on non-free cells and its ghost planes hold the neighbour slabs' values; xc is the
+// fp32 coarse correction of the 2x2x2 aggregates.
 // --------------------------------------------------------------------------------------
+// 1 / c for a neighbour count c in 1..6: v_rcp_f32 plus one Newton step in fp64 (relative error
+// < 1e-13) instead of the ~40-instruction IEEE fp64 division; the smoother only needs a fixed
+// positive diagonal scaling, applied identically everywhere
+__device__ __forceinline__ double inv_count(unsigned c) {
+  const double d = (double)c, y = (double)__builtin_amdgcn_rcpf((float)c);
+  return y * (2.0 - d * y);
+}
+
 template <int R, int MODE>
 __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
-                                                       const double* __restrict__ b, const double* __restrict__ xc,
-                                                       int cnx, int cny, double omega, double scale,
+                                                       const double* __restrict__ b, MgCoarse C, double omega, double scale,
                                                        double* __restrict__ out, int zchunk, int tiles_x, int tiles_y,
                                                        int nzc, double* __restrict__ partials,
                                                        const Ctrl* __restrict__ ctrl) {
@@ -858,11 +868,17 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
   const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
   const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
 
-  // v at one voxel (the pad column holds code 0 and ghost planes are skipped, so xc is never indexed for them)
+  // v at one voxel (the pad column and the ghost planes beyond the domain hold code 0, so the coarse
+  // correction is never indexed for them; ghost planes of a neighbour slab map to its ghost coarse plane)
   auto vval = [&](double bv, unsigned c, int ii, int jj, int gz) -> double {
     if (!c) return 0.0;
-    double v = omega * bv / (double)c;
-    if (MODE == 2) v += scale * xc[(long long)(ii >> 1) + (long long)cnx * ((long long)(jj >> 1) + (long long)cny * ((gz - 1) >> 1))];
+    double v = omega * bv * inv_count(c);
+    if (MODE == 2) {
+      const long long cm = (long long)(ii >> 1) + (long long)C.cnx * (jj >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+      float cv = C.xc[cm];
+      if (C.xc2) cv += C.xc2[cm];
+      v += scale * (double)cv;
+    }
     return v;
   };
   auto v_at = [&](int ii, int jj, int gz) -> double {
@@ -875,7 +891,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       const int j = j0 + w + rr_ * kNW;
       vn[rr_] = make_double2(0.0, 0.0);
       bn[rr_] = make_double2(0.0, 0.0);
-      if (in_x && j < g.ny && gz >= 1 && gz <= g.nzl) {  // ghost planes count as zero (slab-local cycle)
+      if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const double2 bv = ld2(b + e);
         const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
@@ -926,8 +942,8 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
         const double s1 = ((((vc.x + rt.x) + ym.y) + yp.y) + v_prev[rr_].y) + v_nxt[rr_].y;
         double o0 = 0.0, o1 = 0.0;
-        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE == 1 ? bc.x - av : vc.x + omega * (bc.x - av) / (double)c0; }
-        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE == 1 ? bc.y - av : vc.y + omega * (bc.y - av) / (double)c1; }
+        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE == 1 ? bc.x - av : vc.x + omega * (bc.x - av) * inv_count(c0); }
+        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE == 1 ? bc.y - av : vc.y + omega * (bc.y - av) * inv_count(c1); }
         st2(out + e, o0, o1);
         dot += o0 * bc.x; dot += o1 * bc.y;
       }
@@ -941,8 +957,8 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
 }
 
 // mode 1 = pre (out = b - A v), 2 = post (out = z, partial z.b); returns the number of partials
-int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, const double* xc, int cnx, int cny,
-                   double omega, double scale, double* out, double* partials, const Ctrl* ctrl, hipStream_t s) {
+int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
+                   double* out, double* partials, const Ctrl* ctrl, hipStream_t s) {
   constexpr int R = 2;
   const int by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
@@ -960,11 +976,11 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
   }
   const int blocks = (int)(cols * nzc);
   if (mode == 1)
-    hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, xc, cnx, cny, omega, scale, out,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+    hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, zchunk,
+                       tiles_x, tiles_y, nzc, partials, ctrl);
   else
-    hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, xc, cnx, cny, omega, scale, out,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+    hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, zchunk,
+                       tiles_x, tiles_y, nzc, partials, ctrl);
   return blocks;
 }
 
@@ -1319,6 +1335,22 @@ __global__ void k_sum_scalars(double* dst, const double* const* srcs, int nsrc, 
 
 void launch_sum_scalars(double* dst, const double* const* srcs, int nsrc, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_sum_scalars, dim3((n + 63) / 64), dim3(64), 0, s, dst, srcs, nsrc, n);
+}
+
+struct SumSrcs { const float* p[kMaxSumRanks]; };
+__global__ void __launch_bounds__(256) k_sum_f32_ranks(float* __restrict__ dst, SumSrcs srcs, int nsrc, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = srcs.p[0][i];
+    for (int s = 1; s < nsrc; ++s) v += srcs.p[s][i];
+    dst[i] = v;
+  }
+}
+
+void launch_sum_f32_ranks(float* dst, const float* const* srcs_host, int nsrc, size_t n, hipStream_t s) {
+  SumSrcs a = {};
+  for (int r = 0; r < nsrc && r < kMaxSumRanks; ++r) a.p[r] = srcs_host[r];
+  const size_t blocks = std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_sum_f32_ranks, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0, s, dst, a, nsrc, n);
 }
 
 // --------------------------------------------------------------------------------------

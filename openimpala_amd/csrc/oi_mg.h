@@ -4,19 +4,23 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "oi_comm.h"
 #include "oi_device.h"
 
 namespace oi {
 struct MgHierarchy;
-// builds every coarse operator from the fine code bytes (single slab = whole volume)
-MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, hipStream_t s, size_t* bytes_out);
+// builds every coarse operator from the fine code bytes of this slab (ghost code planes valid);
+// collective over `comm` when it has more than one rank
+MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, hipStream_t s, size_t* bytes_out);
 void mg_destroy(MgHierarchy* mg);
-// z = M^-1 r; r, scratch, z are fine vectors (pitched, ghost planes); scratch is overwritten.
-// Also leaves the per-block partial sums of z.r in `partials`; returns their number.
+// z = M^-1 r; r, scratch, z are fine vectors (pitched, ghost planes); scratch is overwritten and
+// r's ghost planes must hold the neighbours' values (z's are NOT filled).
+// Also leaves the per-block partial sums of z.r in `partials`; returns their number (-1: transport failure).
 // tiled = 0 selects the plain (cache-served) fine-level kernels kept as a cross-check.
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
               double* partials, const Ctrl* ctrl, int tiled, hipStream_t s);
 int mg_levels(const MgHierarchy* mg);
+int mg_replicated_from(const MgHierarchy* mg);  // first level (1 = first coarse) solved redundantly on every rank, -1 = none
 // partial sums of a.b over the owned planes; returns the number of partials
 int launch_dot(const Geom& g, const double* a, const double* b, double* partials, hipStream_t s);
 }  // namespace oi

@@ -1,25 +1,36 @@
-// oi_mg.hip -- aggregation-multigrid V-cycle used as the preconditioner of the CG solve
+// oi_mg.hip -- aggregation-multigrid cycle used as the preconditioner of the CG solve
 // (OI_PRECOND_MG).  What HYPRE's SMG buys the reference (TortuosityHypre.cpp:664-693: one
 // multigrid V-cycle per Krylov iteration, <= 200 iterations), rebuilt matrix-free for the
 // masked voxel operator:
 //
-//   * aggregates = 2x2x2 blocks of cells, piecewise-constant prolongation P, restriction P^T;
+//   * aggregates = 2x2x2 blocks of cells (aligned to GLOBAL even coordinates), piecewise-constant
+//     prolongation P, restriction P^T;
 //   * Galerkin coarse operators A_{l+1} = P^T A_l P are again 7-point operators whose entries
 //     are INTEGER link counts: w_x(I) = number of fine links crossing the +x face of block I,
 //     diag(I) = sum of the children's diagonals - 2 * (links inside the block); built level
-//     by level on the device, exact in fp32/fp64;
+//     by level on the device; the first three coarse levels store them as one byte per link and
+//     two per diagonal (5 B/cell), deeper ones as floats (exact below 2^24);
 //   * per level: one damped-Jacobi sweep from zero, residual, restriction, recursion, scaled
-//     coarse correction, one damped-Jacobi sweep; the first three coarse levels are visited
-//     twice (W-cycle: unsmoothed aggregation needs it), deeper ones once; the coarsest level
+//     coarse correction, one damped-Jacobi sweep; coarse levels 1-3 are visited twice per
+//     parent visit (W-cycle: unsmoothed aggregation needs it), the others once; the coarsest level
 //     (<= 512 cells) gets 16 sweeps.  Every step is a fixed symmetric linear map, so the cycle
-//     is an SPD preconditioner and plain PCG applies.
+//     is an SPD preconditioner and plain PCG applies;
+//   * coarse vectors are fp32 (the cycle only preconditions; the outer CG, its residual and
+//     the fine-level smoothing stay fp64).
 //
-// Measured on the oracle prototype (profiles/r01/mg_prototype.txt): 32-61 PCG iterations to
-// 1e-6 against 474-1777 with Jacobi, independent of the grid size.  Single GPU (a slab
-// decomposition would need level agglomeration).
+// Slabs: every level keeps the z-slab partition of the fine grid (ghost plane below and above,
+// one neighbour exchange per produced right-hand side / correction) while the slab boundaries
+// stay on even planes and the level is large; from the first level that is small (<= 2^18
+// cells), thin or misaligned on some rank, the rest of the hierarchy is REPLICATED: its
+// right-hand side is summed across ranks (one all-reduce per visit) and every rank runs the
+// same small cycle.  The arithmetic per cell does not depend on the partition.
+//
+// Measured on the oracle prototype (tools/mg_prototype.py, profiles/r01/mg_prototype.txt):
+// 20-61 PCG iterations to 1e-6 against 474-1777 with Jacobi, independent of the grid size.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "oi_comm.h"
@@ -30,210 +41,247 @@ namespace oi {
 
 namespace {
 
-constexpr double kOmega = 0.8;   // Jacobi damping
-constexpr double kScale = 1.5;   // over-correction of the piecewise-constant coarse correction
+constexpr float kOmega = 0.8f;   // Jacobi damping
+constexpr float kScale = 1.5f;   // over-correction of the piecewise-constant coarse correction
 constexpr int kCoarsestSweeps = 16;
 constexpr long long kCoarsestCells = 512;
-constexpr int kWCycleLevels = 3;  // the first three coarse levels are visited twice (W-cycle), 0 = pure V-cycle
+constexpr unsigned kWCycleMask = 14u;  // bit l: coarse level l (0 = first) is visited twice per parent visit;
+                                       // levels 1-3 (profiles/r01/mg_cycle_sweep.txt)
+constexpr int kCompactLevels = 3;      // link weights <= 4^(l+1) fit a byte, diagonals <= 6 * 4^(l+1) 16 bits
+constexpr long long kReplicateCells = 1ll << 18;
 
-inline int nblk(long long items, int cap = 8192) {
-  long long b = (items + 255) / 256;
-  return (int)std::max<long long>(1, std::min<long long>(b, cap));
-}
-
-struct LevelDev {  // by-value kernel argument
-  int nx, ny, nz;
-  const float *wx, *wy, *wz;  // link weight towards +x / +y / +z (0 = no link)
-  const double* diag;         // 0 = cell does not exist
+struct Dims {
+  int nx, ny, nzl, z0;  // owned planes [z0, z0 + nzl) of the level's global z range
+  long long sz;         // plane stride = nx * ny; arrays hold nzl + 2 planes (ghosts at 0 and nzl + 1)
 };
 
-__device__ __forceinline__ long long cidx(const LevelDev& L, int i, int j, int k) {
-  return (long long)i + (long long)L.nx * ((long long)j + (long long)L.ny * k);
+template <class W, class D>
+struct LevelT : Dims {
+  const W *wx, *wy, *wz;  // link weight towards +x / +y / +z (0 = no link; 0 on the domain faces)
+  const D* diag;          // 0 = cell does not exist
+};
+
+// one thread per cell of the local planes [kfirst, kfirst + nplanes); blocks are x-segments of
+// rows, dealt to the 8 XCDs in contiguous z-chunks so that the +-z neighbours share an L2
+#define OI_MG_CELL(L)                                                                          \
+  int t_ = blockIdx.x;                                                                         \
+  if ((gridDim.x & 7) == 0) t_ = (t_ & 7) * (gridDim.x >> 3) + (t_ >> 3);                      \
+  const int xb_ = (L.nx + blockDim.x - 1) / blockDim.x;                                        \
+  const int i = (t_ % xb_) * blockDim.x + threadIdx.x, j = (t_ / xb_) % L.ny, k = kfirst + t_ / (xb_ * L.ny); \
+  if (i >= L.nx) return;                                                                       \
+  const long long sy = L.nx, sz = L.sz;                                                        \
+  const long long m = (long long)i + sy * j + sz * k;
+
+// 1/d for the (small-integer) diagonals: one v_rcp_f32 (1 ulp) instead of the IEEE division sequence; the
+// smoother only needs a fixed positive diagonal scaling
+__device__ __forceinline__ float rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+
+// sum over the six links of weight * neighbour value.  No edge tests: the weights on the domain
+// faces are zero and every index stays inside the ghosted array.
+template <class W, class D>
+__device__ __forceinline__ float offdiag(const LevelT<W, D>& L, long long m, float vxm, float vxp, float vym, float vyp,
+                                         float vzm, float vzp) {
+  float s = (float)L.wx[m - 1] * vxm;
+  s += (float)L.wx[m] * vxp;
+  s += (float)L.wy[m - L.nx] * vym;
+  s += (float)L.wy[m] * vyp;
+  s += (float)L.wz[m - L.sz] * vzm;
+  s += (float)L.wz[m] * vzp;
+  return s;
 }
 
 // ------------------------------ hierarchy construction ------------------------------
-// level 1 from the fine codes: a fine cell is free iff code != 0; a fine link exists between
-// two free face neighbours; diag_fine = code (active neighbours incl. Dirichlet cells)
-__global__ void __launch_bounds__(256) k_mg_build1(Geom g, const uint8_t* __restrict__ code, int cnx, int cny, int cnz,
+// First coarse level from the fine codes: a fine cell is free iff code != 0; a fine link joins
+// two free face neighbours; diag_fine = code (active neighbours incl. Dirichlet cells).  Only
+// OWNED fine planes contribute (an aggregate straddling two slabs is summed across ranks).
+__global__ void __launch_bounds__(256) k_mg_build1(Geom g, const uint8_t* __restrict__ code, Dims L, int kfirst,
                                                     float* __restrict__ wx, float* __restrict__ wy,
-                                                    float* __restrict__ wz, double* __restrict__ diag) {
-  const long long n = (long long)cnx * cny * cnz;
-  auto fr = [&](int i, int j, int k) -> int {  // free? (k is an owned plane 0..nzl-1 of this slab)
-    if (i < 0 || j < 0 || k < 0 || i >= g.nx || j >= g.ny || k >= g.nzl) return 0;
-    return code[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i] != 0;
+                                                    float* __restrict__ wz, float* __restrict__ diag) {
+  OI_MG_CELL(L)
+  (void)sy;
+  auto fr = [&](int ii, int jj, int gz) -> int {  // free?  gz: local plane incl. the ghosts 0 and nzl + 1
+    if (ii < 0 || jj < 0 || ii >= g.nx || jj >= g.ny) return 0;
+    return code[(long long)gz * g.plane + (long long)jj * g.pitch + ii] != 0;
   };
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-    const int I = (int)(v % cnx), J = (int)((v / cnx) % cny), K = (int)(v / ((long long)cnx * cny));
-    int lx = 0, ly = 0, lz = 0;
-    double d = 0.0;
-    for (int c = 0; c < 2; ++c)
-      for (int b = 0; b < 2; ++b)
-        for (int a = 0; a < 2; ++a) {
-          const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
-          if (!fr(i, j, k)) continue;
-          const int cd = code[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i];
-          // free neighbours inside the same block
-          const int inside = fr(a ? i - 1 : i + 1, j, k) + fr(i, b ? j - 1 : j + 1, k) + fr(i, j, c ? k - 1 : k + 1);
-          d += (double)(cd - inside);
-          if (a == 1) lx += fr(i + 1, j, k);
-          if (b == 1) ly += fr(i, j + 1, k);
-          if (c == 1) lz += fr(i, j, k + 1);
-        }
-    wx[v] = (float)lx; wy[v] = (float)ly; wz[v] = (float)lz; diag[v] = d;
+  const int Kg = L.z0 + k - 1;
+  int lx = 0, ly = 0, lz = 0, d = 0;
+  for (int c = 0; c < 2; ++c) {
+    const int gz = 2 * Kg + c - g.z0 + 1;
+    if (gz < 1 || gz > g.nzl) continue;
+    for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < 2; ++a) {
+        const int ii = 2 * i + a, jj = 2 * j + b;
+        if (!fr(ii, jj, gz)) continue;
+        const int cd = code[(long long)gz * g.plane + (long long)jj * g.pitch + ii];
+        // free neighbours inside the same block stay off the coarse diagonal
+        const int inside = fr(a ? ii - 1 : ii + 1, jj, gz) + fr(ii, b ? jj - 1 : jj + 1, gz) + fr(ii, jj, c ? gz - 1 : gz + 1);
+        d += cd - inside;
+        if (a == 1) lx += fr(ii + 1, jj, gz);
+        if (b == 1) ly += fr(ii, jj + 1, gz);
+        if (c == 1) lz += fr(ii, jj, gz + 1);
+      }
   }
+  wx[m] = (float)lx; wy[m] = (float)ly; wz[m] = (float)lz; diag[m] = (float)d;
 }
 
-// level l+1 from level l (l >= 1)
-__global__ void __launch_bounds__(256) k_mg_build(LevelDev F, int cnx, int cny, int cnz, float* __restrict__ wx,
+// level l+1 from level l (both coarse); again only owned children contribute
+template <class W, class D>
+__global__ void __launch_bounds__(256) k_mg_build(LevelT<W, D> F, Dims L, int kfirst, float* __restrict__ wx,
                                                    float* __restrict__ wy, float* __restrict__ wz,
-                                                   double* __restrict__ diag) {
-  const long long n = (long long)cnx * cny * cnz;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-    const int I = (int)(v % cnx), J = (int)((v / cnx) % cny), K = (int)(v / ((long long)cnx * cny));
-    float lx = 0.f, ly = 0.f, lz = 0.f;
-    double d = 0.0;
-    for (int c = 0; c < 2; ++c)
-      for (int b = 0; b < 2; ++b)
-        for (int a = 0; a < 2; ++a) {
-          const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
-          if (i >= F.nx || j >= F.ny || k >= F.nz) continue;
-          const long long m = cidx(F, i, j, k);
-          d += F.diag[m];
-          // links towards +x/+y/+z: internal ones (a/b/c == 0) leave the diagonal twice,
-          // the ones on the block face become the coarse link
-          if (a == 0) d -= 2.0 * (double)F.wx[m]; else lx += F.wx[m];
-          if (b == 0) d -= 2.0 * (double)F.wy[m]; else ly += F.wy[m];
-          if (c == 0) d -= 2.0 * (double)F.wz[m]; else lz += F.wz[m];
-        }
-    wx[v] = lx; wy[v] = ly; wz[v] = lz; diag[v] = d;
+                                                   float* __restrict__ diag) {
+  OI_MG_CELL(L)
+  (void)sy;
+  const int Kg = L.z0 + k - 1;
+  float lx = 0.f, ly = 0.f, lz = 0.f, d = 0.f;
+  for (int c = 0; c < 2; ++c) {
+    const int kl = 2 * Kg + c - F.z0 + 1;
+    if (kl < 1 || kl > F.nzl) continue;
+    for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < 2; ++a) {
+        const int ii = 2 * i + a, jj = 2 * j + b;
+        if (ii >= F.nx || jj >= F.ny) continue;
+        const long long fm = (long long)ii + (long long)F.nx * jj + F.sz * kl;
+        d += (float)F.diag[fm];
+        // links towards +x/+y/+z: the ones inside the block (a/b/c == 0; weight 0 when the partner
+        // lies beyond the domain) leave the diagonal twice, the ones on the block face become the coarse link
+        if (a == 0) d -= 2.f * (float)F.wx[fm]; else lx += (float)F.wx[fm];
+        if (b == 0) d -= 2.f * (float)F.wy[fm]; else ly += (float)F.wy[fm];
+        if (c == 0) d -= 2.f * (float)F.wz[fm]; else lz += (float)F.wz[fm];
+      }
+  }
+  wx[m] = lx; wy[m] = ly; wz[m] = lz; diag[m] = d;
+}
+
+__global__ void __launch_bounds__(256) k_mg_compact(long long n, const float* __restrict__ wx, const float* __restrict__ wy,
+                                                     const float* __restrict__ wz, const float* __restrict__ diag,
+                                                     uint8_t* __restrict__ ox, uint8_t* __restrict__ oy,
+                                                     uint8_t* __restrict__ oz, uint16_t* __restrict__ od) {
+  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (long long)gridDim.x * blockDim.x) {
+    ox[m] = (uint8_t)wx[m]; oy[m] = (uint8_t)wy[m]; oz[m] = (uint8_t)wz[m]; od[m] = (uint16_t)diag[m];
   }
 }
-// (a child on the far side of an odd-sized level has no +neighbour inside the block: its link
-//  weight towards + is a face link of the coarse block or 0 at the domain edge -- both handled
-//  because weights at the domain edge are 0 by construction.)
 
 // ------------------------------ coarse-level cycle kernels ------------------------------
-__device__ __forceinline__ double capply(const LevelDev& L, int i, int j, int k, long long m, double vc,
-                                         double vxm, double vxp, double vym, double vyp, double vzm, double vzp) {
-  double s = 0.0;
-  if (i > 0) s += (double)L.wx[m - 1] * vxm;
-  if (i < L.nx - 1) s += (double)L.wx[m] * vxp;
-  if (j > 0) s += (double)L.wy[m - L.nx] * vym;
-  if (j < L.ny - 1) s += (double)L.wy[m] * vyp;
-  if (k > 0) s += (double)L.wz[m - (long long)L.nx * L.ny] * vzm;
-  if (k < L.nz - 1) s += (double)L.wz[m] * vzp;
-  return L.diag[m] * vc - s;
-}
-
-// Coarse-level kernels: one thread per cell, grid = (x chunks, ny, nz) so no index division.
-#define OI_MG_CELL                                                        \
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z; \
-  if (i >= L.nx) return;                                                  \
-  const long long sy = L.nx, sz = (long long)L.nx * L.ny;                 \
-  const long long m = (long long)i + sy * j + sz * k;
-
-// x = w b / D (first Jacobi sweep from zero), r = b - A x
-__global__ void __launch_bounds__(256) k_mg_pre(LevelDev L, const double* __restrict__ b, double* __restrict__ x,
-                                                 double* __restrict__ r) {
-  OI_MG_CELL
-  auto xs = [&](long long mm) -> double { const double d = L.diag[mm]; return d > 0.0 ? kOmega * b[mm] / d : 0.0; };
-  double xc = 0.0, res = 0.0;
-  if (L.diag[m] > 0.0) {
-    xc = xs(m);
-    const double ax = capply(L, i, j, k, m, xc, i > 0 ? xs(m - 1) : 0.0, i < L.nx - 1 ? xs(m + 1) : 0.0,
-                             j > 0 ? xs(m - sy) : 0.0, j < L.ny - 1 ? xs(m + sy) : 0.0, k > 0 ? xs(m - sz) : 0.0,
-                             k < L.nz - 1 ? xs(m + sz) : 0.0);
-    res = b[m] - ax;
-  }
-  x[m] = xc;
-  r[m] = res;
-}
-
-// residual of the current iterate (second visit of a W-cycle): r = b - A x
-__global__ void __launch_bounds__(256) k_mg_resid(LevelDev L, const double* __restrict__ b, const double* __restrict__ x,
-                                                   double* __restrict__ r) {
-  OI_MG_CELL
-  double res = 0.0;
-  if (L.diag[m] > 0.0) {
-    const double ax = capply(L, i, j, k, m, x[m], i > 0 ? x[m - 1] : 0.0, i < L.nx - 1 ? x[m + 1] : 0.0,
-                             j > 0 ? x[m - sy] : 0.0, j < L.ny - 1 ? x[m + sy] : 0.0, k > 0 ? x[m - sz] : 0.0,
-                             k < L.nz - 1 ? x[m + sz] : 0.0);
-    res = b[m] - ax;
+// r = b - A (w b / D)   (first Jacobi sweep from zero is never stored; the post-smoother recomputes it)
+template <class W, class D>
+__global__ void __launch_bounds__(256) k_mg_pre(LevelT<W, D> L, int kfirst, const float* __restrict__ b,
+                                                 float* __restrict__ r) {
+  OI_MG_CELL(L)
+  const float d = (float)L.diag[m];
+  float res = 0.f;
+  if (d > 0.f) {
+    auto xs = [&](long long mm) -> float { const float dd = (float)L.diag[mm]; return dd > 0.f ? kOmega * b[mm] * rcp(dd) : 0.f; };
+    const float s = offdiag(L, m, xs(m - 1), xs(m + 1), xs(m - sy), xs(m + sy), xs(m - sz), xs(m + sz));
+    res = b[m] - (d * xs(m) - s);
   }
   r[m] = res;
 }
 
-// y += x (correction of the second W-cycle visit)
-__global__ void __launch_bounds__(256) k_mg_add(long long n, double* __restrict__ y, const double* __restrict__ x) {
-  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (long long)gridDim.x * blockDim.x) y[m] += x[m];
+// residual of a finished visit (the right-hand side of the second W-cycle visit): r = b - A x
+template <class W, class D>
+__global__ void __launch_bounds__(256) k_mg_resid(LevelT<W, D> L, int kfirst, const float* __restrict__ b,
+                                                   const float* __restrict__ x, float* __restrict__ r) {
+  OI_MG_CELL(L)
+  const float d = (float)L.diag[m];
+  float res = 0.f;
+  if (d > 0.f) res = b[m] - (d * x[m] - offdiag(L, m, x[m - 1], x[m + 1], x[m - sy], x[m + sy], x[m - sz], x[m + sz]));
+  r[m] = res;
 }
 
-// coarse right-hand side = P^T r (sum over the 2x2x2 children); L describes the COARSE level
-__global__ void __launch_bounds__(256) k_mg_restrict(int fnx, int fny, int fnz, const double* __restrict__ r, LevelDev L,
-                                                      double* __restrict__ bc) {
-  OI_MG_CELL
-  double s = 0.0;
-  for (int c = 0; c < 2; ++c)
+// coarse right-hand side = P^T r (sum over the owned children); L is the COARSE level
+__global__ void __launch_bounds__(256) k_mg_restrict(Dims F, const float* __restrict__ r, Dims L, int kfirst,
+                                                      float* __restrict__ bc) {
+  OI_MG_CELL(L)
+  (void)sy;
+  const int Kg = L.z0 + k - 1;
+  float s = 0.f;
+  for (int c = 0; c < 2; ++c) {
+    const int kl = 2 * Kg + c - F.z0 + 1;
+    if (kl < 1 || kl > F.nzl) continue;
     for (int bb = 0; bb < 2; ++bb) {
-      const int fj = 2 * j + bb, fk = 2 * k + c;
-      if (fj >= fny || fk >= fnz) continue;
-      const long long row = (long long)fnx * ((long long)fj + (long long)fny * fk);
+      const int fj = 2 * j + bb;
+      if (fj >= F.ny) continue;
+      const long long row = F.sz * kl + (long long)F.nx * fj;
       s += r[row + 2 * i];
-      if (2 * i + 1 < fnx) s += r[row + 2 * i + 1];
+      if (2 * i + 1 < F.nx) s += r[row + 2 * i + 1];
     }
+  }
   bc[m] = s;
 }
 
-// x_out = x2 + w (b - A x2) / D with x2 = x + kScale * P xc   (prolongation + post-smoothing)
-__global__ void __launch_bounds__(256) k_mg_post(LevelDev L, const double* __restrict__ b, const double* __restrict__ x,
-                                                  const double* __restrict__ xc, int cnx, int cny,
-                                                  double* __restrict__ xout) {
-  OI_MG_CELL
-  auto x2 = [&](int ii, int jj, int kk) -> double {
-    const long long mm = cidx(L, ii, jj, kk);
-    if (!(L.diag[mm] > 0.0)) return 0.0;
-    return x[mm] + kScale * xc[(long long)(ii >> 1) + (long long)cnx * ((long long)(jj >> 1) + (long long)cny * (kk >> 1))];
-  };
-  double out = 0.0;
-  const double d = L.diag[m];
-  if (d > 0.0) {
-    const double c = x2(i, j, k);
-    const double ax = capply(L, i, j, k, m, c, i > 0 ? x2(i - 1, j, k) : 0.0, i < L.nx - 1 ? x2(i + 1, j, k) : 0.0,
-                             j > 0 ? x2(i, j - 1, k) : 0.0, j < L.ny - 1 ? x2(i, j + 1, k) : 0.0,
-                             k > 0 ? x2(i, j, k - 1) : 0.0, k < L.nz - 1 ? x2(i, j, k + 1) : 0.0);
-    out = c + kOmega * (b[m] - ax) / d;
+__global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const double* __restrict__ r1, Dims L, int kfirst,
+                                                           float* __restrict__ bc) {
+  OI_MG_CELL(L)
+  (void)sy;
+  const int Kg = L.z0 + k - 1;
+  double s = 0.0;
+  for (int c = 0; c < 2; ++c) {
+    const int gz = 2 * Kg + c - g.z0 + 1;
+    if (gz < 1 || gz > g.nzl) continue;
+    for (int bb = 0; bb < 2; ++bb) {
+      const int fj = 2 * j + bb;
+      if (fj >= g.ny) continue;
+      const long long row = (long long)gz * g.plane + (long long)fj * g.pitch;
+      s += r1[row + 2 * i];
+      if (2 * i + 1 < g.nx) s += r1[row + 2 * i + 1];
+    }
   }
-  xout[m] = out;
+  bc[m] = (float)s;
+}
+
+// out = x2 + w (b - A x2) / D with x2 = w b / D + kScale * P (xc + xc2)   (prolongation + post-smoothing)
+template <class W, class D>
+__global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, const float* __restrict__ b,
+                                                  const float* __restrict__ xc, const float* __restrict__ xc2, Dims C,
+                                                  float scale, float* __restrict__ out) {
+  OI_MG_CELL(L)
+  auto x2 = [&](long long mm, int ii, int jj, int kk) -> float {
+    const float dd = (float)L.diag[mm];
+    if (!(dd > 0.f)) return 0.f;
+    const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * (((L.z0 + kk - 1) >> 1) - C.z0 + 1);
+    float c = xc[cm];
+    if (xc2) c += xc2[cm];
+    return kOmega * b[mm] * rcp(dd) + scale * c;
+  };
+  float o = 0.f;
+  const float d = (float)L.diag[m];
+  if (d > 0.f) {
+    const float c = x2(m, i, j, k);
+    const float s = offdiag(L, m, i > 0 ? x2(m - 1, i - 1, j, k) : 0.f, i < L.nx - 1 ? x2(m + 1, i + 1, j, k) : 0.f,
+                            j > 0 ? x2(m - sy, i, j - 1, k) : 0.f, j < L.ny - 1 ? x2(m + sy, i, j + 1, k) : 0.f,
+                            x2(m - sz, i, j, k - 1), x2(m + sz, i, j, k + 1));
+    o = c + kOmega * (b[m] - (d * c - s)) * rcp(d);
+  }
+  out[m] = o;
 }
 
 // coarsest level: x_out = x_in + w (b - A x_in) / D   (first = 1: x_in = 0)
-__global__ void __launch_bounds__(256) k_mg_jacobi(LevelDev L, const double* __restrict__ b, const double* __restrict__ xin,
-                                                    double* __restrict__ xout, int first) {
-  OI_MG_CELL
-  const double d = L.diag[m];
-  double out = 0.0;
-  if (d > 0.0) {
+template <class W, class D>
+__global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, const float* __restrict__ b,
+                                                    const float* __restrict__ xin, float* __restrict__ xout, int first) {
+  OI_MG_CELL(L)
+  const float d = (float)L.diag[m];
+  float o = 0.f;
+  if (d > 0.f) {
     if (first) {
-      out = kOmega * b[m] / d;
+      o = kOmega * b[m] * rcp(d);
     } else {
-      const double c = xin[m];
-      const double ax = capply(L, i, j, k, m, c, i > 0 ? xin[m - 1] : 0.0, i < L.nx - 1 ? xin[m + 1] : 0.0,
-                               j > 0 ? xin[m - sy] : 0.0, j < L.ny - 1 ? xin[m + sy] : 0.0, k > 0 ? xin[m - sz] : 0.0,
-                               k < L.nz - 1 ? xin[m + sz] : 0.0);
-      out = c + kOmega * (b[m] - ax) / d;
+      const float c = xin[m];
+      o = c + kOmega * (b[m] - (d * c - offdiag(L, m, xin[m - 1], xin[m + 1], xin[m - sy], xin[m + sy], xin[m - sz], xin[m + sz]))) * rcp(d);
     }
   }
-  xout[m] = out;
+  xout[m] = o;
 }
 
-// ------------------------------ fine-level cycle kernels ------------------------------
-// fine vectors live in the pitched / ghost-plane layout; b vanishes on non-free cells.
-// r1 = b - A (w b / code)
+// ------------------------------ plain fine-level kernels (cross-check of the tiled ones) ------------------------------
+// fine vectors live in the pitched / ghost-plane layout; b vanishes on non-free cells and its
+// ghost planes hold the neighbours' values.   r1 = b - A (w b / code)
 __global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
                                                       double* __restrict__ r1, const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->done) return;
   const long long n = (long long)g.nzl * g.ny * g.nx;
-  auto xs = [&](long long e) -> double { const unsigned c = code[e]; return c ? kOmega * b[e] / (double)c : 0.0; };
+  const double w = (double)kOmega;
+  auto xs = [&](long long e) -> double { const unsigned c = code[e]; return c ? w * b[e] / (double)c : 0.0; };
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
     const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
@@ -248,34 +296,20 @@ __global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __re
   }
 }
 
-__global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const double* __restrict__ r1, int cnx, int cny, int cnz,
-                                                           double* __restrict__ bc) {
-  const long long n = (long long)cnx * cny * cnz;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-    const int I = (int)(v % cnx), J = (int)((v / cnx) % cny), K = (int)(v / ((long long)cnx * cny));
-    double s = 0.0;
-    for (int c = 0; c < 2; ++c)
-      for (int b = 0; b < 2; ++b)
-        for (int a = 0; a < 2; ++a) {
-          const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + c;
-          if (i < g.nx && j < g.ny && k < g.nzl) s += r1[(long long)(k + 1) * g.plane + (long long)j * g.pitch + i];
-        }
-    bc[v] = s;
-  }
-}
-
-// z = x2 + w (b - A x2) / code,  x2 = w b / code + kScale * P xc
+// z = x2 + w (b - A x2) / code,  x2 = w b / code + kScale * P (xc + xc2)
 __global__ void __launch_bounds__(256) k_mg_fine_post(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
-                                                       const double* __restrict__ xc, int cnx, int cny,
-                                                       double* __restrict__ z, const Ctrl* __restrict__ ctrl) {
+                                                       MgCoarse C, double sc, double* __restrict__ z, const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->done) return;
   const long long n = (long long)g.nzl * g.ny * g.nx;
-  auto x2 = [&](int i, int j, int gz) -> double {  // gz: plane incl. ghost offset; ghost planes hold code 0
+  const double w = (double)kOmega;
+  auto x2 = [&](int i, int j, int gz) -> double {  // gz: plane incl. ghost offset
     const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    return kOmega * b[e] / (double)c +
-           kScale * xc[(long long)(i >> 1) + (long long)cnx * ((long long)(j >> 1) + (long long)cny * ((gz - 1) >> 1))];
+    const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+    float cv = C.xc[cm];
+    if (C.xc2) cv += C.xc2[cm];
+    return w * b[e] / (double)c + sc * (double)cv;
   };
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
@@ -286,8 +320,8 @@ __global__ void __launch_bounds__(256) k_mg_fine_post(Geom g, const uint8_t* __r
       const double xc0 = x2(i, j, gz);
       const double s = ((((i > 0 ? x2(i - 1, j, gz) : 0.0) + (i < g.nx - 1 ? x2(i + 1, j, gz) : 0.0)) +
                          (j > 0 ? x2(i, j - 1, gz) : 0.0)) + (j < g.ny - 1 ? x2(i, j + 1, gz) : 0.0)) +
-                       (gz > 1 ? x2(i, j, gz - 1) : 0.0) + (gz < g.nzl ? x2(i, j, gz + 1) : 0.0);
-      out = xc0 + kOmega * (b[e] - ((double)c * xc0 - s)) / (double)c;
+                       x2(i, j, gz - 1) + x2(i, j, gz + 1);
+      out = xc0 + w * (b[e] - ((double)c * xc0 - s)) / (double)c;
     }
     z[e] = out;
   }
@@ -312,31 +346,95 @@ __global__ void __launch_bounds__(256) k_mg_dot(Geom g, const double* __restrict
   if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+inline int nblk(long long items, int cap = 8192) {
+  long long b = (items + 255) / 256;
+  return (int)std::max<long long>(1, std::min<long long>(b, cap));
+}
+
 }  // namespace
 
-int launch_dot(const Geom& g, const double* a, const double* b, double* partials, hipStream_t s);
-
 struct MgLevelHost {
-  int nx = 0, ny = 0, nz = 0;
-  long long n = 0;
-  float *wx = nullptr, *wy = nullptr, *wz = nullptr;
-  double *diag = nullptr, *b = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr, *xs = nullptr;
-  LevelDev dev() const { return LevelDev{nx, ny, nz, wx, wy, wz, diag}; }
+  Dims d{};
+  int nz = 0;               // global plane count of the level
+  bool replicated = false;  // every rank holds (and solves) the whole level
+  bool compact = false;     // byte weights / 16-bit diagonal
+  long long n = 0;          // cells incl. the two ghost planes
+  void *wx = nullptr, *wy = nullptr, *wz = nullptr, *diag = nullptr;
+  float *b = nullptr, *b2 = nullptr, *r = nullptr, *x2 = nullptr, *xs = nullptr;
+  template <class W, class D>
+  LevelT<W, D> dev() const {
+    LevelT<W, D> L;
+    static_cast<Dims&>(L) = d;
+    L.wx = (const W*)wx; L.wy = (const W*)wy; L.wz = (const W*)wz; L.diag = (const D*)diag;
+    return L;
+  }
+  int bx() const { return d.nx >= 256 ? 256 : (d.nx >= 128 ? 128 : 64); }
+  int blocks(int nplanes) const { return ((d.nx + bx() - 1) / bx()) * d.ny * nplanes; }
 };
 
 struct MgHierarchy {
   std::vector<MgLevelHost> levels;  // levels[0] = first COARSE level
+  oi_comm* comm = nullptr;          // neighbours of the slab partition (null: whole volume)
   size_t bytes = 0;
+  unsigned wmask = kWCycleMask;
+  float scale = kScale;
+  bool failed = false;
 };
 
 void mg_destroy(MgHierarchy* mg) {
   if (!mg) return;
   for (auto& L : mg->levels) {
-    void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.x, L.x2, L.r, L.xs};
+    void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.b2, L.r, L.x2, L.xs};
     for (void* q : p)
       if (q) (void)hipFree(q);
   }
   delete mg;
+}
+
+// typed launch of a level kernel: KERN<uint8_t, uint16_t> on the compact levels, <float, float> below
+#define OI_MG_LAUNCH(KERN, LV, NPLANES, S, ...)                                                                      \
+  do {                                                                                                               \
+    if ((LV).blocks(NPLANES) > 0) {                                                                                  \
+      if ((LV).compact)                                                                                              \
+        hipLaunchKernelGGL((KERN<uint8_t, uint16_t>), dim3((LV).blocks(NPLANES)), dim3((LV).bx()), 0, S,             \
+                           (LV).dev<uint8_t, uint16_t>(), __VA_ARGS__);                                              \
+      else                                                                                                           \
+        hipLaunchKernelGGL((KERN<float, float>), dim3((LV).blocks(NPLANES)), dim3((LV).bx()), 0, S,                   \
+                           (LV).dev<float, float>(), __VA_ARGS__);                                                   \
+    }                                                                                                                \
+  } while (0)
+
+// ghost planes of a per-level array from the z-neighbours (no-op without neighbours / on replicated levels)
+static bool ghost_exchange(MgHierarchy* mg, const MgLevelHost& L, void* base, size_t elem, hipStream_t s) {
+  if (!mg->comm || L.replicated) return true;
+  char* p = (char*)base;
+  const size_t pb = (size_t)L.d.sz * elem;
+  if (mg->comm->exchange(p + pb, p, p + pb * (size_t)L.d.nzl, p + pb * (size_t)(L.d.nzl + 1), pb, s) != OI_OK) {
+    mg->failed = true;
+    return false;
+  }
+  return true;
+}
+
+// coarse planes (local indices) that receive contributions from the owned planes [z0, z0 + nzl) of the parent
+static void child_span(const MgLevelHost& C, int pz0, int pnzl, int* kfirst, int* nplanes) {
+  const int ka = pz0 >> 1, kb = (pz0 + pnzl - 1) >> 1;  // global
+  *kfirst = ka - C.d.z0 + 1;
+  *nplanes = kb - ka + 1;
+}
+
+// after the owned contributions of a right-hand side / operator array are in place: sum across ranks
+// (first replicated level) or fetch the ghost planes (slab level)
+static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool parent_replicated, float* a, hipStream_t s) {
+  if (!mg->comm || parent_replicated) return true;
+  if (C.replicated) {
+    if (mg->comm->allreduce_sum_f32(a + C.d.sz, (size_t)C.d.sz * C.d.nzl, s) != OI_OK) {
+      mg->failed = true;
+      return false;
+    }
+    return true;
+  }
+  return ghost_exchange(mg, C, a, sizeof(float), s);
 }
 
 #define MGC(call)                                                            \
@@ -349,99 +447,173 @@ void mg_destroy(MgHierarchy* mg) {
     }                                                                        \
   } while (0)
 
-MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, hipStream_t s, size_t* bytes_out) {
+MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, hipStream_t s, size_t* bytes_out) {
   MgHierarchy* mg = new MgHierarchy();
-  int fx = g.nx, fy = g.ny, fz = g.nzl;  // the hierarchy covers the owned planes of this slab
+  mg->comm = (comm && comm->size > 1) ? comm : nullptr;
+  int pnx = g.nx, pny = g.ny, pnz = g.nz, pz0 = g.z0, pnzl = g.nzl;
+  bool prep = false;  // parent replicated?
+  long long replicate_cells = kReplicateCells;
+  if (const char* e = getenv("OI_MG_REPLICATE_CELLS")) replicate_cells = atoll(e);  // tests: distribute small levels too
+  if (const char* e = getenv("OI_MG_WMASK")) mg->wmask = (unsigned)atoi(e);            // experiments with the cycle shape
+  if (const char* e = getenv("OI_MG_SCALE")) mg->scale = (float)atof(e);
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
-    L.nx = (fx + 1) / 2; L.ny = (fy + 1) / 2; L.nz = (fz + 1) / 2;
-    L.n = (long long)L.nx * L.ny * L.nz;
-    MGC(hipMalloc((void**)&L.wx, sizeof(float) * L.n));
-    MGC(hipMalloc((void**)&L.wy, sizeof(float) * L.n));
-    MGC(hipMalloc((void**)&L.wz, sizeof(float) * L.n));
-    MGC(hipMalloc((void**)&L.diag, sizeof(double) * L.n));
-    MGC(hipMalloc((void**)&L.b, sizeof(double) * L.n));
-    MGC(hipMalloc((void**)&L.x, sizeof(double) * L.n));
-    MGC(hipMalloc((void**)&L.x2, sizeof(double) * L.n));
-    MGC(hipMalloc((void**)&L.r, sizeof(double) * L.n));
-    MGC(hipMalloc((void**)&L.xs, sizeof(double) * L.n));
-    mg->bytes += (size_t)L.n * (3 * sizeof(float) + 6 * sizeof(double));
-    if (l == 0) {
-      hipLaunchKernelGGL(k_mg_build1, dim3(nblk(L.n)), dim3(256), 0, s, g, code, L.nx, L.ny, L.nz, L.wx, L.wy, L.wz, L.diag);
+    L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
+    L.d.sz = (long long)L.d.nx * L.d.ny;
+    L.compact = l < kCompactLevels;
+    // keep the slab partition while every rank's slab starts on an even plane, holds at least two
+    // planes and the level is worth distributing; otherwise this and all deeper levels are replicated
+    L.replicated = prep;
+    if (mg->comm && !prep) {
+      int viol = ((pz0 & 1) || pnzl < 2 || L.d.sz * L.nz <= replicate_cells) ? 1 : 0;
+      if (mg->comm->allreduce_max_i32_host(&viol, 1, s) != OI_OK) { mg_destroy(mg); return nullptr; }
+      L.replicated = viol != 0;
+    }
+    if (mg->comm && !L.replicated) {
+      L.d.z0 = pz0 >> 1;
+      L.d.nzl = ((pz0 + pnzl + 1) >> 1) - L.d.z0;
     } else {
-      hipLaunchKernelGGL(k_mg_build, dim3(nblk(L.n)), dim3(256), 0, s, mg->levels.back().dev(), L.nx, L.ny, L.nz, L.wx,
-                         L.wy, L.wz, L.diag);
+      L.d.z0 = 0;
+      L.d.nzl = L.nz;
+    }
+    L.n = L.d.sz * (L.d.nzl + 2);
+    const size_t wb = L.compact ? 1 : 4, db = L.compact ? 2 : 4;
+    MGC(hipMalloc(&L.wx, wb * L.n)); MGC(hipMalloc(&L.wy, wb * L.n)); MGC(hipMalloc(&L.wz, wb * L.n));
+    MGC(hipMalloc(&L.diag, db * L.n));
+    float** vecs[] = {&L.b, &L.b2, &L.r, &L.x2, &L.xs};
+    for (float** v : vecs) {
+      MGC(hipMalloc((void**)v, sizeof(float) * L.n));
+      MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
+    }
+    mg->bytes += (size_t)L.n * (3 * wb + db + 5 * sizeof(float));
+    // operator: owned contributions into float arrays, summed / exchanged, then (compact levels) narrowed
+    float* t[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (L.compact) {
+      for (auto& p : t) MGC(hipMalloc((void**)&p, sizeof(float) * L.n));
+    } else {
+      t[0] = (float*)L.wx; t[1] = (float*)L.wy; t[2] = (float*)L.wz; t[3] = (float*)L.diag;
+    }
+    for (auto p : t) MGC(hipMemsetAsync(p, 0, sizeof(float) * L.n, s));
+    int kfirst = 1, nplanes = L.d.nzl;
+    if (L.replicated && !prep && mg->comm) child_span(L, pz0, pnzl, &kfirst, &nplanes);
+    if (L.blocks(nplanes) > 0) {
+      if (l == 0) {
+        hipLaunchKernelGGL(k_mg_build1, dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s, g, code, L.d, kfirst, t[0], t[1], t[2], t[3]);
+      } else {
+        const MgLevelHost& P = mg->levels.back();
+        if (P.compact)
+          hipLaunchKernelGGL((k_mg_build<uint8_t, uint16_t>), dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s,
+                             P.dev<uint8_t, uint16_t>(), L.d, kfirst, t[0], t[1], t[2], t[3]);
+        else
+          hipLaunchKernelGGL((k_mg_build<float, float>), dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s, P.dev<float, float>(),
+                             L.d, kfirst, t[0], t[1], t[2], t[3]);
+      }
+    }
+    bool ok = true;
+    if (L.replicated) {
+      for (auto p : t) ok = ok && finish_child_array(mg, L, prep, p, s);
+    } else {  // the cycle reads the diagonal and the +z weights of the ghost planes
+      ok = finish_child_array(mg, L, prep, t[2], s) && finish_child_array(mg, L, prep, t[3], s);
+    }
+    if (L.compact) {
+      if (ok)
+        hipLaunchKernelGGL(k_mg_compact, dim3(nblk(L.n)), dim3(256), 0, s, L.n, t[0], t[1], t[2], t[3], (uint8_t*)L.wx,
+                           (uint8_t*)L.wy, (uint8_t*)L.wz, (uint16_t*)L.diag);
+      (void)hipStreamSynchronize(s);
+      for (auto p : t) (void)hipFree(p);
     }
     mg->levels.push_back(L);
-    fx = L.nx; fy = L.ny; fz = L.nz;
-    if (L.n <= kCoarsestCells || (L.nx == 1 && L.ny == 1 && L.nz == 1)) break;
+    if (!ok) { mg_destroy(mg); return nullptr; }
+    pnx = L.d.nx; pny = L.d.ny; pnz = L.nz; pz0 = L.d.z0; pnzl = L.d.nzl; prep = L.replicated;
+    const long long cells = L.d.sz * L.nz;
+    if (cells <= kCoarsestCells || (L.d.nx == 1 && L.d.ny == 1 && L.nz == 1)) break;
   }
   MGC(hipStreamSynchronize(s));
   if (bytes_out) *bytes_out = mg->bytes;
   return mg;
 }
 
-// z = M^-1 r on the fine level; `scratch` is a fine vector the caller does not need meanwhile
-static inline int bx_for(int nx) { return nx >= 256 ? 256 : (nx >= 128 ? 128 : 64); }
-static inline dim3 grid_for(const MgLevelHost& L) { return dim3((L.nx + bx_for(L.nx) - 1) / bx_for(L.nx), L.ny, L.nz); }
-
-// Approximate solve of level l: right-hand side in Ls[l].b, result in Ls[l].x2.
-// Levels above kWCycleLevels are visited twice per parent visit (W-cycle: the second visit
-// solves for the residual of the first), deeper levels once; every step is a fixed symmetric
-// linear map, so the whole cycle stays a valid CG preconditioner.
-static void coarse_cycle(MgHierarchy* mg, int l, hipStream_t s) {
-  auto& Ls = mg->levels;
-  const int nl = (int)Ls.size();
-  MgLevelHost& L = Ls[l];
-  const dim3 gr = grid_for(L), bl(bx_for(L.nx));
-  if (l == nl - 1) {  // coarsest: a fixed number of damped-Jacobi sweeps
-    double *in = L.x, *out = L.x2;
-    for (int it = 0; it < kCoarsestSweeps; ++it) {
-      hipLaunchKernelGGL(k_mg_jacobi, gr, bl, 0, s, L.dev(), L.b, in, out, it == 0 ? 1 : 0);
-      std::swap(in, out);
-    }
-    if (in != L.x2) (void)hipMemcpyAsync(L.x2, in, sizeof(double) * L.n, hipMemcpyDeviceToDevice, s);
-    return;
+// right-hand side of child C from the residual of its parent (fine parent: r1 in the solver layout)
+static bool restrict_to(MgHierarchy* mg, const Geom* g, const double* r1, const MgLevelHost* P, MgLevelHost& C, float* bc,
+                        hipStream_t s) {
+  const bool prep = P ? P->replicated : false;
+  const int pz0 = P ? P->d.z0 : g->z0, pnzl = P ? P->d.nzl : g->nzl;
+  int kfirst = 1, nplanes = C.d.nzl;
+  if (C.replicated && !prep && mg->comm) {
+    (void)hipMemsetAsync(bc, 0, sizeof(float) * C.n, s);
+    child_span(C, pz0, pnzl, &kfirst, &nplanes);
   }
-  MgLevelHost& C = Ls[l + 1];
-  const dim3 grc = grid_for(C), blc(bx_for(C.nx));
-  hipLaunchKernelGGL(k_mg_pre, gr, bl, 0, s, L.dev(), L.b, L.x, L.r);
-  hipLaunchKernelGGL(k_mg_restrict, grc, blc, 0, s, L.nx, L.ny, L.nz, L.r, C.dev(), C.b);
-  coarse_cycle(mg, l + 1, s);
-  if (l + 1 < kWCycleLevels) {  // second visit of the child level
-    hipLaunchKernelGGL(k_mg_resid, grc, blc, 0, s, C.dev(), C.b, C.x2, C.r);
-    (void)hipMemcpyAsync(C.xs, C.x2, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
-    (void)hipMemcpyAsync(C.b, C.r, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
-    coarse_cycle(mg, l + 1, s);
-    hipLaunchKernelGGL(k_mg_add, dim3(nblk(C.n, 2048)), dim3(256), 0, s, C.n, C.x2, C.xs);
+  if (C.blocks(nplanes) > 0) {
+    if (P) hipLaunchKernelGGL(k_mg_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, P->d, P->r, C.d, kfirst, bc);
+    else hipLaunchKernelGGL(k_mg_fine_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, *g, r1, C.d, kfirst, bc);
   }
-  hipLaunchKernelGGL(k_mg_post, gr, bl, 0, s, L.dev(), L.b, L.x, C.x2, C.nx, C.ny, L.x2);
+  return finish_child_array(mg, C, prep, bc, s);
 }
 
+// Approximate solve of level l: right-hand side `rhs` (ghost planes valid), result in `out` (ghost
+// planes valid on return).  Levels in kWCycleMask are visited twice per parent visit (the
+// second visit solves for the residual of the first), the others once.
+static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, hipStream_t s) {
+  auto& Ls = mg->levels;
+  MgLevelHost& L = Ls[l];
+  const int kfirst = 1;
+  if (l == (int)Ls.size() - 1) {  // coarsest: a fixed number of damped-Jacobi sweeps, the last one lands in `out`
+    for (int it = 1; it <= kCoarsestSweeps; ++it) {
+      const bool to_out = ((kCoarsestSweeps - it) & 1) == 0;
+      float* dst = to_out ? out : L.r;
+      const float* src = to_out ? L.r : out;
+      OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, src, dst, it == 1 ? 1 : 0);
+      if (!ghost_exchange(mg, L, dst, sizeof(float), s)) return false;
+    }
+    return true;
+  }
+  MgLevelHost& C = Ls[l + 1];
+  OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
+  if (!restrict_to(mg, nullptr, nullptr, &L, C, C.b, s)) return false;
+  if (!coarse_cycle(mg, l + 1, C.b, C.x2, s)) return false;
+  const float* second = nullptr;
+  if ((mg->wmask >> (l + 1)) & 1u) {
+    OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, kfirst, C.b, C.x2, C.b2);
+    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s)) return false;
+    if (!coarse_cycle(mg, l + 1, C.b2, C.xs, s)) return false;
+    second = C.xs;
+  }
+  OI_MG_LAUNCH(k_mg_post, L, L.d.nzl, s, kfirst, rhs, C.x2, second, C.d, mg->scale, out);
+  return ghost_exchange(mg, L, out, sizeof(float), s);
+}
+
+// z = M^-1 r on the fine level; `scratch` is a fine vector the caller does not need meanwhile.
+// r's ghost planes must hold the neighbours' values.  Returns the number of z.r partials, -1 on a
+// transport failure.
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
               double* partials, const Ctrl* ctrl, int tiled, hipStream_t s) {
   auto& Ls = mg->levels;
   const long long nfine = (long long)g.nzl * g.ny * g.nx;
   MgLevelHost& C = Ls[0];
-  if (tiled) launch_mg_fine(1, g, code, r, nullptr, 0, 0, kOmega, kScale, scratch, partials, ctrl, s);
+  MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz};
+  if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, partials, ctrl, s);
   else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl);
-  hipLaunchKernelGGL(k_mg_fine_restrict, dim3(nblk(C.n)), dim3(256), 0, s, g, scratch, C.nx, C.ny, C.nz, C.b);
-  coarse_cycle(mg, 0, s);
-  if (kWCycleLevels > 0) {
-    const dim3 grc = grid_for(C), blc(bx_for(C.nx));
-    hipLaunchKernelGGL(k_mg_resid, grc, blc, 0, s, C.dev(), C.b, C.x2, C.r);
-    (void)hipMemcpyAsync(C.xs, C.x2, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
-    (void)hipMemcpyAsync(C.b, C.r, sizeof(double) * C.n, hipMemcpyDeviceToDevice, s);
-    coarse_cycle(mg, 0, s);
-    hipLaunchKernelGGL(k_mg_add, dim3(nblk(C.n, 2048)), dim3(256), 0, s, C.n, C.x2, C.xs);
+  if (!restrict_to(mg, &g, scratch, nullptr, C, C.b, s)) return -1;
+  if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
+  if (mg->wmask & 1u) {
+    OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, 1, C.b, C.x2, C.b2);
+    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s)) return -1;
+    if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
+    cref.xc2 = C.xs;
   }
   if (tiled)  // also leaves the per-block partial sums of z.r
-    return launch_mg_fine(2, g, code, r, C.x2, C.nx, C.ny, kOmega, kScale, z, partials, ctrl, s);
-  hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, C.x2, C.nx, C.ny, z, ctrl);
+    return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, partials, ctrl, s);
+  hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl);
   return launch_dot(g, r, z, partials, s);
 }
 
 int mg_levels(const MgHierarchy* mg) { return mg ? (int)mg->levels.size() + 1 : 0; }
+int mg_replicated_from(const MgHierarchy* mg) {
+  if (!mg) return -1;
+  for (size_t l = 0; l < mg->levels.size(); ++l)
+    if (mg->levels[l].replicated) return (int)l + 1;
+  return -1;
+}
 
 int launch_dot(const Geom& g, const double* a, const double* b, double* partials, hipStream_t s) {
   const int blocks = nblk((long long)g.nzl * g.plane / 2, 2048);

@@ -75,6 +75,7 @@ struct oi_tort {
   double* rec = nullptr;                // its per-iteration scalar records
   double* z = nullptr;                  // preconditioned residual of the multigrid variant
   oi::MgHierarchy* mg = nullptr;
+  int mg_tiled = 1;  // 0 (env OI_MG_PLAIN): plain fine-level kernels, kept as a cross-check
   void* p[2] = {nullptr, nullptr};  // search direction: fp64, or fp32 storage when p_f32
   bool p_f32 = false;
   size_t p_elem = sizeof(double);
@@ -355,10 +356,13 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     OIC(dmalloc(h, &h->z, (size_t)g.nvec));
     HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
     size_t mg_bytes = 0;
-    h->mg = mg_setup(g, h->code, s, &mg_bytes);
+    h->mg_tiled = getenv("OI_MG_PLAIN") ? 0 : 1;
+    h->mg = mg_setup(g, h->code, h->comm, s, &mg_bytes);
     if (!h->mg) return OI_HIP_ERROR;
     h->bytes_device += mg_bytes;
-    if (h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] multigrid hierarchy: %d levels, %.1f MB\n", mg_levels(h->mg), mg_bytes / 1e6);
+    if (h->opts.verbose > 1)
+      fprintf(stderr, "[openimpala_amd] multigrid hierarchy: %d levels (replicated from level %d), %.1f MB\n",
+              mg_levels(h->mg), mg_replicated_from(h->mg), mg_bytes / 1e6);
   }
   h->vectors_ready = true;
   h->st.t_setup_s = now_s() - t2;
@@ -395,8 +399,7 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->fused = o.kernel != OI_KERNEL_UNFUSED;
   h->cg1 = o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_AUTO;  // fastest variant is the default
   if (o.precond == OI_PRECOND_MG) {
-    // with neighbours every slab runs the cycle on its own planes (block-Jacobi across slabs, no
-    // exchange inside the cycle); only z's ghost planes travel, in place of r's
+    // with neighbours the hierarchy keeps the slab partition (see oi_mg.hip); r's and z's ghost planes travel
     if (o.kernel == OI_KERNEL_FUSED1) {
       oi::set_error("the multigrid preconditioner runs on the two-kernel or unfused iteration (kernel = auto | fused | unfused)");
       return OI_BAD_ARG;
@@ -503,7 +506,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
     { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
     // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
     OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
-    if (h->fused && !h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+    if (h->fused || h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
   }
   h->iters_issued = 0;
   h->iters_done = 0;
@@ -561,7 +564,8 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     void* p_out = h->p[k & 1];
     const double* zsrc = h->r;
     if (h->mg) {  // preconditioned residual from the multigrid V-cycle, and r.z into hist[k]
-      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, getenv("OI_MG_PLAIN") ? 0 : 1, s); }
+      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, s); }
+      if (nb < 0) return OI_RCCL_ERROR;
       OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
       OIC(exchange_planes(h, h->z, sizeof(double) * g.plane));
       zsrc = h->z;
@@ -574,11 +578,12 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     { PROF(K_UPDATE_R); nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
-    if (!h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+    OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
   } else if (h->mg) {
     // PCG with the multigrid V-cycle: z = M^-1 r, r.z, p = z + beta p, q = A p, x/r update
     double* p = (double*)h->p[0];
-    { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, getenv("OI_MG_PLAIN") ? 0 : 1, s); }
+    { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, s); }
+    if (nb < 0) return OI_RCCL_ERROR;
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
     if (k > 0) {
       PROF(K_UPDATE_P);
@@ -594,6 +599,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       nb = launch_update_xr(g, h->code, h->x, h->r, p, h->q, 0, h->hist, k, h->partials, h->ctrl, s);
     }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
+    OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
   } else {
     if (k > 0) {
       PROF(K_UPDATE_P);
