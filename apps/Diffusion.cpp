@@ -223,13 +223,20 @@ int main(int argc, char* argv[]) {
     int tverbose = verbose;
     in.query("tortuosity.verbose", tverbose);
     in.query("tortuosity.remspot_passes", opts.remspot_passes);
-    std::string precond = "jacobi", kernel = "auto";  // Jacobi costs no extra traffic in the default kernel
+    // default: the multigrid cycle (the role of SMG in the reference's FlexGMRES, tens of iterations);
+    // jacobi / none select the plain single-kernel CG iteration (O(10 N) iterations)
+    std::string precond = "mg", kernel = "auto";
     in.query("gpu.precond", precond);
     in.query("gpu.kernel", kernel);
-    opts.precond = lower(precond) == "jacobi" ? OI_PRECOND_JACOBI : OI_PRECOND_NONE;
+    const std::string pl = lower(precond);
+    if (pl == "mg" || pl == "multigrid") opts.precond = OI_PRECOND_MG;
+    else if (pl == "jacobi") opts.precond = OI_PRECOND_JACOBI;
+    else if (pl == "none") opts.precond = OI_PRECOND_NONE;
+    else throw std::runtime_error("gpu.precond must be mg, jacobi or none (got '" + precond + "')");
     const std::string kl = lower(kernel);
     opts.kernel = kl == "unfused" ? OI_KERNEL_UNFUSED
                   : (kl == "fused" ? OI_KERNEL_FUSED : (kl == "fused1" ? OI_KERNEL_FUSED1 : OI_KERNEL_AUTO));
+    if (opts.precond == OI_PRECOND_MG && opts.kernel == OI_KERNEL_FUSED1) opts.kernel = OI_KERNEL_AUTO;  // the cycle sits between the two kernels
     in.query("gpu.device", opts.device);
 
     if (verbose > 0) std::cout << "Calculating Volume Fraction for Phase ID: " << phase_id << "\n";

@@ -240,6 +240,10 @@ int oi_abi_version(void);
  * (RawReader.cpp:379-491), HDF5Reader::threshold (HDF5Reader.cpp:333-402). */
 oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
                        int* bits_per_sample);
+/* numbered single-slice files <base><index zero-padded to digits><suffix>, index = start_index ...
+ * start_index + num_files - 1: TiffReader::readFileSequence (TiffReader.H:117-123, TiffReader.cpp:85-88,209-285) */
+oi_status oi_read_tiff_sequence(const char* base_pattern, int num_files, int start_index, int digits, const char* suffix,
+                                double threshold, uint8_t** phase, int* nx, int* ny, int* nz, int* bits_per_sample);
 /* dtype: OI_RAW_* below, same numbering as the reference's RawDataType (RawReader.H:30-46) */
 enum {
   OI_RAW_UNKNOWN = 0, OI_RAW_UINT8 = 1, OI_RAW_INT8, OI_RAW_INT16_LE, OI_RAW_INT16_BE, OI_RAW_UINT16_LE, OI_RAW_UINT16_BE,

@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_raw oi_read_hdf5 oi_read_dat oi_free_host"
+    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_sequence oi_read_raw oi_read_hdf5 oi_read_dat oi_free_host"
 ).split()
 
 
@@ -158,6 +158,8 @@ def lib():
     L.oi_dev_download.argtypes = [vp, vp, C.c_size_t]
     L.oi_device_count.restype = i
     L.oi_read_tiff.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.oi_read_tiff_sequence.argtypes = [C.c_char_p, i, i, i, C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
+                                        C.POINTER(i)]
     L.oi_read_raw.argtypes = [C.c_char_p, i, i, i, i, d, pp]
     L.oi_read_hdf5.argtypes = [C.c_char_p, C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_dat.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
@@ -549,18 +551,26 @@ class EffectiveDiffusivityMI355:
 # readers (src/io)
 # ------------------------------------------------------------------------------------------
 class TiffReader:
-    """OpenImpala::TiffReader for single stack files (src/io/TiffReader.{H,cpp})."""
+    """OpenImpala::TiffReader (src/io/TiffReader.{H,cpp}): a stack file, `TiffReader(filename)`, or a
+    numbered sequence of single-slice files, `TiffReader(base_pattern, num_files, start_index, digits,
+    suffix)` (TiffReader.H:60-80)."""
 
-    def __init__(self, filename):
+    def __init__(self, filename, num_files=None, start_index=0, digits=1, suffix=".tif"):
         self.filename = filename
+        self.sequence = None if num_files is None else (int(num_files), int(start_index), int(digits), suffix)
         self._meta = None
 
     def threshold(self, raw_threshold=0.5):
         """-> uint8 (nz, ny, nx): 1 where voxel > threshold else 0 (TiffReader.cpp:449-455)."""
         p = C.c_void_p()
         nx, ny, nz, bps = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        _check(lib().oi_read_tiff(self.filename.encode(), raw_threshold, C.byref(p), C.byref(nx), C.byref(ny),
-                                  C.byref(nz), C.byref(bps)))
+        if self.sequence is None:
+            _check(lib().oi_read_tiff(self.filename.encode(), raw_threshold, C.byref(p), C.byref(nx), C.byref(ny),
+                                      C.byref(nz), C.byref(bps)))
+        else:
+            nf, si, dg, sfx = self.sequence
+            _check(lib().oi_read_tiff_sequence(self.filename.encode(), nf, si, dg, sfx.encode(), raw_threshold, C.byref(p),
+                                               C.byref(nx), C.byref(ny), C.byref(nz), C.byref(bps)))
         try:
             n = nx.value * ny.value * nz.value
             out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()

@@ -3,12 +3,16 @@
 //
 // Restates the behaviour of the reference readers without libtiff:
 //   TiffReader  (src/io/TiffReader.cpp:139-202 metadata, :289-444 decode): multi-directory
-//               stacks, strips or tiles, 1/8/16/32/64 bits per sample, UINT/INT/IEEEFP,
-//               1 sample per pixel, contiguous planar config; 1-bit data honours FILLORDER
-//               and ignores PHOTOMETRIC; voxel > threshold -> 1 else 0.
-//               Supported encodings here: uncompressed and PackBits (classic TIFF, both
-//               byte orders); anything else is reported, never guessed.
+//               stacks and numbered file sequences (:85-88, :209-285), strips or tiles,
+//               1/8/16/32/64 bits per sample, UINT/INT/IEEEFP, 1 sample per pixel, contiguous
+//               planar config; 1-bit data honours FILLORDER and ignores PHOTOMETRIC;
+//               voxel > threshold -> 1 else 0.
+//               Encodings decoded here (what libtiff decodes for the reference): none, LZW (5),
+//               Deflate (8 / 32946, zlib), PackBits (32773), horizontal predictor (317 = 2);
+//               classic TIFF and BigTIFF, both byte orders.  Anything else is reported, never guessed.
 //   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
+#include <zlib.h>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -27,10 +31,14 @@ namespace {
 struct File {
   std::vector<uint8_t> d;
   bool le = true;
+  bool big = false;  // BigTIFF (magic 43): 8-byte offsets, 20-byte directory entries
   uint16_t u16(size_t o) const { return le ? (uint16_t)(d[o] | d[o + 1] << 8) : (uint16_t)(d[o] << 8 | d[o + 1]); }
   uint32_t u32(size_t o) const {
     return le ? (uint32_t)d[o] | (uint32_t)d[o + 1] << 8 | (uint32_t)d[o + 2] << 16 | (uint32_t)d[o + 3] << 24
               : (uint32_t)d[o] << 24 | (uint32_t)d[o + 1] << 16 | (uint32_t)d[o + 2] << 8 | (uint32_t)d[o + 3];
+  }
+  uint64_t u64(size_t o) const {
+    return le ? (uint64_t)u32(o) | (uint64_t)u32(o + 4) << 32 : (uint64_t)u32(o) << 32 | (uint64_t)u32(o + 4);
   }
 };
 
@@ -48,7 +56,7 @@ bool slurp(const char* path, std::vector<uint8_t>& out) {
 }
 
 struct Ifd {
-  uint32_t w = 0, h = 0, bps = 1, comp = 1, spp = 1, rps = 0, fmt = 1, fill = 1, planar = 1;
+  uint32_t w = 0, h = 0, bps = 1, comp = 1, spp = 1, rps = 0, fmt = 1, fill = 1, planar = 1, predictor = 1;
   uint32_t tile_w = 0, tile_h = 0;
   std::vector<uint64_t> offs, counts;
   bool tiled = false;
@@ -58,36 +66,39 @@ size_t type_size(uint16_t t) {
   switch (t) {
     case 1: case 2: case 6: case 7: return 1;
     case 3: case 8: return 2;
-    case 4: case 9: case 11: return 4;
-    case 5: case 10: case 12: return 8;
+    case 4: case 9: case 11: case 13: return 4;
+    case 5: case 10: case 12: case 16: case 17: case 18: return 8;
     default: return 0;
   }
 }
 
 bool read_values(const File& f, size_t entry, std::vector<uint64_t>& out) {
   const uint16_t type = f.u16(entry + 2);
-  const uint32_t count = f.u32(entry + 4);
+  const uint64_t count = f.big ? f.u64(entry + 4) : f.u32(entry + 4);
   const size_t ts = type_size(type);
-  if (ts == 0) return false;
-  size_t pos = entry + 8;
-  if (ts * count > 4) pos = f.u32(entry + 8);
+  if (ts == 0 || count > (1ull << 32)) return false;
+  const size_t inline_bytes = f.big ? 8 : 4, val = entry + (f.big ? 12 : 8);
+  size_t pos = val;
+  if (ts * count > inline_bytes) pos = f.big ? (size_t)f.u64(val) : f.u32(val);
   if (pos + ts * count > f.d.size()) return false;
   out.resize(count);
-  for (uint32_t i = 0; i < count; ++i) {
+  for (uint64_t i = 0; i < count; ++i) {
     if (ts == 1) out[i] = f.d[pos + i];
     else if (ts == 2) out[i] = f.u16(pos + 2 * i);
-    else out[i] = f.u32(pos + 4 * i);
+    else if (ts == 4) out[i] = f.u32(pos + 4 * i);
+    else out[i] = (type == 16 || type == 17 || type == 18) ? f.u64(pos + 8 * i) : f.u32(pos + 8 * i);  // rationals: numerator
   }
   return true;
 }
 
 bool parse_ifd(const File& f, size_t off, Ifd& ifd, size_t& next) {
-  if (off + 2 > f.d.size()) return false;
-  const uint16_t n = f.u16(off);
-  if (off + 2 + 12 * (size_t)n + 4 > f.d.size()) return false;
+  const size_t cnt_bytes = f.big ? 8 : 2, ent_bytes = f.big ? 20 : 12, next_bytes = f.big ? 8 : 4;
+  if (off + cnt_bytes > f.d.size()) return false;
+  const uint64_t n = f.big ? f.u64(off) : f.u16(off);
+  if (n > 65535 || off + cnt_bytes + ent_bytes * (size_t)n + next_bytes > f.d.size()) return false;
   std::vector<uint64_t> v;
-  for (uint16_t e = 0; e < n; ++e) {
-    const size_t ent = off + 2 + 12 * (size_t)e;
+  for (uint64_t e = 0; e < n; ++e) {
+    const size_t ent = off + cnt_bytes + ent_bytes * (size_t)e;
     const uint16_t tag = f.u16(ent);
     if (!read_values(f, ent, v) || v.empty()) continue;
     switch (tag) {
@@ -101,6 +112,7 @@ bool parse_ifd(const File& f, size_t off, Ifd& ifd, size_t& next) {
       case 278: ifd.rps = (uint32_t)v[0]; break;
       case 279: ifd.counts = v; break;
       case 284: ifd.planar = (uint32_t)v[0]; break;
+      case 317: ifd.predictor = (uint32_t)v[0]; break;
       case 322: ifd.tile_w = (uint32_t)v[0]; ifd.tiled = true; break;
       case 323: ifd.tile_h = (uint32_t)v[0]; ifd.tiled = true; break;
       case 324: ifd.offs = v; ifd.tiled = true; break;
@@ -109,7 +121,8 @@ bool parse_ifd(const File& f, size_t off, Ifd& ifd, size_t& next) {
       default: break;
     }
   }
-  next = f.u32(off + 2 + 12 * (size_t)n);
+  const size_t np = off + cnt_bytes + ent_bytes * (size_t)n;
+  next = f.big ? (size_t)f.u64(np) : f.u32(np);
   return true;
 }
 
@@ -133,6 +146,64 @@ bool unpackbits(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t 
   return true;
 }
 
+// TIFF LZW (compression 5, TIFF 6.0 section 13): MSB-first codes of 9..12 bits, ClearCode 256,
+// EndOfInformation 257, the code width grows one code EARLY (at 511 / 1023 / 2047 table entries)
+bool unlzw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
+  out.clear();
+  out.reserve(expect);
+  struct Entry { uint32_t prev; uint32_t len; uint8_t first, last; };
+  std::vector<Entry> tab(4096);
+  for (uint32_t i = 0; i < 256; ++i) tab[i] = Entry{0xffffffffu, 1, (uint8_t)i, (uint8_t)i};
+  uint32_t next = 258, width = 9, prev = 0xffffffffu;
+  uint64_t acc = 0;
+  int nbits = 0;
+  size_t pos = 0;
+  auto emit = [&](uint32_t code) {  // appends the string of `code`
+    const uint32_t len = tab[code].len;
+    const size_t base = out.size();
+    out.resize(base + len);
+    uint32_t c = code;
+    for (uint32_t i = len; i-- > 0;) {
+      out[base + i] = tab[c].last;
+      c = tab[c].prev;
+    }
+  };
+  while (out.size() < expect) {
+    while (nbits < (int)width && pos < n) { acc = (acc << 8) | src[pos++]; nbits += 8; }
+    if (nbits < (int)width) break;  // ran out of data (some writers omit EOI)
+    const uint32_t code = (uint32_t)((acc >> (nbits - width)) & ((1u << width) - 1));
+    nbits -= width;
+    if (code == 257) break;
+    if (code == 256) { next = 258; width = 9; prev = 0xffffffffu; continue; }
+    if (prev == 0xffffffffu) {
+      if (code >= 256) return false;
+      emit(code);
+    } else if (code < next) {
+      emit(code);
+      if (next < 4096) { tab[next] = Entry{prev, tab[prev].len + 1, tab[prev].first, tab[code].first}; ++next; }
+    } else if (code == next && next < 4096) {  // KwKwK
+      tab[next] = Entry{prev, tab[prev].len + 1, tab[prev].first, tab[prev].first};
+      ++next;
+      emit(code);
+    } else {
+      return false;
+    }
+    prev = code;
+    if (next + 1 >= (1u << width) && width < 12) ++width;
+  }
+  if (out.size() > expect) out.resize(expect);
+  return true;
+}
+
+// Deflate / "Adobe Deflate" (compression 8 and 32946): a zlib stream per strip or tile
+bool uninflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
+  out.assign(expect, 0);
+  uLongf got = (uLongf)expect;
+  const int rc = uncompress(out.data(), &got, src, (uLong)n);
+  if (rc != Z_OK && rc != Z_BUF_ERROR) return false;  // Z_BUF_ERROR: more data than rows needed (padded strips)
+  return rc == Z_OK || got == expect;
+}
+
 template <typename T>
 T load_swapped(const uint8_t* p, bool swap) {
   uint8_t b[sizeof(T)];
@@ -140,6 +211,26 @@ T load_swapped(const uint8_t* p, bool swap) {
   T v;
   memcpy(&v, b, sizeof(T));
   return v;
+}
+
+template <typename T>
+void store_swapped(uint8_t* p, T v, bool swap) {
+  uint8_t b[sizeof(T)];
+  memcpy(b, &v, sizeof(T));
+  for (size_t i = 0; i < sizeof(T); ++i) p[i] = swap ? b[sizeof(T) - 1 - i] : b[i];
+}
+
+// undo the horizontal differencing predictor (tag 317 = 2) row by row, in place (integer samples, file byte order)
+template <typename T>
+void unpredict_rows(uint8_t* buf, size_t rows, size_t cols, bool swap) {
+  for (size_t r = 0; r < rows; ++r) {
+    uint8_t* row = buf + r * cols * sizeof(T);
+    T acc = load_swapped<T>(row, swap);
+    for (size_t c = 1; c < cols; ++c) {
+      acc = (T)(acc + load_swapped<T>(row + c * sizeof(T), swap));
+      store_swapped<T>(row + c * sizeof(T), acc, swap);
+    }
+  }
 }
 
 // interpretBytesAsDouble of the reference (TiffReader.cpp, used at :385,:430)
@@ -162,13 +253,8 @@ bool host_is_le() {
   return *reinterpret_cast<const uint8_t*>(&one) == 1;
 }
 
-}  // namespace
-
-extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
-                                  int* bits_per_sample) {
-  if (!path || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
-  *phase = nullptr;
-  File f;
+// header + directory chain of one file
+oi_status open_tiff(const char* path, File& f, std::vector<Ifd>& pages) {
   if (!slurp(path, f.d) || f.d.size() < 8) {
     oi::set_error("cannot read TIFF file '%s'", path);
     return OI_IO_ERROR;
@@ -176,12 +262,18 @@ extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** 
   if (f.d[0] == 'I' && f.d[1] == 'I') f.le = true;
   else if (f.d[0] == 'M' && f.d[1] == 'M') f.le = false;
   else { oi::set_error("'%s' is not a TIFF file", path); return OI_IO_ERROR; }
-  if (f.u16(2) != 42) {
-    oi::set_error("'%s': only classic TIFF (magic 42) is supported", path);
+  const uint16_t magic = f.u16(2);
+  size_t off = 0;
+  if (magic == 42) {
+    off = f.u32(4);
+  } else if (magic == 43 && f.d.size() >= 16 && f.u16(4) == 8) {
+    f.big = true;
+    off = (size_t)f.u64(8);
+  } else {
+    oi::set_error("'%s': neither classic TIFF (42) nor BigTIFF (43)", path);
     return OI_IO_ERROR;
   }
-  std::vector<Ifd> pages;
-  size_t off = f.u32(4);
+  pages.clear();
   while (off) {  // TiffReader.cpp:175-177: depth = number of directories
     Ifd ifd;
     size_t next = 0;
@@ -191,83 +283,158 @@ extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** 
     off = next;
   }
   if (pages.empty()) { oi::set_error("'%s': no directories", path); return OI_IO_ERROR; }
-  const Ifd& p0 = pages[0];
+  return OI_OK;
+}
+
+oi_status check_first_page(const char* path, const Ifd& p0) {
   const bool valid_bps = p0.bps == 1 || p0.bps == 8 || p0.bps == 16 || p0.bps == 32 || p0.bps == 64;
   if (p0.w == 0 || p0.h == 0 || !valid_bps || p0.planar != 1 || p0.spp != 1) {  // TiffReader.cpp:167-173
     oi::set_error("'%s': unsupported TIFF (W=%u H=%u BPS=%u planar=%u SPP=%u)", path, p0.w, p0.h, p0.bps, p0.planar,
                   p0.spp);
     return OI_IO_ERROR;
   }
+  return OI_OK;
+}
+
+// one directory -> one thresholded W x H slice
+oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd& p0, size_t k, double threshold,
+                      uint8_t* slice, std::vector<uint8_t>& buf) {
+  const size_t W = p0.w, H = p0.h;
+  if (pg.w != p0.w || pg.h != p0.h || pg.bps != p0.bps) {
+    oi::set_error("'%s': page %zu differs in size/depth from page 0", path, k);
+    return OI_IO_ERROR;
+  }
+  const bool known = pg.comp == 1 || pg.comp == 5 || pg.comp == 8 || pg.comp == 32946 || pg.comp == 32773;
+  if (!known) {
+    oi::set_error("'%s': TIFF compression %u is not supported (none, LZW, Deflate and PackBits are)", path, pg.comp);
+    return OI_IO_ERROR;
+  }
+  if (pg.predictor != 1 && !(pg.predictor == 2 && pg.bps >= 8 && pg.fmt != 3)) {
+    oi::set_error("'%s': TIFF predictor %u with %u-bit format %u is not supported", path, pg.predictor, pg.bps, pg.fmt);
+    return OI_IO_ERROR;
+  }
+  const bool swap = f.le != host_is_le();
+  const size_t bytes_ps = p0.bps >= 8 ? p0.bps / 8 : 1;
+  // geometry of one chunk (strip or tile)
+  const size_t cw = pg.tiled ? pg.tile_w : W;
+  const size_t ch = pg.tiled ? pg.tile_h : (pg.rps == 0 || pg.rps > H ? H : pg.rps);
+  if (cw == 0 || ch == 0) { oi::set_error("'%s': bad strip/tile geometry", path); return OI_IO_ERROR; }
+  const size_t row_bytes = p0.bps == 1 ? (cw + 7) / 8 : cw * bytes_ps;
+  const size_t across = pg.tiled ? (W + cw - 1) / cw : 1;
+  const size_t down = (H + ch - 1) / ch;
+  if (pg.offs.size() < across * down || pg.counts.size() < across * down) {
+    oi::set_error("'%s': page %zu lacks strip/tile offsets", path, k);
+    return OI_IO_ERROR;
+  }
+  for (size_t cy = 0; cy < down; ++cy)
+    for (size_t cx = 0; cx < across; ++cx) {
+      const size_t ci = cy * across + cx;
+      const size_t rows_here = pg.tiled ? ch : std::min(ch, H - cy * ch);
+      const size_t expect = row_bytes * rows_here;
+      const uint64_t o = pg.offs[ci], n = pg.counts[ci];
+      if (o + n > f.d.size()) { oi::set_error("'%s': chunk outside file", path); return OI_IO_ERROR; }
+      const uint8_t* src = f.d.data() + o;
+      size_t avail = n;
+      if (pg.comp != 1 || pg.predictor == 2) {
+        bool ok = true;
+        if (pg.comp == 32773) ok = unpackbits(src, n, buf, expect);
+        else if (pg.comp == 5) ok = unlzw(src, n, buf, expect);
+        else if (pg.comp == 8 || pg.comp == 32946) ok = uninflate(src, n, buf, expect);
+        else buf.assign(src, src + std::min<size_t>(n, expect));
+        if (!ok) { oi::set_error("'%s': corrupt compressed data (compression %u, page %zu)", path, pg.comp, k); return OI_IO_ERROR; }
+        if (pg.predictor == 2) {
+          const size_t rows_ok = buf.size() / row_bytes;
+          if (bytes_ps == 1) unpredict_rows<uint8_t>(buf.data(), rows_ok, cw, false);
+          else if (bytes_ps == 2) unpredict_rows<uint16_t>(buf.data(), rows_ok, cw, swap);
+          else if (bytes_ps == 4) unpredict_rows<uint32_t>(buf.data(), rows_ok, cw, swap);
+          else unpredict_rows<uint64_t>(buf.data(), rows_ok, cw, swap);
+        }
+        src = buf.data();
+        avail = buf.size();
+      }
+      for (size_t r = 0; r < rows_here; ++r) {
+        const size_t y = cy * ch + r;
+        if (y >= H) break;
+        for (size_t c = 0; c < cw; ++c) {
+          const size_t x = cx * cw + c;
+          if (x >= W) break;
+          double val = 0.0;
+          if (p0.bps == 1) {  // TiffReader.cpp:419-426 (strips) / :376-381 (tiles)
+            const size_t bi = r * row_bytes + c / 8;
+            if (bi < avail) {
+              const int bit = (int)(c % 8);
+              // libtiff hands data back MSB-first unless the file says LSB2MSB and the
+              // reference then picks the bit by FILLORDER (TiffReader.cpp:425)
+              val = (double)((pg.fill == 2 ? (src[bi] >> bit) : (src[bi] >> (7 - bit))) & 1);
+            }
+          } else {
+            const size_t bo = (r * cw + c) * bytes_ps;
+            if (bo + bytes_ps <= avail) val = sample_as_double(src + bo, p0.bps, pg.fmt, swap);
+          }
+          slice[y * W + x] = val > threshold ? 1 : 0;  // TiffReader.cpp:434
+        }
+      }
+    }
+  return OI_OK;
+}
+
+}  // namespace
+
+extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
+                                  int* bits_per_sample) {
+  if (!path || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
+  *phase = nullptr;
+  File f;
+  std::vector<Ifd> pages;
+  oi_status st = open_tiff(path, f, pages);
+  if (st != OI_OK) return st;
+  const Ifd& p0 = pages[0];
+  if ((st = check_first_page(path, p0)) != OI_OK) return st;
   const size_t W = p0.w, H = p0.h, D = pages.size();
   uint8_t* out = (uint8_t*)malloc(W * H * D);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
-  const bool swap = f.le != host_is_le();
-  const size_t bytes_ps = p0.bps >= 8 ? p0.bps / 8 : 1;
   std::vector<uint8_t> buf;
   for (size_t k = 0; k < D; ++k) {
-    const Ifd& pg = pages[k];
-    if (pg.w != p0.w || pg.h != p0.h || pg.bps != p0.bps) {
-      free(out);
-      oi::set_error("'%s': page %zu differs in size/depth from page 0", path, k);
-      return OI_IO_ERROR;
-    }
-    if (pg.comp != 1 && pg.comp != 32773) {
-      free(out);
-      oi::set_error("'%s': TIFF compression %u is not supported (uncompressed and PackBits are)", path, pg.comp);
-      return OI_IO_ERROR;
-    }
-    // geometry of one chunk (strip or tile)
-    const size_t cw = pg.tiled ? pg.tile_w : W;
-    size_t ch = pg.tiled ? pg.tile_h : (pg.rps == 0 || pg.rps > H ? H : pg.rps);
-    if (cw == 0 || ch == 0) { free(out); oi::set_error("'%s': bad strip/tile geometry", path); return OI_IO_ERROR; }
-    const size_t row_bytes = p0.bps == 1 ? (cw + 7) / 8 : cw * bytes_ps;
-    const size_t across = pg.tiled ? (W + cw - 1) / cw : 1;
-    const size_t down = (H + ch - 1) / ch;
-    if (pg.offs.size() < across * down || pg.counts.size() < across * down) {
-      free(out);
-      oi::set_error("'%s': page %zu lacks strip/tile offsets", path, k);
-      return OI_IO_ERROR;
-    }
-    for (size_t cy = 0; cy < down; ++cy)
-      for (size_t cx = 0; cx < across; ++cx) {
-        const size_t ci = cy * across + cx;
-        const size_t rows_here = pg.tiled ? ch : std::min(ch, H - cy * ch);
-        const size_t expect = row_bytes * rows_here;
-        const uint64_t o = pg.offs[ci], n = pg.counts[ci];
-        if (o + n > f.d.size()) { free(out); oi::set_error("'%s': chunk outside file", path); return OI_IO_ERROR; }
-        const uint8_t* src = f.d.data() + o;
-        size_t avail = n;
-        if (pg.comp == 32773) {
-          if (!unpackbits(src, n, buf, expect)) { free(out); oi::set_error("'%s': bad PackBits data", path); return OI_IO_ERROR; }
-          src = buf.data();
-          avail = buf.size();
-        }
-        for (size_t r = 0; r < rows_here; ++r) {
-          const size_t y = cy * ch + r;
-          if (y >= H) break;
-          for (size_t c = 0; c < cw; ++c) {
-            const size_t x = cx * cw + c;
-            if (x >= W) break;
-            double val = 0.0;
-            if (p0.bps == 1) {  // TiffReader.cpp:419-426 (strips) / :376-381 (tiles)
-              const size_t bi = r * row_bytes + c / 8;
-              if (bi < avail) {
-                const int bit = (int)(c % 8);
-                // libtiff hands data back MSB-first unless the file says LSB2MSB and the
-                // reference then picks the bit by FILLORDER (TiffReader.cpp:425)
-                val = (double)((pg.fill == 2 ? (src[bi] >> bit) : (src[bi] >> (7 - bit))) & 1);
-              }
-            } else {
-              const size_t bo = (r * cw + c) * bytes_ps;
-              if (bo + bytes_ps <= avail) val = sample_as_double(src + bo, p0.bps, pg.fmt, swap);
-            }
-            out[(k * H + y) * W + x] = val > threshold ? 1 : 0;  // TiffReader.cpp:434
-          }
-        }
-      }
+    st = decode_page(path, f, pages[k], p0, k, threshold, out + k * W * H, buf);
+    if (st != OI_OK) { free(out); return st; }
   }
   *phase = out;
   *nx = (int)W; *ny = (int)H; *nz = (int)D;
+  if (bits_per_sample) *bits_per_sample = (int)p0.bps;
+  return OI_OK;
+}
+
+// Numbered single-slice files <base><index, zero-padded to `digits`><suffix>, index = start_index ..
+// start_index + num_files - 1 (TiffReader::readFileSequence, TiffReader.cpp:85-88, :209-285; the
+// decode reads directory 0 of every file, :325-329); all slices must match the first one.
+extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_files, int start_index, int digits,
+                                           const char* suffix, double threshold, uint8_t** phase, int* nx, int* ny,
+                                           int* nz, int* bits_per_sample) {
+  if (!base_pattern || !phase || !nx || !ny || !nz || num_files < 1 || digits < 0 || digits > 32) return OI_BAD_ARG;
+  *phase = nullptr;
+  uint8_t* out = nullptr;
+  Ifd p0;
+  std::vector<uint8_t> buf;
+  for (int k = 0; k < num_files; ++k) {
+    char num[64];
+    snprintf(num, sizeof(num), "%0*d", digits, start_index + k);
+    const std::string name = std::string(base_pattern) + num + (suffix ? suffix : "");
+    File f;
+    std::vector<Ifd> pages;
+    oi_status st = open_tiff(name.c_str(), f, pages);
+    if (st == OI_OK && k == 0) {
+      p0 = pages[0];
+      st = check_first_page(name.c_str(), p0);
+      if (st == OI_OK) {
+        out = (uint8_t*)malloc((size_t)p0.w * p0.h * (size_t)num_files);
+        if (!out) { oi::set_error("out of memory"); st = OI_IO_ERROR; }
+      }
+    }
+    if (st == OI_OK) st = decode_page(name.c_str(), f, pages[0], p0, (size_t)k, threshold, out + (size_t)k * p0.w * p0.h, buf);
+    if (st != OI_OK) { free(out); return st; }
+  }
+  *phase = out;
+  *nx = (int)p0.w; *ny = (int)p0.h; *nz = num_files;
   if (bits_per_sample) *bits_per_sample = (int)p0.bps;
   return OI_OK;
 }

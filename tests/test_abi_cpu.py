@@ -131,3 +131,82 @@ def test_tiff_reader_other_bundled_files():
     sp = oia.TiffReader(os.path.join(GOLDEN, "spheres.tif")).threshold(0.5)
     assert sp.shape == (100, 100, 100) and sp.mean() == pytest.approx(0.888024, abs=5e-7)
     assert np.array_equal(sp, o.read_tiff_phase(os.path.join(GOLDEN, "spheres.tif")))
+
+
+def _pil():
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, features
+    if not features.check("libtiff"):
+        pytest.skip("Pillow without libtiff")
+    return Image
+
+
+@pytest.mark.parametrize("compression", ["raw", "tiff_lzw", "tiff_adobe_deflate", "tiff_deflate", "packbits"])
+@pytest.mark.parametrize("mode,dtype", [("L", np.uint8), ("I;16", np.uint16), ("F", np.float32), ("1", np.uint8)])
+def test_tiff_reader_compressed_stacks_written_by_libtiff(tmp_path, compression, mode, dtype):
+    """Multi-page stacks written by libtiff (through Pillow) in every encoding the reference's libtiff-based
+    reader meets in practice; expected voxels = libtiff's own decode of the same file."""
+    Image = _pil()
+    rng = np.random.default_rng(7)
+    nz, ny, nx = 5, 37, 83
+    if mode == "1":
+        vol = (rng.random((nz, ny, nx)) < 0.4)
+        pages = [Image.fromarray(v) for v in vol]
+        thr = 0.5
+    else:
+        smooth = np.cumsum(rng.integers(-3, 4, size=(nz, ny, nx)), axis=2) + 120   # compressible rows
+        vol = np.clip(smooth, 0, 250).astype(dtype) * (257 if dtype == np.uint16 else 1)
+        pages = [Image.fromarray(v) for v in vol]
+        thr = float(np.median(vol))
+    p = tmp_path / "stack.tif"
+    pages[0].save(p, format="TIFF", compression=compression, save_all=True, append_images=pages[1:])
+    expect = np.stack([_page(Image, p, k) for k in range(nz)])
+    got = oia.TiffReader(str(p)).threshold(thr)
+    assert got.shape == (nz, ny, nx)
+    assert np.array_equal(got, (expect.astype(np.float64) > thr).astype(np.uint8))
+    assert 0 < got.mean() < 1
+
+
+def _page(Image, path, k):
+    with Image.open(path) as im:
+        im.seek(k)
+        return np.array(im)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_tiff_reader_predictor_bigtiff_and_sequences(tmp_path, big):
+    Image = _pil()
+    rng = np.random.default_rng(11)
+    nz, ny, nx = 4, 29, 50
+    vol = (np.cumsum(rng.integers(-40, 41, size=(nz, ny, nx)), axis=2) + 30000).astype(np.uint16)
+    thr = float(np.median(vol))
+    pages = [Image.fromarray(v) for v in vol]
+    kw = dict(format="TIFF", compression="tiff_lzw", tiffinfo={317: 2})   # horizontal differencing predictor
+    if big:   # Pillow's libtiff path ignores big_tiff; its own (uncompressed) writer honours it
+        kw = dict(format="TIFF", big_tiff=True)
+    p = tmp_path / "pred.tif"
+    pages[0].save(p, save_all=True, append_images=pages[1:], **kw)
+    assert open(p, "rb").read(4)[2] == (43 if big else 42)
+    got = oia.TiffReader(str(p)).threshold(thr)
+    assert np.array_equal(got, (vol > thr).astype(np.uint8))
+    # the same slices as a numbered file sequence (TiffReader.H:117-123)
+    for k, im in enumerate(pages):
+        im.save(tmp_path / f"slice_{k + 3:04d}.tif", **kw)
+    seq = oia.TiffReader(str(tmp_path / "slice_"), num_files=nz, start_index=3, digits=4, suffix=".tif")
+    assert np.array_equal(seq.threshold(thr), got)
+    assert (seq.width(), seq.height(), seq.depth(), seq.bitsPerSample()) == (nx, ny, nz, 16)
+    with pytest.raises(oia.OpenImpalaError):   # a missing member of the sequence is an error, not a short volume
+        oia.TiffReader(str(tmp_path / "slice_"), num_files=nz + 1, start_index=3, digits=4).threshold(thr)
+
+
+def test_tiff_reader_rejects_what_it_cannot_decode(tmp_path):
+    Image = _pil()
+    a = (np.arange(64 * 64) % 256).astype(np.uint8).reshape(64, 64)
+    p = tmp_path / "jpeg.tif"
+    try:
+        Image.fromarray(a).save(p, format="TIFF", compression="jpeg")
+    except Exception:
+        pytest.skip("libtiff without JPEG")
+    with pytest.raises(oia.OpenImpalaError) as e:
+        oia.TiffReader(str(p)).threshold(1.0)
+    assert "compression" in str(e.value)

@@ -43,12 +43,18 @@ verbose = 0
     # bad number
     r = subprocess.run([app, _inputs(tmp_path, base), "phase_id=abc"], capture_output=True, text=True)
     assert r.returncode == 1 and "phase_id" in r.stderr
+    r = subprocess.run([app, _inputs(tmp_path, base + "calculation_method = flow_through\ndirection = X\n"),
+                        "gpu.precond=smg"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "gpu.precond" in r.stderr
 
 
 @pytest.mark.gpu
-def test_diffusion_results_file(app, tmp_path, goldens):
+@pytest.mark.parametrize("precond", ["", "gpu.precond = jacobi", "gpu.precond = none\ngpu.kernel = fused"])
+def test_diffusion_results_file(app, tmp_path, goldens, precond):
+    """Default solver = multigrid-preconditioned CG; the plain CG variants give the same file."""
     g = goldens["phases"]["1"]
     text = f"""
+{precond}
 filename = SampleData_2Phase_stack_3d_1bit.tif
 data_path = {GOLDEN}
 results_path = {tmp_path}/res
