@@ -229,9 +229,17 @@ def main():
                 traffic = ent["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
+    # The kernels predicate vector loads/stores on the code byte: 128-byte lines (16 doubles) without a free
+    # voxel are never moved.  `achieved` / `frac` keep SURVEY 8(d)'s DENSE definition (every voxel streams its
+    # 61 B); `moved_*` is the same launch priced on the lines it cannot skip -- the number that says how close
+    # the memory system itself is to its peak.
+    live16 = t.live_fraction(16)
+    moved = (1.0 + (BYTES_PER_VOXEL[main_k] - 1.0) * live16) * n * n * nzl
     roofline = {"bound": "hbm", "kernel": main_k, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": BYTES_PER_VOXEL[main_k] * n * n * nzl,
+                "live_line_fraction": live16, "moved_bytes_per_launch_model": moved,
+                "moved_GBps": moved / ms_launch / 1e6, "moved_frac_of_peak": moved / ms_launch / 1e6 / HBM_PEAK_GBS,
                 "ms_per_launch": ms_launch,
                 "bytes_per_voxel_iter": alg_bytes_iter,
                 "iteration_GBps": alg_bytes_iter * n * n * nzl / (dt / args.steps) / 1e9,

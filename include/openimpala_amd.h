@@ -188,6 +188,12 @@ void oi_tort_set_apply_tuning(int tile_rows);
  * updated every second iteration with both pending terms (1, default) or every iteration (0) */
 void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
 
+/* The solver kernels predicate their vector loads/stores on the code byte, so a cache line without a
+ * free voxel is never moved.  Fraction of the aligned runs of `group_voxels` voxels along x (this slab)
+ * that hold at least one free voxel -- 16 doubles = one 128-byte line; used by bench.py to state the
+ * bytes the kernel cannot avoid. */
+oi_status oi_tort_live_fraction(oi_tort* h, int group_voxels, double* fraction);
+
 /* per-kernel HIP-event timings gathered while opts.profile = 1.  names: fixed list,
  * see oi_kernel_name().  Returns the number of kernels written (<= cap). */
 int oi_tort_kernel_times(oi_tort* h, int cap, int* kernel_ids, double* total_ms, int64_t* launches);

@@ -130,6 +130,7 @@ def lib():
     L.oi_tort_debug_apply.argtypes = [vp, vp, vp, i]
     L.oi_tort_debug_get_codes.argtypes = [vp, vp]
     L.oi_tort_bench_apply.argtypes = [vp, i, i, C.POINTER(d)]
+    L.oi_tort_live_fraction.argtypes = [vp, i, C.POINTER(d)]
     L.oi_tort_kernel_times.argtypes = [vp, i, C.POINTER(i), C.POINTER(d), i64p]
     L.oi_tort_kernel_times.restype = i
     L.oi_tort_reset_kernel_times.argtypes = [vp]
@@ -492,6 +493,13 @@ class TortuosityMI355:
 
     def reset_kernel_times(self):
         lib().oi_tort_reset_kernel_times(self._h)
+
+    def live_fraction(self, group_voxels=16):
+        """Fraction of the aligned x-runs of `group_voxels` voxels holding a free voxel (16 doubles = one
+        128-byte line): the lines of r/q/p/x the predicated solver kernels still have to move."""
+        f = C.c_double()
+        _check(lib().oi_tort_live_fraction(self._h, int(group_voxels), C.byref(f)))
+        return f.value
 
     def destroy(self):
         if self._h:

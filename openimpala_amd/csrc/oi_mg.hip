@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(256) k_mg_restrict(Dims F, const float* __rest
   bc[m] = s;
 }
 
-__global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const double* __restrict__ r1, Dims L, int kfirst,
+__global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const uint8_t* __restrict__ code,
+                                                           const double* __restrict__ r1, Dims L, int kfirst,
                                                            float* __restrict__ bc) {
   OI_MG_CELL(L)
   (void)sy;
@@ -222,8 +223,10 @@ __global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const double* 
       const int fj = 2 * j + bb;
       if (fj >= g.ny) continue;
       const long long row = (long long)gz * g.plane + (long long)fj * g.pitch;
-      s += r1[row + 2 * i];
-      if (2 * i + 1 < g.nx) s += r1[row + 2 * i + 1];
+      // r1 vanishes on non-free voxels; the pad column holds code 0, so the pair is always readable
+      const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + row + 2 * i);
+      if (cc & 0xff) s += r1[row + 2 * i];
+      if (cc >> 8) s += r1[row + 2 * i + 1];
     }
   }
   bc[m] = (float)s;
@@ -534,8 +537,8 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, hipStre
 }
 
 // right-hand side of child C from the residual of its parent (fine parent: r1 in the solver layout)
-static bool restrict_to(MgHierarchy* mg, const Geom* g, const double* r1, const MgLevelHost* P, MgLevelHost& C, float* bc,
-                        hipStream_t s) {
+static bool restrict_to(MgHierarchy* mg, const Geom* g, const uint8_t* code, const double* r1, const MgLevelHost* P,
+                        MgLevelHost& C, float* bc, hipStream_t s) {
   const bool prep = P ? P->replicated : false;
   const int pz0 = P ? P->d.z0 : g->z0, pnzl = P ? P->d.nzl : g->nzl;
   int kfirst = 1, nplanes = C.d.nzl;
@@ -545,7 +548,7 @@ static bool restrict_to(MgHierarchy* mg, const Geom* g, const double* r1, const 
   }
   if (C.blocks(nplanes) > 0) {
     if (P) hipLaunchKernelGGL(k_mg_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, P->d, P->r, C.d, kfirst, bc);
-    else hipLaunchKernelGGL(k_mg_fine_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, *g, r1, C.d, kfirst, bc);
+    else hipLaunchKernelGGL(k_mg_fine_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, *g, code, r1, C.d, kfirst, bc);
   }
   return finish_child_array(mg, C, prep, bc, s);
 }
@@ -569,7 +572,7 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   }
   MgLevelHost& C = Ls[l + 1];
   OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
-  if (!restrict_to(mg, nullptr, nullptr, &L, C, C.b, s)) return false;
+  if (!restrict_to(mg, nullptr, nullptr, nullptr, &L, C, C.b, s)) return false;
   if (!coarse_cycle(mg, l + 1, C.b, C.x2, s)) return false;
   const float* second = nullptr;
   if ((mg->wmask >> (l + 1)) & 1u) {
@@ -593,7 +596,7 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz};
   if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, partials, ctrl, s);
   else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl);
-  if (!restrict_to(mg, &g, scratch, nullptr, C, C.b, s)) return -1;
+  if (!restrict_to(mg, &g, code, scratch, nullptr, C, C.b, s)) return -1;
   if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
   if (mg->wmask & 1u) {
     OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, 1, C.b, C.x2, C.b2);

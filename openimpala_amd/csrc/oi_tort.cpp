@@ -978,6 +978,22 @@ extern "C" oi_status oi_tort_check_matrix_properties(oi_tort* h, int64_t* n_viol
   return OI_OK;
 }
 
+// fraction of the aligned `group_voxels`-long x-runs (this slab) that contain a free voxel
+extern "C" oi_status oi_tort_live_fraction(oi_tort* h, int group_voxels, double* fraction) {
+  if (!h || !fraction || group_voxels < 1) return OI_BAD_ARG;
+  *fraction = 0.0;
+  if (!h->percolates || !h->code) return OI_NO_PERCOLATION;
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  HIPC(hipMemsetAsync(h->counters, 0, sizeof(unsigned long long), h->stream));
+  launch_count_live_groups(g, h->code, group_voxels, h->counters, h->stream);
+  HIPC(hipMemcpyAsync(h->h_counters, h->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  const double groups = (double)g.nzl * g.ny * ((g.nx + group_voxels - 1) / group_voxels);
+  *fraction = (double)h->h_counters[0] / groups;
+  return OI_OK;
+}
+
 extern "C" int oi_tort_kernel_times(oi_tort* h, int cap, int* kernel_ids, double* total_ms, int64_t* launches) {
   if (!h) return 0;
   prof_harvest(h);

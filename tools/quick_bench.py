@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 kind = sys.argv[2] if len(sys.argv) > 2 else "s"
 shape = (n, n, n)
 buf = oia.gen_bernoulli_device(shape, 20251031, 0.5) if kind == "b" else oia.gen_spheres_device(shape, 20251031, 24 if n >= 512 else 8, 0.4)
-configs = [("cg1", 16, 0), ("cg1", 32, 0), ("cg1", 16, 1), ("cg1", 32, 1)]
+configs = [("cg1", 8, 0), ("cg1", 16, 0), ("cg1", 32, 0), ("cg1", 33, 0), ("cg1", 16, 1), ("cg1", 32, 1)]
 for kern, rows, pf32 in configs:
     oia.set_tuning(16, 0, 32, rows)
     k = oia.KERNEL_FUSED1 if kern == "cg1" else oia.KERNEL_FUSED
