@@ -235,7 +235,9 @@ int main(int argc, char* argv[]) {
     else throw std::runtime_error("gpu.precond must be mg, jacobi or none (got '" + precond + "')");
     const std::string kl = lower(kernel);
     opts.kernel = kl == "unfused" ? OI_KERNEL_UNFUSED
-                  : (kl == "fused" ? OI_KERNEL_FUSED : (kl == "fused1" ? OI_KERNEL_FUSED1 : OI_KERNEL_AUTO));
+                  : (kl == "fused" ? OI_KERNEL_FUSED
+                     : (kl == "fused1" ? OI_KERNEL_FUSED1 : (kl == "lean" ? OI_KERNEL_LEAN : OI_KERNEL_AUTO)));
+    if (opts.kernel == OI_KERNEL_LEAN && opts.precond == OI_PRECOND_MG) opts.precond = OI_PRECOND_JACOBI;  // capacity mode: CG
     if (opts.precond == OI_PRECOND_MG && opts.kernel == OI_KERNEL_FUSED1) opts.kernel = OI_KERNEL_AUTO;  // the cycle sits between the two kernels
     in.query("gpu.device", opts.device);
 

@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--nz", type=int, default=0, help="planes along z if not cubic (slab-size rehearsal)")
     ap.add_argument("--structure", default="spheres", choices=["spheres", "bernoulli", "blobs"])
     ap.add_argument("--direction", default="X", choices=["X", "Y", "Z"], help="flow axis (headline: X)")
-    ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused"])
+    ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused", "lean"],
+                    help="lean = capacity mode (x, r, p only; 25 B/voxel of HBM)")
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
@@ -168,7 +169,10 @@ def main():
     buf, desc = make_structure(oia, args, shape, z0, nzl)
     t_gen = time.time() - t_gen
     direction = {"X": oia.Direction.X, "Y": oia.Direction.Y, "Z": oia.Direction.Z}[args.direction]
-    kernel = {"fused1": oia.KERNEL_FUSED1, "fused": oia.KERNEL_FUSED, "unfused": oia.KERNEL_UNFUSED}[args.kernel]
+    if args.kernel == "lean":  # q-free passes: p.Ap reads p + code; the update reads p, code, r, x and writes r, x
+        BYTES_PER_VOXEL.update({"apply": 9.0, "update_xr": 41.0, "update_p": 24.0})
+    kernel = {"fused1": oia.KERNEL_FUSED1, "fused": oia.KERNEL_FUSED, "unfused": oia.KERNEL_UNFUSED,
+              "lean": oia.KERNEL_LEAN}[args.kernel]
     precond = oia.PRECOND_JACOBI if args.precond == "jacobi" else oia.PRECOND_NONE
     t_create = time.time()
     # eps = 1e-300 during the timed region: every one of the K steps does full work
@@ -186,7 +190,7 @@ def main():
 
     # ---- stand-alone stencil apply (the kernel the 70 %-of-roofline target names) ----
     apply_info = None
-    if not args.no_apply_bench:
+    if not args.no_apply_bench and args.kernel != "lean":
         ms = t.bench_apply(20, oia.KERNEL_FUSED)
         vox_local = n * n * nzl
         gbs = BYTES_PER_VOXEL["apply"] * vox_local / ms / 1e6
@@ -272,7 +276,7 @@ def main():
 
     # ---- same solve with the multigrid cycle as preconditioner (the role of SMG in the reference) ----
     solve_mg = None
-    if not args.no_solve:
+    if not args.no_solve and args.kernel != "lean":  # (the capacity mode is for volumes that leave no room for the cycle)
         t.destroy()
         bufm, _ = make_structure(oia, args, shape, z0, nzl)
         kwm = dict(eps=1e-6, precond=oia.PRECOND_MG, profile=1, maxiter=1000, device=local_rank)
@@ -301,7 +305,7 @@ def main():
 
     # ---- variant: search direction p STORED as fp32 (x, r, q and all arithmetic fp64) ----
     variants = None
-    if not args.no_variants and args.kernel != "unfused":
+    if not args.no_variants and args.kernel not in ("unfused", "lean"):
         if t is not None:
             t.destroy()
         buf2, _ = make_structure(oia, args, shape, z0, nzl)

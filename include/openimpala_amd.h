@@ -45,12 +45,15 @@ typedef enum oi_status {
 typedef struct oi_tort oi_tort; /* replaces an OpenImpala::TortuosityHypre object */
 typedef struct oi_comm oi_comm; /* replaces MPI_COMM_WORLD / amrex::ParallelDescriptor for this path */
 
-/* MG: aggregation-multigrid V(1,1) cycle per PCG iteration (what SMG is to the reference's
- * FlexGMRES): O(50) iterations instead of O(10 N); single GPU */
+/* MG: one 2x2x2 aggregation-multigrid cycle per PCG iteration (what SMG is to the reference's
+ * FlexGMRES): tens of iterations instead of O(10 N); works on z-slabs too */
 enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1, OI_PRECOND_MG = 2 };
 /* UNFUSED: apply / p-update / x,r-update kernels (89 B/voxel-iter); FUSED: two kernels (73 B);
- * FUSED1: ONE kernel per iteration with a single reduction (65 B), see DESIGN.md section 4 */
-enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2, OI_KERNEL_FUSED1 = 3 };
+ * FUSED1: ONE kernel per iteration with a single reduction (61 B), see DESIGN.md section 4;
+ * LEAN: capacity mode -- only x, r, p are stored (25 B/voxel of HBM instead of 57): A p is never
+ * written, the x/r update recomputes it (74 B/voxel-iter, still exact fp64 CG); for volumes that
+ * do not fit otherwise (BASELINE config 5: 4096^3 on 8 GPUs = 215 GB per GPU) */
+enum { OI_KERNEL_AUTO = 0, OI_KERNEL_UNFUSED = 1, OI_KERNEL_FUSED = 2, OI_KERNEL_FUSED1 = 3, OI_KERNEL_LEAN = 4 };
 enum { OI_STORE_F64 = 0, OI_STORE_F32 = 1 };
 
 /* Options.  `eps` / `maxiter` are the reference's hypre.eps / hypre.maxiter

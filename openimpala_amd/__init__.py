@@ -31,7 +31,7 @@ ABI_VERSION = 1
 OI_OK, OI_BAD_ARG, OI_NO_PERCOLATION, OI_NOT_CONVERGED, OI_FLUX_NOT_CONSERVED = 0, 1, 2, 3, 4
 OI_HIP_ERROR, OI_RCCL_ERROR, OI_NO_DEVICE, OI_IO_ERROR = 5, 6, 7, 8
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_MG = 0, 1, 2
-KERNEL_AUTO, KERNEL_UNFUSED, KERNEL_FUSED, KERNEL_FUSED1 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_UNFUSED, KERNEL_FUSED, KERNEL_FUSED1, KERNEL_LEAN = 0, 1, 2, 3, 4
 STORE_F64, STORE_F32 = 0, 1
 COMM_ID_BYTES = 128
 
@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
-    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_kernel_times "
+    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "

@@ -79,6 +79,12 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
+// q-free CG iteration of the capacity mode (x, r, p only): p.Ap without storing q, then
+// x += alpha p, r -= alpha A p with A p recomputed on the fly; partials {p.q} / {r.r, r.z}
+int launch_lean_dot(const Geom& g, const uint8_t* code, const double* p, double* partials, const Ctrl* ctrl,
+                    hipStream_t s);
+int launch_lean_update(const Geom& g, const uint8_t* code, const double* p, double* x, double* r, int jacobi,
+                       const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);
 // coarse correction handed to the fine-level post-smoother of the multigrid cycle: fp32 arrays in
 // the first coarse level's layout (cnx * cny cells per plane, planes csz apart, one ghost plane
 // first; z0c = global index of the first owned coarse plane); the correction is xc + xc2

@@ -432,6 +432,7 @@ __global__ void __launch_bounds__(256) k_update_p(Geom g, const uint8_t* __restr
   const double beta = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * (k - 1) + H_RZ]);
   OI_PAIR_LOOP_BEGIN
   (void)i; (void)j;
+  if (!cc) continue;  // r and p vanish on non-free voxels: such pairs are neither read nor written
   const double2 rv = ld2(r + e), pv = ld2(p + e);
   const double z0 = (jacobi && c0) ? rv.x / (double)c0 : rv.x;
   const double z1 = (jacobi && c1) ? rv.y / (double)c1 : rv.y;
@@ -623,7 +624,11 @@ constexpr int kBX = 128;            // tile width in voxels = 64 lanes x 2
 constexpr int kLP = kBX + 4;        // LDS row pitch in doubles
 constexpr int kNW = 8;              // waves per block
 
-template <int R, bool PURE, typename PT>
+// LEAN (with PURE) turns the apply into the two stencil passes of the q-free CG iteration, the
+// capacity mode that stores x, r, p only (25 B/voxel): LEAN = 1 reduces p.Ap without storing q;
+// LEAN = 2 recomputes q = A p on the fly and applies x += alpha p, r -= alpha q (`q` argument = r
+// vector), partials {r.r, r.z}.  Both take a CG vector and are predicated on the code byte.
+template <int R, bool PURE, typename PT, int LEAN = 0>
 __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                        const double* __restrict__ r, const PT* __restrict__ p_in,
                                                        PT* __restrict__ p_out, double* __restrict__ q, int jacobi,
@@ -643,11 +648,13 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
   if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
   const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
 
-  double beta = 0.0, alpha_prev = 0.0;
+  static_assert(LEAN == 0 || PURE, "the lean passes are forms of the stand-alone apply");
+  double beta = 0.0, alpha_prev = 0.0, alpha_now = 0.0;
   if (!PURE && k > 0) {
     beta = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * (k - 1) + H_RZ]);
     alpha_prev = safe_div(hist[H_STRIDE * (k - 1) + H_RZ], hist[H_STRIDE * (k - 1) + H_PQ]);
   }
+  if (LEAN == 2) alpha_now = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = tx * kBX + 2 * lane, j0 = ty * BY;
@@ -665,7 +672,8 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
   // on the code byte, so cache lines without a free voxel are never moved.  The PURE apply takes any v
   // (the solution with its Dirichlet values included) and reads everything.
   auto pnew_at = [&](long long e) -> double {
-    if (PURE) return r[e];
+    if (PURE && LEAN == 0) return r[e];
+    if (PURE) return code[e] ? r[e] : 0.0;
     const unsigned c = code[e];
     if (!c) return 0.0;
     double z = r[e];
@@ -684,8 +692,9 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
         cn[rr_] = cc;
-        if (PURE) { pn[rr_] = ld2(r + e); continue; }
+        if (PURE && LEAN == 0) { pn[rr_] = ld2(r + e); continue; }
         if (!cc) continue;
+        if (PURE) { pn[rr_] = ld2(r + e); continue; }
         const double2 rv = ld2(r + e);
         pin[rr_] = PIo<PT>::ld_pair(p_in + e);
         double z0 = rv.x, z1 = rv.y;
@@ -731,7 +740,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
   stage(gs & 1, gs, pn_cur);
   __syncthreads();
 
-  double pq = 0.0;
+  double pq = 0.0, pz = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
     load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
@@ -740,7 +749,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       const unsigned short cc = cc_cur[rr_];
-      if (PURE ? (in_x && j < g.ny) : (cc != 0)) {
+      if ((PURE && LEAN == 0) ? (in_x && j < g.ny) : (cc != 0)) {
         const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
         const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
@@ -753,7 +762,21 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + pn_prev[rr_].y) + pn_nxt[rr_].y;
         const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
         const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
-        st2(q + e, q0, q1);
+        if (LEAN == 2) {
+          const double2 rv = ld2(q + e), xv = ld2(x + e);
+          const double r0 = rv.x - alpha_now * q0, r1 = rv.y - alpha_now * q1;
+          st2(q + e, r0, r1);
+          st2(x + e, xv.x + alpha_now * pc.x, xv.y + alpha_now * pc.y);
+          double z0 = r0, z1 = r1;
+          if (jacobi) {
+            if (c0) z0 = r0 / (double)c0;
+            if (c1) z1 = r1 / (double)c1;
+          }
+          pq += r0 * r0; pq += r1 * r1;
+          pz += r0 * z0; pz += r1 * z1;
+          continue;
+        }
+        if (LEAN == 0) st2(q + e, q0, q1);
         if (!PURE) {
           PIo<PT>::st_pair(p_out + e, pc.x, pc.y);
           if (k > 0) {
@@ -773,7 +796,12 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     __syncthreads();
   }
   const double t = block_sum(pq, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  if (LEAN == 2) {
+    const double t2 = block_sum(pz, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = t; partials[2 * blockIdx.x + 1] = t2; }
+  } else if (threadIdx.x == 0) {
+    partials[blockIdx.x] = t;
+  }
 }
 
 // Defaults from the 1024^3 sweep in profiles/r01/tile_sweep.txt: 16-row tiles for the CG
@@ -790,15 +818,15 @@ void set_apply_tuning(int tile_rows) {
   if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_pure_rows = tile_rows / 8;
 }
 
-template <int R, bool PURE, typename PT>
+template <int R, bool PURE, typename PT, int LEAN>
 static void launch_tiled_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
                            void* p_out, double* q, int jacobi, const double* hist, int k, int zchunk, int tiles_x,
                            int tiles_y, int nzc, double* partials, const Ctrl* ctrl, hipStream_t s) {
-  hipLaunchKernelGGL((k_fused_a<R, PURE, PT>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
+  hipLaunchKernelGGL((k_fused_a<R, PURE, PT, LEAN>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
                      (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
 }
 
-template <bool PURE, typename PT>
+template <bool PURE, typename PT, int LEAN = 0>
 static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
                         double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
                         hipStream_t s) {
@@ -823,15 +851,25 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
   }
   const int blocks = (int)(cols * nzc);
   if (R == 4)
-    launch_tiled_r<4, PURE, PT>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc,
-                                partials, ctrl, s);
+    launch_tiled_r<4, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
+                                      nzc, partials, ctrl, s);
   else if (R == 2)
-    launch_tiled_r<2, PURE, PT>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc,
-                                partials, ctrl, s);
+    launch_tiled_r<2, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
+                                      nzc, partials, ctrl, s);
   else
-    launch_tiled_r<1, PURE, PT>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc,
-                                partials, ctrl, s);
+    launch_tiled_r<1, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
+                                      nzc, partials, ctrl, s);
   return blocks;
+}
+
+// q-free CG passes (capacity mode): p.Ap, then x += alpha p, r -= alpha A p with partials {rr, rz}
+int launch_lean_dot(const Geom& g, const uint8_t* code, const double* p, double* partials, const Ctrl* ctrl,
+                    hipStream_t s) {
+  return launch_tiled<true, double, 1>(g, code, nullptr, p, nullptr, nullptr, nullptr, 0, nullptr, 0, partials, ctrl, s);
+}
+int launch_lean_update(const Geom& g, const uint8_t* code, const double* p, double* x, double* r, int jacobi,
+                       const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s) {
+  return launch_tiled<true, double, 2>(g, code, x, p, nullptr, nullptr, r, jacobi, hist, k, partials, ctrl, s);
 }
 
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,

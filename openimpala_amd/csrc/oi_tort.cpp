@@ -74,6 +74,7 @@ struct oi_tort {
   double *r2 = nullptr, *q2 = nullptr;  // second buffers of the single-kernel variant
   double* rec = nullptr;                // its per-iteration scalar records
   double* z = nullptr;                  // preconditioned residual of the multigrid variant
+  bool lean = false;  // OI_KERNEL_LEAN: no q vector, A p recomputed in the update pass
   oi::MgHierarchy* mg = nullptr;
   int mg_tiled = 1;  // 0 (env OI_MG_PLAIN): plain fine-level kernels, kept as a cross-check
   void* p[2] = {nullptr, nullptr};  // search direction: fp64, or fp32 storage when p_f32
@@ -342,7 +343,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap));
   OIC(dmalloc(h, &h->x, (size_t)g.nvec));
   OIC(dmalloc(h, &h->r, (size_t)g.nvec));
-  OIC(dmalloc(h, &h->q, (size_t)g.nvec));
+  if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)g.nvec));
   if (h->cg1) {
     OIC(dmalloc(h, &h->r2, (size_t)g.nvec));
     OIC(dmalloc(h, &h->q2, (size_t)g.nvec));
@@ -396,8 +397,17 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->device = device;
   h->phase_id = phase_id;
   h->jacobi = o.precond == OI_PRECOND_JACOBI;
-  h->fused = o.kernel != OI_KERNEL_UNFUSED;
+  h->lean = o.kernel == OI_KERNEL_LEAN;
+  h->fused = o.kernel != OI_KERNEL_UNFUSED && !h->lean;
   h->cg1 = o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_AUTO;  // fastest variant is the default
+  if (o.kernel < OI_KERNEL_AUTO || o.kernel > OI_KERNEL_LEAN) {
+    oi::set_error("unknown kernel variant %d", o.kernel);
+    return OI_BAD_ARG;
+  }
+  if (h->lean && o.precond == OI_PRECOND_MG) {
+    oi::set_error("the capacity mode (kernel = lean) runs plain or Jacobi-preconditioned CG");
+    return OI_BAD_ARG;
+  }
   if (o.precond == OI_PRECOND_MG) {
     // with neighbours the hierarchy keeps the slab partition (see oi_mg.hip); r's and z's ghost planes travel
     if (o.kernel == OI_KERNEL_FUSED1) {
@@ -489,7 +499,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   HIPC(hipMemcpyAsync(h->ctrl, h->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
   HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * h->hist_cap, s));
   HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, s));
-  HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
+  if (h->q) HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
   HIPC(hipMemsetAsync(h->p[0], 0, h->p_elem * g.nvec, s));
   if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * g.nvec, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
@@ -600,6 +610,18 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
     OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+  } else if (h->lean) {
+    // q-free iteration: p = z + beta p; p.Ap (nothing stored); x += alpha p, r -= alpha A p (A p recomputed)
+    double* p = (double*)h->p[0];
+    if (k > 0) {
+      PROF(K_UPDATE_P);
+      launch_update_p(g, h->code, h->r, p, h->jacobi, h->hist, k, h->ctrl, s);
+    }
+    OIC(exchange_planes(h, p, sizeof(double) * g.plane));
+    { PROF(K_APPLY); nb = launch_lean_dot(g, h->code, p, h->partials, h->ctrl, s); }
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
+    { PROF(K_UPDATE_XR); nb = launch_lean_update(g, h->code, p, h->x, h->r, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
+    OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
   } else {
     if (k > 0) {
       PROF(K_UPDATE_P);
@@ -872,6 +894,7 @@ extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q,
   if (!h || !v || !q) return OI_BAD_ARG;
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
   if (h->cg_active) return OI_BAD_ARG;
+  if (!h->q) { oi::set_error("the capacity mode keeps no A p vector: use another kernel variant for the stand-alone apply"); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
@@ -899,6 +922,7 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
   if (!h || reps < 1 || !ms_per_launch) return OI_BAD_ARG;
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
   if (h->cg_active) return OI_BAD_ARG;
+  if (!h->q) { oi::set_error("the capacity mode keeps no A p vector: use another kernel variant for the stand-alone apply"); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   // a smooth non-trivial field: the ramp (p = x0); one untimed launch warms the code path

@@ -20,7 +20,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 TIF = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")
-VARIANTS = [oia.KERNEL_FUSED, oia.KERNEL_UNFUSED, oia.KERNEL_FUSED1]
+VARIANTS = [oia.KERNEL_FUSED, oia.KERNEL_UNFUSED, oia.KERNEL_FUSED1, oia.KERNEL_LEAN]
 
 
 @pytest.fixture(scope="module")
@@ -340,3 +340,21 @@ def test_other_bundled_tiffs_match_oracle(name, pid):
         else:
             assert math.isnan(tau) and t.status == ref["status"]
         t.destroy()
+
+
+def test_capacity_mode_footprint_and_refusals(sample, goldens):
+    """KERNEL_LEAN stores x, r, p and the code bytes only (A p is recomputed in the update pass): less than
+    half the device memory of the default variant, same answer; the stand-alone apply and the multigrid
+    cycle need the vector it does not keep."""
+    g = goldens["phases"]["1"]
+    lean = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], eps=1e-10, kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_JACOBI)
+    full = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_JACOBI)
+    assert lean.value() == pytest.approx(g["tau"][0], rel=1e-7)
+    assert abs(lean.getSolverIterations() - (full.value() and full.getSolverIterations())) <= 3
+    nvec = 102 * 100 * 100
+    assert lean.stats().bytes_device < 27 * nvec and full.stats().bytes_device > 55 * nvec
+    with pytest.raises(oia.OpenImpalaError):
+        lean.apply(np.zeros(sample.shape))
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TortuosityMI355(sample, 1, 0, kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_MG)
+    lean.destroy(); full.destroy()

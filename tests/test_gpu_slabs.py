@@ -66,7 +66,7 @@ def test_slabs_match_single_domain(nranks, direction):
 
 @pytest.mark.parametrize("variant,jacobi,pf32", [(oia.KERNEL_UNFUSED, False, 0), (oia.KERNEL_FUSED, True, 0),
                                                  (oia.KERNEL_FUSED, False, 1), (oia.KERNEL_FUSED1, False, 0),
-                                                 (oia.KERNEL_FUSED1, True, 1)])
+                                                 (oia.KERNEL_FUSED1, True, 1), (oia.KERNEL_LEAN, True, 0)])
 def test_slab_variants_on_sample(sample_phase, goldens, variant, jacobi, pf32):
     g = goldens["phases"]["1"]
     sub = np.ascontiguousarray(sample_phase)
