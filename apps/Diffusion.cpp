@@ -21,6 +21,9 @@
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <random>
+#include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -143,9 +146,123 @@ int main(int argc, char* argv[]) {
       return 1;
     }
 
+    // ---- REV study, Diffusion.cpp:317-502: random cubic sub-volumes, periodic cell problems on each ----
     bool rev_study = false;
+    int rev_num_samples = 3, rev_write_plotfiles = 0, rev_verbose = 1;
+    std::string rev_sizes = "32 64 96", rev_solver = "FlexGMRES", rev_results_file = "rev_study_Deff.csv";
     in.query("rev.do_study", rev_study);
-    if (rev_study) std::cerr << "Warning: rev.do_study is not implemented by this build (REV sampling); ignored.\n";
+    in.query("rev.num_samples", rev_num_samples);
+    in.query("rev.sizes", rev_sizes);
+    in.query("rev.solver_type", rev_solver);
+    in.query("rev.results_file", rev_results_file);
+    in.query("rev.write_plotfiles", rev_write_plotfiles);
+    in.query("rev.verbose", rev_verbose);
+
+    oi_tort_opts hopts;
+    oi_tort_default_opts(&hopts);
+    if (!in.query("hypre.eps", hopts.eps)) in.query("hypre_eps", hopts.eps);
+    in.query("gpu.maxiter", hopts.maxiter);
+    in.query("gpu.device", hopts.device);
+    const char* axis_names[3] = {"X", "Y", "Z"};
+    // three chi_k solves + tensor on one (sub-)volume; false when a solve does not converge (:545-548)
+    auto homogenize = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9]) -> bool {
+      oi_tort_opts o = hopts;
+      o.verbose = vb;
+      oi_effdiff* eh = nullptr;
+      oi_status est = oi_effdiff_create(&eh, ph, nx, ny, nz, phase_id, &o);
+      if (est != OI_OK) throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error());
+      bool ok = true;
+      for (int k = 0; k < 3 && ok; ++k) {
+        if (vb >= 1) std::cout << "\n--- Solving for " << what << " chi_" << axis_names[k] << " ---\n";
+        int conv = 0, iters = 0;
+        double rel = 0.0;
+        est = oi_effdiff_solve(eh, k, &conv, &iters, &rel);
+        if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
+        if (vb >= 1)
+          std::cout << "  Solver iterations: " << iters << "\n  Final Relative Residual Norm: " << std::scientific << rel
+                    << std::defaultfloat << "\n  Solver Converged Status: " << (conv ? "Yes" : "No") << "\n";
+        if (!conv) ok = false;
+      }
+      if (ok) {
+        est = oi_effdiff_tensor(eh, D);
+        if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
+      }
+      oi_effdiff_destroy(eh);
+      return ok;
+    };
+
+    if (rev_study) {
+      if (verbose >= 1)
+        std::cout << "\n--- Starting REV Study (Homogenization Method) for Phase ID " << phase_id << " ---\n"
+                  << "  Number of samples per size: " << rev_num_samples << "\n  Target REV sizes: " << rev_sizes
+                  << "\n  REV Solver: " << rev_solver << "\n  REV Plotfiles: " << (rev_write_plotfiles ? "Yes" : "No") << std::endl;
+      (void)solver_from_string(rev_solver);
+      std::vector<int> sizes;
+      {
+        std::stringstream ss(rev_sizes);
+        int v;
+        while (ss >> v) sizes.push_back(v);
+      }
+      if (sizes.empty()) {
+        std::cerr << "Warning: REV sizes string is empty or invalid. Skipping REV study.\n";  // :332
+      } else {
+        std::ofstream csv(results_dir / rev_results_file);
+        csv << "SampleNo,SeedX,SeedY,SeedZ,REV_Size_Target,ActualSizeX,ActualSizeY,ActualSizeZ,D_xx,D_yy,D_zz,D_xy,D_xz,D_yz\n";
+        std::mt19937 gen(0 + 12345 + rev_num_samples);  // MyProc() + 12345 + num_samples (:341), one process here
+        const int dims[3] = {vol.nx, vol.ny, vol.nz};
+        std::vector<uint8_t> sub;
+        for (int s_idx = 0; s_idx < rev_num_samples; ++s_idx) {
+          for (int target : sizes) {
+            int lo[3], len[3];
+            for (int d = 0; d < 3; ++d) {  // :346-355: uniform seed so that the box fits, else the domain corner
+              const int max_coord = dims[d] - 1 - (target - 1);
+              if (0 > max_coord || target > dims[d]) {
+                lo[d] = 0;
+              } else {
+                std::uniform_int_distribution<> distr(0, max_coord);
+                lo[d] = distr(gen);
+              }
+              len[d] = std::max(0, std::min(lo[d] + target, dims[d]) - lo[d]);  // box &= domain (:359)
+            }
+            const int longside = std::max(len[0], std::max(len[1], len[2]));
+            if (len[0] <= 0 || len[1] <= 0 || len[2] <= 0 || longside < 8) {  // :361-368
+              if (rev_verbose >= 1)
+                std::cerr << "Warning: Skipping REV for sample " << s_idx + 1 << " target size " << target
+                          << " due to small/empty box after intersection\n";
+              continue;
+            }
+            if (rev_verbose >= 1)
+              std::cout << " REV Sample " << s_idx + 1 << ", Target Size " << target << ", Seed Lo (global): (" << lo[0] << ","
+                        << lo[1] << "," << lo[2] << "), Actual REV Box (global): ((" << lo[0] << "," << lo[1] << "," << lo[2]
+                        << ") (" << lo[0] + len[0] - 1 << "," << lo[1] + len[1] - 1 << "," << lo[2] + len[2] - 1 << "))" << std::endl;
+            sub.resize((size_t)len[0] * len[1] * len[2]);
+            for (int k = 0; k < len[2]; ++k)
+              for (int j = 0; j < len[1]; ++j)
+                std::memcpy(&sub[((size_t)k * len[1] + j) * len[0]],
+                            &vol.phase[((size_t)(lo[2] + k) * vol.ny + (lo[1] + j)) * vol.nx + lo[0]], (size_t)len[0]);
+            double D[9];
+            for (double& v : D) v = std::numeric_limits<double>::quiet_NaN();  // :465-466
+            bool ok = false;
+            try {
+              ok = homogenize(sub.data(), len[0], len[1], len[2], rev_verbose >= 2 ? rev_verbose : 0, "REV", D);
+              if (!ok && rev_verbose >= 1) std::cout << "    REV Chi solve FAILED" << std::endl;
+            } catch (const std::exception& e) {
+              std::cout << "    REV Chi solve EXCEPTION: " << e.what() << std::endl;  // :459-461
+            }
+            if (!ok) for (double& v : D) v = std::numeric_limits<double>::quiet_NaN();
+            csv << s_idx + 1 << "," << lo[0] << "," << lo[1] << "," << lo[2] << "," << target << "," << len[0] << "," << len[1]
+                << "," << len[2] << "," << std::fixed << std::setprecision(8) << D[0] << "," << D[4] << "," << D[8] << ","
+                << D[1] << "," << D[2] << "," << D[5] << "\n";
+            csv.flush();
+          }
+        }
+      }
+    }
+    if (rev_study && method == "skip_if_rev") {  // :505
+      const double secs_r = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+      std::cout << std::endl << "Total run time (seconds) = " << secs_r << std::endl;
+      return 0;
+    }
 
     if (method == "homogenization") {
       // ---- Diffusion.cpp:509-589: three periodic cell problems chi_k, then the D_eff tensor ----
@@ -154,32 +271,8 @@ int main(int argc, char* argv[]) {
         std::cout << "\n--- Effective Diffusivity via Homogenization (Full Domain) ---\n";
       }
       (void)solver_from_string(solver_str);  // invalid names abort in the reference (:45-58)
-      oi_tort_opts hopts;
-      oi_tort_default_opts(&hopts);
-      if (!in.query("hypre.eps", hopts.eps)) in.query("hypre_eps", hopts.eps);
-      in.query("gpu.maxiter", hopts.maxiter);
-      in.query("gpu.device", hopts.device);
-      hopts.verbose = verbose;
-      oi_effdiff* eh = nullptr;
-      oi_status est = oi_effdiff_create(&eh, vol.phase.data(), vol.nx, vol.ny, vol.nz, phase_id, &hopts);
-      if (est != OI_OK) throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error());
-      bool all_converged = true;
-      const char* names[3] = {"X", "Y", "Z"};
-      for (int k = 0; k < 3 && all_converged; ++k) {
-        if (verbose >= 1) std::cout << "\n--- Solving for Full Domain chi_" << names[k] << " ---\n";
-        int conv = 0, iters = 0;
-        double rel = 0.0;
-        est = oi_effdiff_solve(eh, k, &conv, &iters, &rel);
-        if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
-        if (verbose >= 1)
-          std::cout << "  Solver iterations: " << iters << "\n  Final Relative Residual Norm: " << std::scientific << rel
-                    << std::defaultfloat << "\n  Solver Converged Status: " << (conv ? "Yes" : "No") << "\n";
-        if (!conv) all_converged = false;  // :545-548
-      }
-      if (all_converged) {
-        double D[9];
-        est = oi_effdiff_tensor(eh, D);
-        if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
+      double D[9];
+      if (homogenize(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D)) {
         std::cout << "Full Domain Effective Diffusivity Tensor D_eff / D_material:\n";  // :573-582
         for (int r = 0; r < 3; ++r) {
           std::cout << "  [";
@@ -194,7 +287,6 @@ int main(int argc, char* argv[]) {
       } else {
         std::cout << "Full domain D_eff calculation skipped due to chi_k non-convergence.\n";  // :587-589
       }
-      oi_effdiff_destroy(eh);
       const double secs_h = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
       std::cout << std::endl << "Total run time (seconds) = " << std::defaultfloat << secs_h << std::endl;
       return 0;

@@ -128,3 +128,45 @@ hypre.eps = 1e-10
     assert "Full Domain Effective Diffusivity Tensor D_eff / D_material:" in r.stdout
     got = np.loadtxt(tmp_path / "res" / "Deff_tensor.txt")
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_diffusion_rev_study(app, tmp_path):
+    """rev.do_study (Diffusion.cpp:317-502): random cubic sub-volumes with periodic cell problems, one CSV
+    row per (sample, size); a row is checked against the oracle on the same crop, oversized targets are
+    clipped to the domain, calculation_method = skip_if_rev ends after the study."""
+    import numpy as np
+    from oracle import oracle as o
+    tif = os.path.join(GOLDEN, "SampleData_2Phase_squared.tif")  # 64^3
+    phase = o.read_tiff_phase(tif)
+    text = f"""
+filename = SampleData_2Phase_squared.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+calculation_method = skip_if_rev
+hypre.eps = 1e-10
+rev.do_study = 1
+rev.num_samples = 2
+rev.sizes = "24 40 100"
+rev.verbose = 1
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "--- Starting REV Study (Homogenization Method) for Phase ID 1 ---" in r.stdout
+    assert "Full Domain" not in r.stdout
+    lines = open(tmp_path / "res" / "rev_study_Deff.csv").read().splitlines()
+    assert lines[0] == "SampleNo,SeedX,SeedY,SeedZ,REV_Size_Target,ActualSizeX,ActualSizeY,ActualSizeZ,D_xx,D_yy,D_zz,D_xy,D_xz,D_yz"
+    rows = [l.split(",") for l in lines[1:]]
+    assert [(int(r_[0]), int(r_[4])) for r_ in rows] == [(1, 24), (1, 40), (1, 100), (2, 24), (2, 40), (2, 100)]
+    for r_ in rows:
+        sx, sy, sz, target, ax, ay, az = (int(v) for v in r_[1:8])
+        if target <= 64:
+            assert (ax, ay, az) == (target,) * 3 and all(0 <= s <= 64 - target for s in (sx, sy, sz))
+        else:  # larger than the domain: the corner seed and the whole domain (:350-359)
+            assert (sx, sy, sz) == (0, 0, 0) and (ax, ay, az) == (64, 64, 64)
+    sx, sy, sz = (int(v) for v in rows[0][1:4])
+    want, _ = o.effective_diffusivity(np.ascontiguousarray(phase[sz:sz + 24, sy:sy + 24, sx:sx + 24]), 1, eps=1e-10)
+    got = [float(v) for v in rows[0][8:14]]
+    np.testing.assert_allclose(got, [want[0][0], want[1][1], want[2][2], want[0][1], want[0][2], want[1][2]], rtol=0, atol=2e-8)
+    full, _ = o.effective_diffusivity(phase, 1, eps=1e-10)
+    np.testing.assert_allclose([float(v) for v in rows[2][8:11]], [full[0][0], full[1][1], full[2][2]], rtol=0, atol=2e-8)
