@@ -24,6 +24,7 @@
 #include <random>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -358,11 +359,29 @@ int main(int argc, char* argv[]) {
 
     std::map<std::string, double> results;  // std::map: alphabetical X, Y, Z as in the reference
     const auto solver_type = solver_from_string(solver_str);
+    // one upload of the phase bytes for all directions (each direction is still a new solver object:
+    // mask, hierarchy, solve -- as in the reference, Diffusion.cpp:655-706)
+    struct DevBuf {
+      void* p = nullptr;
+      ~DevBuf() { if (p) oi_dev_free(p); }
+    } dev_phase;
+    const bool share_upload = opts.device <= 0;  // oi_dev_malloc allocates on the current (= default) device
+    if (!dirs.empty() && share_upload) {
+      oi_status ds = oi_dev_malloc(&dev_phase.p, vol.phase.size());
+      if (ds == OI_OK) ds = oi_dev_upload(dev_phase.p, vol.phase.data(), vol.phase.size());
+      if (ds != OI_OK) throw std::runtime_error(std::string(oi_status_string(ds)) + ": " + oi_last_error());
+    }
     for (const auto dir : dirs) {
       const std::string dc = dir == OpenImpala::Direction::X ? "X" : (dir == OpenImpala::Direction::Y ? "Y" : "Z");
       if (verbose >= 1) std::cout << "\n--- Solving for Tortuosity in Direction: " << dc << " ---\n";
-      OpenImpala::TortuosityMI355 solver(vol.phase.data(), vol.nx, vol.ny, vol.nz, volume_fraction, phase_id, dir,
-                                         solver_type, results_path, vlo, vhi, tverbose, write_plotfile != 0, &opts);
+      using TM = OpenImpala::TortuosityMI355;
+      std::unique_ptr<TM> solver_ptr(
+          share_upload ? new TM(TM::DevicePhase{static_cast<const std::uint8_t*>(dev_phase.p)}, vol.nx, vol.ny, vol.nz,
+                                volume_fraction, phase_id, dir, solver_type, results_path, vlo, vhi, tverbose,
+                                write_plotfile != 0, &opts)
+                       : new TM(vol.phase.data(), vol.nx, vol.ny, vol.nz, volume_fraction, phase_id, dir, solver_type,
+                                results_path, vlo, vhi, tverbose, write_plotfile != 0, &opts));
+      TM& solver = *solver_ptr;
       const double tau = solver.value();
       results["Tortuosity_" + dc] = tau;
       if (verbose >= 1) {

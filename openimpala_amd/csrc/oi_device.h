@@ -141,6 +141,8 @@ void launch_sum_f32_ranks(float* dst, const float* const* srcs_host, int nsrc, s
 void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipStream_t s);
 void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipStream_t s);
 void launch_codes_out(const Geom& g, const uint8_t* code, uint8_t* dense, hipStream_t s);
+// one relaxation sweep of the (sequentially defined) remspot pass, see oi_kernels.hip
+void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nz, int* changed, hipStream_t s);
 // *out += number of aligned x-groups of `group` voxels (owned planes) with at least one free voxel
 void launch_count_live_groups(const Geom& g, const uint8_t* code, int group, unsigned long long* out, hipStream_t s);
 

@@ -1627,6 +1627,32 @@ void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipS
   hipLaunchKernelGGL(k_pitch_out, dim3(cap_blocks((long long)g.nzl * g.ny * g.nx, 256, 8192)), dim3(256), 0, s, g,
                      vec, dense);
 }
+// tortuosity_remspot (Tortuosity_filcc.F90:88-177) is sequential: voxels are visited x-fastest and a
+// flip is seen by the voxels visited later.  Voxel m therefore depends on the NEW values of its -x/-y/-z
+// neighbours and the OLD values of its +x/+y/+z neighbours: a triangular system.  Sweeping
+//     cur[m] = f(old[m]; cur[m-1], cur[m-sy], cur[m-sz]; old[m+1], old[m+sy], old[m+sz])
+// in any order converges to its unique solution (= the sequential result) in as many sweeps as the
+// longest chain of flipped voxels, a handful in practice; `changed` counts the updates of a sweep.
+__global__ void __launch_bounds__(256) k_remspot_sweep(const uint8_t* __restrict__ old, uint8_t* __restrict__ cur, int nx,
+                                                        int ny, int nz, int* __restrict__ changed) {
+  const long long n = (long long)nx * ny * nz, sy = nx, sz = (long long)nx * ny;
+  int ch = 0;
+  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(m % nx), j = (int)((m / nx) % ny), k = (int)(m / sz);
+    const uint8_t c = old[m];
+    const bool connected = (i > 0 && cur[m - 1] == c) || (i < nx - 1 && old[m + 1] == c) ||
+                           (j > 0 && cur[m - sy] == c) || (j < ny - 1 && old[m + sy] == c) ||
+                           (k > 0 && cur[m - sz] == c) || (k < nz - 1 && old[m + sz] == c);
+    const uint8_t v = connected ? c : (uint8_t)(c == 0 ? 1 : 0);
+    if (cur[m] != v) { cur[m] = v; ch = 1; }
+  }
+  if (ch) atomicOr(changed, 1);
+}
+void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nz, int* changed, hipStream_t s) {
+  hipLaunchKernelGGL(k_remspot_sweep, dim3(cap_blocks((long long)nx * ny * nz, 256, 8192)), dim3(256), 0, s, old, cur, nx,
+                     ny, nz, changed);
+}
+
 // counts the aligned groups of `group` voxels (along x, within a row) of the owned planes that hold at
 // least one free voxel: the cache lines of r/q/p/x the solver kernels cannot skip
 __global__ void __launch_bounds__(256) k_count_live_groups(Geom g, const uint8_t* __restrict__ code, int group,

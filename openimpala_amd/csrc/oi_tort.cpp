@@ -438,27 +438,65 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   return OI_OK;
 }
 
-extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes);
+// preconditionPhaseFab (TortuosityHypre.cpp:248-292): `passes` remspot passes on a private copy of the
+// phase field, on the device (dense nx*ny*nz bytes).  *out_dev is hipMalloc'ed.
+static oi_status remspot_private_copy(const uint8_t* phase, bool on_device, int nx, int ny, int nz, int passes,
+                                      int device_opt, uint8_t** out_dev) {
+  int device = 0;
+  OIC(ensure_device(device_opt, &device));
+  const size_t n = (size_t)nx * ny * nz;
+  uint8_t *old = nullptr, *cur = nullptr;
+  int *changed = nullptr, *h_changed = nullptr;
+  oi_status rc = OI_OK;
+  do {
+    if (hipMalloc((void**)&old, n) != hipSuccess || hipMalloc((void**)&cur, n) != hipSuccess ||
+        hipMalloc((void**)&changed, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&h_changed, sizeof(int)) != hipSuccess ||
+        hipMemcpy(old, phase, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess) {
+      rc = OI_HIP_ERROR;
+      break;
+    }
+    for (int pass = 0; pass < passes && rc == OI_OK; ++pass) {
+      if (hipMemcpy(cur, old, n, hipMemcpyDeviceToDevice) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+      for (long long sweep = 0;; ++sweep) {
+        if (hipMemset(changed, 0, sizeof(int)) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+        launch_remspot_sweep(old, cur, nx, ny, nz, changed, nullptr);
+        if (hipMemcpy(h_changed, changed, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+        if (!*h_changed) break;
+        if (sweep > (long long)nx + ny + nz + 8) { oi::set_error("remspot relaxation did not settle"); rc = OI_HIP_ERROR; break; }
+      }
+      std::swap(old, cur);  // the settled field is the input of the next pass
+    }
+  } while (0);
+  if (rc == OI_HIP_ERROR && !*oi::last_error()) oi::set_error("remspot: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (cur) (void)hipFree(cur);
+  if (changed) (void)hipFree(changed);
+  if (h_changed) (void)hipHostFree(h_changed);
+  if (rc != OI_OK) { if (old) (void)hipFree(old); return rc; }
+  *out_dev = old;
+  return OI_OK;
+}
+
+static oi_status create_whole(oi_tort** out, const uint8_t* phase, bool on_device, int nx, int ny, int nz, int phase_id,
+                              int dir, double vlo, double vhi, const oi_tort_opts* opts) {
+  if (opts && opts->remspot_passes > 0 && phase && nx > 0 && ny > 0 && nz > 0) {
+    uint8_t* priv = nullptr;
+    OIC(remspot_private_copy(phase, on_device, nx, ny, nz, opts->remspot_passes, opts->device, &priv));
+    const oi_status st = create_common(out, nullptr, priv, true, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+    (void)hipFree(priv);
+    return st;
+  }
+  return create_common(out, nullptr, phase, on_device, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+}
 
 extern "C" oi_status oi_tort_create(oi_tort** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
                                     int dir, double vlo, double vhi, const oi_tort_opts* opts) {
-  if (opts && opts->remspot_passes > 0 && phase && nx > 0 && ny > 0 && nz > 0) {
-    // preconditionPhaseFab (TortuosityHypre.cpp:248-292) works on the solver's private copy
-    std::vector<uint8_t> copy(phase, phase + (size_t)nx * ny * nz);
-    OIC(oi_remspot(copy.data(), nx, ny, nz, opts->remspot_passes));
-    return create_common(out, nullptr, copy.data(), false, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
-  }
-  return create_common(out, nullptr, phase, false, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+  return create_whole(out, phase, false, nx, ny, nz, phase_id, dir, vlo, vhi, opts);
 }
 
 extern "C" oi_status oi_tort_create_device(oi_tort** out, const uint8_t* phase_dev, int nx, int ny, int nz,
                                            int phase_id, int dir, double vlo, double vhi,
                                            const oi_tort_opts* opts) {
-  if (opts && opts->remspot_passes > 0) {
-    oi::set_error("remspot needs the host entry point");
-    return OI_BAD_ARG;
-  }
-  return create_common(out, nullptr, phase_dev, true, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+  return create_whole(out, phase_dev, true, nx, ny, nz, phase_id, dir, vlo, vhi, opts);
 }
 
 extern "C" oi_status oi_tort_create_slab(oi_tort** out, oi_comm* comm, const uint8_t* phase, int on_device,
@@ -1071,21 +1109,16 @@ extern "C" oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phas
   return OI_OK;
 }
 
-// tortuosity_remspot (Tortuosity_filcc.F90:88-177): in place, x-fastest order, one box.
+// tortuosity_remspot (Tortuosity_filcc.F90:88-177) on a host array: in place, x-fastest order, one box.
+// Runs on the device like everything else (no CPU path).
 extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes) {
-  if (!q || nx < 1 || ny < 1 || nz < 1) return OI_BAD_ARG;
-  const long long sy = nx, sz = (long long)nx * ny;
-  for (int pass = 0; pass < passes; ++pass)
-    for (int k = 0; k < nz; ++k)
-      for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i) {
-          const long long m = i + sy * j + sz * k;
-          const uint8_t c = q[m];
-          const bool connected = (i > 0 && q[m - 1] == c) || (i < nx - 1 && q[m + 1] == c) ||
-                                 (j > 0 && q[m - sy] == c) || (j < ny - 1 && q[m + sy] == c) ||
-                                 (k > 0 && q[m - sz] == c) || (k < nz - 1 && q[m + sz] == c);
-          if (!connected) q[m] = (c == 0) ? 1 : 0;
-        }
+  if (!q || nx < 1 || ny < 1 || nz < 1 || passes < 0) return OI_BAD_ARG;
+  if (passes == 0) return OI_OK;
+  uint8_t* dev = nullptr;
+  OIC(remspot_private_copy(q, false, nx, ny, nz, passes, -1, &dev));
+  const hipError_t e = hipMemcpy(q, dev, (size_t)nx * ny * nz, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  HIPC(e);
   return OI_OK;
 }
 

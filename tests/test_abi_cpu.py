@@ -72,10 +72,10 @@ def test_raw_reader_types(tmp_path):
         oia.RawReader(str(p), 5, 4, 4, "UINT8").threshold(1.0)  # size mismatch
 
 
-def test_remspot_matches_oracle():
-    from oracle import oracle as o
-    ph = o.gen_bernoulli((12, 10, 14), 5, 0.5)
-    assert np.array_equal(oia.remspot(ph, 2), o.remspot(ph, 2))
+def test_remspot_needs_the_device():
+    """remspot runs on the GPU like every other compute step: no CPU path to fall back to."""
+    with pytest.raises(oia.OpenImpalaError):
+        oia.remspot(np.zeros((4, 4, 4), np.uint8), 1)
 
 
 def test_slab_ranges_cover_the_volume():

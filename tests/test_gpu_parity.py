@@ -358,3 +358,31 @@ def test_capacity_mode_footprint_and_refusals(sample, goldens):
     with pytest.raises(oia.OpenImpalaError):
         oia.TortuosityMI355(sample, 1, 0, kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_MG)
     lean.destroy(); full.destroy()
+
+
+def test_remspot_on_the_device_equals_the_sequential_pass():
+    """tortuosity_remspot is defined by its x-fastest in-place order (a flip is seen by the voxels after it);
+    the device relaxation must land on exactly that result: iid noise (many isolated voxels), a 3-D
+    checkerboard (every voxel isolated: the longest possible dependency chains), several passes, ragged shapes."""
+    for shape, seed, p in (((12, 10, 14), 5, 0.5), ((33, 20, 17), 9, 0.2), ((7, 64, 40), 2, 0.8)):
+        ph = o.gen_bernoulli(shape, seed, p)
+        for passes in (1, 2, 3):
+            want = ph.copy()
+            for _ in range(passes):
+                want = o.remspot(want)
+            assert np.array_equal(oia.remspot(ph, passes), want), (shape, passes)
+    k, j, i = np.indices((9, 11, 13))
+    board = ((i + j + k) & 1).astype(np.uint8)
+    assert np.array_equal(oia.remspot(board, 1), o.remspot(board))
+    # through the solver's constructor (host and device entry points): same mask as the oracle after the pass
+    ph = o.gen_bernoulli((24, 28, 32), 3, 0.6)
+    clean = o.remspot(ph)
+    ref = o.tortuosity(clean, 1, 0, eps=1e-10)
+    t = oia.TortuosityMI355(ph, 1, 0, eps=1e-10, remspot_passes=1)
+    assert np.array_equal(t.mask(), ref["mask"]) and t.value() == pytest.approx(ref["tau"], rel=1e-8)
+    t.destroy()
+    buf = oia.DeviceBuffer(ph.size)
+    buf.upload(ph)
+    t = oia.TortuosityMI355(buf, 1, 0, shape=ph.shape, eps=1e-10, remspot_passes=1)
+    assert np.array_equal(t.mask(), ref["mask"])
+    t.destroy(); buf.free()
