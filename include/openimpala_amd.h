@@ -156,11 +156,16 @@ oi_status oi_tort_set_eps(oi_tort* h, double eps);
  * D_eff tensor built from them.  Replaces OpenImpala::EffectiveDiffusivityHypre
  * (EffectiveDiffusivityHypre.cpp: ctor + generateActiveMask :213-323, solve :543-687,
  * getChiSolution :689-; assembly EffDiffFillMtx.F90:42-264) and
- * calculate_Deff_tensor_homogenization (Diffusion.cpp:60-167).  Single GPU in this version.
+ * calculate_Deff_tensor_homogenization (Diffusion.cpp:60-167).
  * opts: eps / maxiter = hypre.eps / hypre.maxiter (defaults 1e-9 / 1000, :120,152-154). */
 typedef struct oi_effdiff oi_effdiff;
 oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
                             const oi_tort_opts* opts);
+/* One z-slab [z0, z0 + nz_local) per rank of `comm` (declared below); the ranks form a RING (periodic z:
+ * rank 0 and the last rank exchange planes too).  Collective; `phase` holds the slab's planes only, on the
+ * host or (on_device != 0) in HBM.  get_chi returns the slab, tensor / info the global values on every rank. */
+oi_status oi_effdiff_create_slab(oi_effdiff** out, oi_comm* comm, const uint8_t* phase, int on_device, int nx, int ny,
+                                 int nz_global, int z0, int nz_local, int phase_id, const oi_tort_opts* opts);
 /* solve(): *converged = 0 leaves chi_k = 0 exactly as the reference does (:641-645) */
 oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, int* iterations, double* relres);
 oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi);

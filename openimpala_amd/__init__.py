@@ -39,7 +39,7 @@ COMM_ID_BYTES = 128
 ABI_SYMBOLS = (
     "oi_tort_default_opts oi_tort_create oi_tort_create_device oi_tort_create_slab oi_tort_destroy "
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
-    "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
+    "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
@@ -115,6 +115,7 @@ def lib():
     L.oi_volume_fraction.argtypes = [vp, C.c_size_t, i, i64p, i64p]
     L.oi_remspot.argtypes = [vp, i, i, i, i]
     L.oi_effdiff_create.argtypes = [pp, vp, i, i, i, i, C.POINTER(Opts)]
+    L.oi_effdiff_create_slab.argtypes = [pp, vp, vp, i, i, i, i, i, i, i, C.POINTER(Opts)]
     L.oi_effdiff_solve.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(d)]
     L.oi_effdiff_get_chi.argtypes = [vp, i, vp]
     L.oi_effdiff_tensor.argtypes = [vp, C.POINTER(d)]
@@ -517,14 +518,22 @@ class EffectiveDiffusivityMI355:
     """Mirror of OpenImpala::EffectiveDiffusivityHypre (src/props/EffectiveDiffusivityHypre.{H,cpp})
     plus the tensor integrator of Diffusion.cpp:60-167.  One object serves all three directions."""
 
-    def __init__(self, phase, phase_id, verbose=0, **opts):
+    def __init__(self, phase, phase_id, verbose=0, comm=None, z0=0, nz_global=None, **opts):
+        """phase: uint8 (nz, ny, nx); with `comm` it is this rank's z-slab [z0, z0 + nz) of a volume of
+        nz_global planes spread over the ring of ranks (periodic z across the first and last rank)."""
         self._host = np.ascontiguousarray(phase, np.uint8)
         nz, ny, nx = self._host.shape
         self.shape = (nz, ny, nx)
         self._h = C.c_void_p()
         o = default_opts(verbose=verbose, **opts)
-        _check(lib().oi_effdiff_create(C.byref(self._h), self._host.ctypes.data_as(C.c_void_p), nx, ny, nz, phase_id,
-                                       C.byref(o)))
+        if comm is None:
+            _check(lib().oi_effdiff_create(C.byref(self._h), self._host.ctypes.data_as(C.c_void_p), nx, ny, nz,
+                                           phase_id, C.byref(o)))
+        else:
+            self._comm = comm
+            _check(lib().oi_effdiff_create_slab(C.byref(self._h), comm._h, self._host.ctypes.data_as(C.c_void_p), 0, nx,
+                                                ny, int(nz_global if nz_global is not None else nz), int(z0), nz,
+                                                phase_id, C.byref(o)))
 
     def solve(self, direction):
         """EffectiveDiffusivityHypre::solve for chi_k -> (converged, iterations, relres)."""

@@ -68,6 +68,24 @@ struct RcclComm : oi_comm {
     NCCLC(ncclGroupEnd());
     return OI_OK;
   }
+  oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,
+                          hipStream_t s) override {
+    if (size == 1) {  // my own planes wrap around
+      HIPC(hipMemcpyAsync(recv_lo, send_hi, bytes, hipMemcpyDeviceToDevice, s));
+      HIPC(hipMemcpyAsync(recv_hi, send_lo, bytes, hipMemcpyDeviceToDevice, s));
+      return OI_OK;
+    }
+    const int prev = (rank + size - 1) % size, next = (rank + 1) % size;
+    // with two ranks both neighbours are the same peer: messages between a pair match in posting
+    // order, so sends go (lo, hi) and receives (hi, lo) -- the peer's first plane is my upper ghost
+    NCCLC(ncclGroupStart());
+    NCCLC(ncclSend(send_lo, bytes, ncclInt8, prev, nccl, s));
+    NCCLC(ncclSend(send_hi, bytes, ncclInt8, next, nccl, s));
+    NCCLC(ncclRecv(recv_hi, bytes, ncclInt8, next, nccl, s));
+    NCCLC(ncclRecv(recv_lo, bytes, ncclInt8, prev, nccl, s));
+    NCCLC(ncclGroupEnd());
+    return OI_OK;
+  }
   // a one-rank communicator still goes through RCCL (identity): lets a single-GPU box
   // exercise the library's RCCL calls next to torch.distributed's own communicator
   oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) override {
@@ -163,6 +181,29 @@ struct LocalComm : oi_comm {
     if (rank > 0) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank - 1], 0));
     if (rank < size - 1) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank + 1], 0));
     sh->barrier();  // events are re-recorded by the next collective only after everyone has waited
+    return OI_OK;
+  }
+  oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,
+                          hipStream_t s) override {
+    if (size == 1) {
+      HIPC(hipMemcpyAsync(recv_lo, send_hi, bytes, hipMemcpyDeviceToDevice, s));
+      HIPC(hipMemcpyAsync(recv_hi, send_lo, bytes, hipMemcpyDeviceToDevice, s));
+      return OI_OK;
+    }
+    const int prev = (rank + size - 1) % size, next = (rank + 1) % size;
+    sh->send_lo[rank] = send_lo;
+    sh->send_hi[rank] = send_hi;
+    HIPC(hipEventRecord(sh->ev_ready[rank], s));
+    sh->barrier();
+    HIPC(hipStreamWaitEvent(s, sh->ev_ready[prev], 0));
+    HIPC(hipMemcpyAsync(recv_lo, sh->send_hi[prev], bytes, hipMemcpyDeviceToDevice, s));
+    HIPC(hipStreamWaitEvent(s, sh->ev_ready[next], 0));
+    HIPC(hipMemcpyAsync(recv_hi, sh->send_lo[next], bytes, hipMemcpyDeviceToDevice, s));
+    HIPC(hipEventRecord(sh->ev_done[rank], s));
+    sh->barrier();
+    HIPC(hipStreamWaitEvent(s, sh->ev_done[prev], 0));
+    HIPC(hipStreamWaitEvent(s, sh->ev_done[next], 0));
+    sh->barrier();
     return OI_OK;
   }
   oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) override {

@@ -19,6 +19,10 @@ struct oi_comm {
   // recv_lo); chain ends skip the missing neighbour.  Asynchronous on `s`.
   virtual oi_status exchange(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
                              size_t bytes, hipStream_t s) = 0;
+  // the same on a RING (rank 0 and rank size-1 are neighbours too): periodic z of the homogenization
+  // cell problems.  With one rank the planes wrap onto the rank's own ghosts.
+  virtual oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
+                                  size_t bytes, hipStream_t s) = 0;
   // in-place sum of n doubles resident on the device, asynchronous on `s`
   virtual oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) = 0;
   // in-place sum of a (large) float array resident on the device, asynchronous on `s`: gathers the

@@ -1,7 +1,8 @@
 // oi_effdiff.hip -- homogenization path (the reference's default calculation_method):
 // periodic cell problems chi_k and the D_eff tensor, on the same HBM layout and CG
-// building blocks as the tortuosity path.  First cut of SURVEY 8f-3: single GPU,
-// unfused iteration (periodic apply + the flat vector kernels of oi_kernels.hip).
+// building blocks as the tortuosity path: unfused iteration (periodic apply +
+// the flat vector kernels of oi_kernels.hip); z-slabs over a RING of ranks (rank 0 and the last
+// rank are neighbours: periodic z), one p-plane ring exchange and two scalar all-reduces per iteration.
 //
 // Replaces OpenImpala::EffectiveDiffusivityHypre (src/props/EffectiveDiffusivityHypre.cpp:
 // ctor/generateActiveMask :213-323, solve :543-687, getChiSolution :689-) with its Fortran
@@ -175,6 +176,7 @@ struct oi_effdiff {
   Geom g{};
   oi_tort_opts opts{};
   int device = 0, phase_id = 0;
+  oi_comm* comm = nullptr;  // ring of z-slabs (null: the whole volume lives here)
   hipStream_t stream = nullptr;
   uint8_t* code = nullptr;
   double *chi[3] = {nullptr, nullptr, nullptr}, *r = nullptr, *p = nullptr, *q = nullptr;
@@ -204,16 +206,29 @@ extern "C" void oi_effdiff_destroy(oi_effdiff* h) {
 static oi_status wrap_z(oi_effdiff* h, void* base, size_t plane_bytes) {
   char* b = (char*)base;
   const size_t nzl = (size_t)h->g.nzl;
+  if (h->comm)  // my first plane -> previous rank's upper ghost, my last plane -> next rank's lower ghost
+    return h->comm->exchange_ring(b + plane_bytes, b, b + plane_bytes * nzl, b + plane_bytes * (nzl + 1), plane_bytes,
+                                  h->stream);
   HIPC(hipMemcpyAsync(b, b + plane_bytes * nzl, plane_bytes, hipMemcpyDeviceToDevice, h->stream));
   HIPC(hipMemcpyAsync(b + plane_bytes * (nzl + 1), b + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, h->stream));
   return OI_OK;
 }
 
-extern "C" oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
-                                       const oi_tort_opts* opts) {
+// sum of per-block partials into dst (deterministic), summed over the ranks, optional convergence test
+static oi_status reduce_to(oi_effdiff* h, int nblocks, int ncomp, double* dst, bool check, int iter_done) {
+  launch_finalize(h->partials, nblocks, ncomp, dst, h->ctrl, (check && !h->comm) ? 1 : 0, iter_done, h->stream);
+  if (h->comm) {
+    OIC(h->comm->allreduce_sum_f64(dst, ncomp, h->stream));
+    if (check) launch_check_done(dst, h->ctrl, iter_done, h->stream);
+  }
+  return OI_OK;
+}
+
+static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const uint8_t* phase, bool on_device, int nx,
+                                       int ny, int nz, int z0, int nzl, int phase_id, const oi_tort_opts* opts) {
   if (!out) return OI_BAD_ARG;
   *out = nullptr;
-  if (!phase || nx < 1 || ny < 1 || nz < 1) return OI_BAD_ARG;
+  if (!phase || nx < 1 || ny < 1 || nz < 1 || nzl < 1 || z0 < 0 || z0 + nzl > nz) return OI_BAD_ARG;
   oi_tort_opts o;
   oi_tort_default_opts(&o);
   if (opts) o = *opts;
@@ -223,18 +238,20 @@ extern "C" oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, i
     oi::set_error("no HIP device visible: this library has no CPU fallback");
     return OI_NO_DEVICE;
   }
-  if (o.device >= 0) HIPC(hipSetDevice(o.device));
+  if (comm) HIPC(hipSetDevice(comm->device));
+  else if (o.device >= 0) HIPC(hipSetDevice(o.device));
   std::unique_ptr<oi_effdiff, void (*)(oi_effdiff*)> h(new oi_effdiff(), oi_effdiff_destroy);
   HIPC(hipGetDevice(&h->device));
   h->opts = o;
   h->phase_id = phase_id;
+  h->comm = (comm && comm->size > 1) ? comm : nullptr;
   Geom& g = h->g;
-  g.nx = nx; g.ny = ny; g.nz = nz; g.z0 = 0; g.nzl = nz; g.dir = 0;
+  g.nx = nx; g.ny = ny; g.nz = nz; g.z0 = z0; g.nzl = nzl; g.dir = 0;
   g.pitch = (nx + 1) & ~1;
   g.W = (nx + 63) / 64;
   g.plane = (long long)g.pitch * ny;
   g.wplane = (long long)g.W * ny;
-  g.nvec = (long long)(nz + 2) * g.plane;
+  g.nvec = (long long)(nzl + 2) * g.plane;
   g.nwords = 0;
   g.vlo = 0; g.vhi = 0;
   // the reference's default budget is 1000 multigrid-preconditioned iterations (:120); CG on this
@@ -255,19 +272,36 @@ extern "C" oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, i
   HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
   HIPC(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), s));
   for (int k = 0; k < 3; ++k) HIPC(hipMemsetAsync(h->chi[k], 0, sizeof(double) * g.nvec, s));
-  const size_t n = (size_t)nx * ny * nz;
+  const size_t n = (size_t)nx * ny * nzl;
   uint8_t* tmp = nullptr;
-  HIPC(hipMalloc((void**)&tmp, n));
-  HIPC(hipMemcpyAsync(tmp, phase, n, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_ed_codes, dim3(nblocks((long long)n, 8192)), dim3(256), 0, s, g, tmp, phase_id, h->code, h->counter);
+  const uint8_t* dphase = phase;
+  if (!on_device) {
+    HIPC(hipMalloc((void**)&tmp, n));
+    HIPC(hipMemcpyAsync(tmp, phase, n, hipMemcpyHostToDevice, s));
+    dphase = tmp;
+  }
+  hipLaunchKernelGGL(k_ed_codes, dim3(nblocks((long long)n, 8192)), dim3(256), 0, s, g, dphase, phase_id, h->code, h->counter);
   OIC(wrap_z(h.get(), h->code, (size_t)g.plane));
   unsigned long long cnt = 0;
   HIPC(hipMemcpyAsync(&cnt, h->counter, sizeof(cnt), hipMemcpyDeviceToHost, s));
   HIPC(hipStreamSynchronize(s));
-  HIPC(hipFree(tmp));
+  if (tmp) HIPC(hipFree(tmp));
+  if (h->comm) OIC(h->comm->allreduce_sum_u64_host(&cnt, 1, s));
   h->n_active = (long long)cnt;
   *out = h.release();
   return OI_OK;
+}
+
+extern "C" oi_status oi_effdiff_create(oi_effdiff** out, const uint8_t* phase, int nx, int ny, int nz, int phase_id,
+                                       const oi_tort_opts* opts) {
+  return effdiff_create_common(out, nullptr, phase, false, nx, ny, nz, 0, nz, phase_id, opts);
+}
+
+// one z-slab [z0, z0 + nz_local) of a volume spread over the ranks of `comm` (collective)
+extern "C" oi_status oi_effdiff_create_slab(oi_effdiff** out, oi_comm* comm, const uint8_t* phase, int on_device, int nx,
+                                            int ny, int nz_global, int z0, int nz_local, int phase_id,
+                                            const oi_tort_opts* opts) {
+  return effdiff_create_common(out, comm, phase, on_device != 0, nx, ny, nz_global, z0, nz_local, phase_id, opts);
 }
 
 // EffectiveDiffusivityHypre::solve (EffectiveDiffusivityHypre.cpp:543-687) for direction k.
@@ -299,7 +333,7 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
   Ctrl c;
   c.done = 0; c.pad = 0; c.tol2 = std::numeric_limits<double>::infinity();  // set once ||b|| is known
   HIPC(hipMemcpyAsync(h->ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice, s));
-  launch_finalize(h->partials, nb0, 2, h->hist + H_RR, nullptr, 0, 0, s);
+  OIC(reduce_to(h, nb0, 2, h->hist + H_RR, false, 0));
   double bb = 0.0;
   HIPC(hipMemcpyAsync(&bb, h->hist + H_RR, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPC(hipStreamSynchronize(s));
@@ -319,9 +353,9 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
         if (k > 0) launch_update_p(g, h->code, h->r, h->p, 0, h->hist, k, h->ctrl, s);
         OIC(wrap_z(h, h->p, sizeof(double) * g.plane));
         hipLaunchKernelGGL(k_ed_apply, dim3(nb0), dim3(256), 0, s, g, h->code, h->p, h->q, h->partials, h->ctrl);
-        launch_finalize(h->partials, nb0, 1, h->hist + H_STRIDE * k + H_PQ, h->ctrl, 0, 0, s);
+        OIC(reduce_to(h, nb0, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
         const int nb = launch_update_xr(g, h->code, chi, h->r, h->p, h->q, 0, h->hist, k, h->partials, h->ctrl, s);
-        launch_finalize(h->partials, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, h->ctrl, 1, k + 2, s);
+        OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
       }
       HIPC(hipMemcpyAsync(&seen, h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
       HIPC(hipStreamSynchronize(s));
@@ -373,6 +407,7 @@ extern "C" oi_status oi_effdiff_tensor(oi_effdiff* h, double* deff9) {
   hipLaunchKernelGGL(k_ed_tensor, dim3(nb), dim3(256), 0, h->stream, g, h->code, h->chi[0], h->chi[1], h->chi[2],
                      h->partials);
   launch_finalize(h->partials, nb, 9, h->scal, nullptr, 0, 0, h->stream);
+  if (h->comm) OIC(h->comm->allreduce_sum_f64(h->scal, 9, h->stream));
   double sums[9];
   HIPC(hipMemcpyAsync(sums, h->scal, sizeof(sums), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));

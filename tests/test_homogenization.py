@@ -78,3 +78,44 @@ def test_gpu_homogenization_edge_cases():
     assert not conv and it == 2 and np.all(h.getChiSolution(0) == 0.0)
     with pytest.raises(oia.OpenImpalaError):
         h.tensor()                                                          # chi_y, chi_z missing
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_gpu_homogenization_on_a_ring_of_slabs(sample_phase, nranks):
+    """z-slabs over a ring of ranks (in-process transport: host threads on one GPU): periodic z crosses
+    the first/last rank, every rank reports the global tensor, chi slabs concatenate to the single-domain field."""
+    import threading
+    import openimpala_amd as oia
+    sub = np.ascontiguousarray(sample_phase[:37, :28, :45])
+    nz = sub.shape[0]
+    want, its = o.effective_diffusivity(sub, 1, eps=1e-10)
+    comms = oia.Comm.create_local(nranks)
+    out, err = [None] * nranks, []
+
+    def work(r):
+        try:
+            z0, z1 = oia.slab_range(nz, nranks, r)
+            h = oia.EffectiveDiffusivityMI355(np.ascontiguousarray(sub[z0:z1]), 1, eps=1e-10, comm=comms[r], z0=z0, nz_global=nz)
+            res = [h.solve(k) for k in range(3)]
+            out[r] = dict(res=res, D=h.tensor(), chi=[h.getChiSolution(k) for k in range(3)])
+            h.destroy()
+        except Exception as e:
+            err.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "slab threads hung"
+    assert not err, err
+    for c in comms:
+        c.destroy()
+    for r in range(nranks):
+        assert all(conv for conv, _, _ in out[r]["res"])
+        assert [it for _, it, _ in out[r]["res"]] == [it for _, it, _ in out[0]["res"]]
+        assert np.array_equal(out[r]["D"], out[0]["D"])
+    assert all(abs(it - its[k]) <= 2 for k, (_, it, _) in enumerate(out[0]["res"]))
+    np.testing.assert_allclose(out[0]["D"], want, rtol=0, atol=1e-9)
+    for k in range(3):
+        chi, ok, _, _ = o.effdiff_solve(sub, 1, k, eps=1e-10)
+        np.testing.assert_allclose(np.concatenate([out[r]["chi"][k] for r in range(nranks)]), chi, rtol=0, atol=1e-9)
