@@ -25,6 +25,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -333,6 +334,18 @@ int main(int argc, char* argv[]) {
     if (opts.kernel == OI_KERNEL_LEAN && opts.precond == OI_PRECOND_MG) opts.precond = OI_PRECOND_JACOBI;  // capacity mode: CG
     if (opts.precond == OI_PRECOND_MG && opts.kernel == OI_KERNEL_FUSED1) opts.kernel = OI_KERNEL_AUTO;  // the cycle sits between the two kernels
     in.query("gpu.device", opts.device);
+    // gpu.ngpus > 1: one host thread per GPU, z-slabs, RCCL over xGMI (the reference's mpirun -np N);
+    // gpu.transport = local keeps all slabs on ONE GPU (in-process transport: a rehearsal of the slab path)
+    int ngpus = 1;
+    std::string transport = "rccl";
+    in.query("gpu.ngpus", ngpus);
+    in.query("gpu.transport", transport);
+    if (ngpus < 1 || ngpus > 64 || ngpus > vol.nz) throw std::runtime_error("gpu.ngpus must be between 1 and min(64, nz)");
+    if (transport != "rccl" && transport != "local") throw std::runtime_error("gpu.transport must be rccl or local");
+    if (ngpus > 1 && transport == "rccl" && oi_device_count() < ngpus)
+      throw std::runtime_error("gpu.ngpus = " + std::to_string(ngpus) + " but only " + std::to_string(oi_device_count()) +
+                               " GPU(s) are visible (gpu.transport = local runs the slabs on one GPU)");
+    if (ngpus > 1 && opts.remspot_passes > 0) throw std::runtime_error("tortuosity.remspot_passes needs gpu.ngpus = 1");
 
     if (verbose > 0) std::cout << "Calculating Volume Fraction for Phase ID: " << phase_id << "\n";
     long long phase_voxels = 0, total_voxels = 0;
@@ -365,7 +378,7 @@ int main(int argc, char* argv[]) {
       void* p = nullptr;
       ~DevBuf() { if (p) oi_dev_free(p); }
     } dev_phase;
-    const bool share_upload = opts.device <= 0;  // oi_dev_malloc allocates on the current (= default) device
+    const bool share_upload = opts.device <= 0 && ngpus == 1;  // oi_dev_malloc allocates on the current (= default) device
     if (!dirs.empty() && share_upload) {
       oi_status ds = oi_dev_malloc(&dev_phase.p, vol.phase.size());
       if (ds == OI_OK) ds = oi_dev_upload(dev_phase.p, vol.phase.data(), vol.phase.size());
@@ -374,38 +387,108 @@ int main(int argc, char* argv[]) {
     for (const auto dir : dirs) {
       const std::string dc = dir == OpenImpala::Direction::X ? "X" : (dir == OpenImpala::Direction::Y ? "Y" : "Z");
       if (verbose >= 1) std::cout << "\n--- Solving for Tortuosity in Direction: " << dc << " ---\n";
-      using TM = OpenImpala::TortuosityMI355;
-      std::unique_ptr<TM> solver_ptr(
-          share_upload ? new TM(TM::DevicePhase{static_cast<const std::uint8_t*>(dev_phase.p)}, vol.nx, vol.ny, vol.nz,
-                                volume_fraction, phase_id, dir, solver_type, results_path, vlo, vhi, tverbose,
-                                write_plotfile != 0, &opts)
-                       : new TM(vol.phase.data(), vol.nx, vol.ny, vol.nz, volume_fraction, phase_id, dir, solver_type,
-                                results_path, vlo, vhi, tverbose, write_plotfile != 0, &opts));
-      TM& solver = *solver_ptr;
-      const double tau = solver.value();
+      double tau = std::numeric_limits<double>::quiet_NaN();
+      oi_tort_stats st{};
+      std::vector<double> phi;
+      bool have_phi = false;
+      if (ngpus == 1) {
+        using TM = OpenImpala::TortuosityMI355;
+        std::unique_ptr<TM> solver_ptr(
+            share_upload ? new TM(TM::DevicePhase{static_cast<const std::uint8_t*>(dev_phase.p)}, vol.nx, vol.ny, vol.nz,
+                                  volume_fraction, phase_id, dir, solver_type, results_path, vlo, vhi, tverbose,
+                                  write_plotfile != 0, &opts)
+                         : new TM(vol.phase.data(), vol.nx, vol.ny, vol.nz, volume_fraction, phase_id, dir, solver_type,
+                                  results_path, vlo, vhi, tverbose, write_plotfile != 0, &opts));
+        tau = solver_ptr->value();
+        st = solver_ptr->stats();
+        if (write_plotfile != 0 && st.converged) {
+          phi.resize(vol.phase.size());
+          have_phi = oi_tort_get_solution(solver_ptr->handle(), phi.data()) == OI_OK;
+        }
+      } else {
+        // ---- z-slabs: slab boundaries on multiples of 16 planes where the volume allows it (keeps the
+        // multigrid hierarchy slab-partitioned for more levels), one host thread per slab ----
+        const int N = ngpus;
+        std::vector<int> zb(N + 1, 0);
+        {
+          const int unit = (vol.nz / N >= 32) ? 16 : 1, units = vol.nz / unit;
+          for (int r = 0; r <= N; ++r) zb[r] = (int)((long long)units * r / N) * unit;
+          zb[N] = vol.nz;
+        }
+        std::vector<oi_comm*> comms(N, nullptr);
+        unsigned char uid[OI_COMM_ID_BYTES];
+        if (transport == "local") {
+          const oi_status cs = oi_comm_create_local(comms.data(), N, opts.device);
+          if (cs != OI_OK) throw std::runtime_error(std::string(oi_status_string(cs)) + ": " + oi_last_error());
+        } else {
+          const oi_status cs = oi_comm_unique_id(uid);
+          if (cs != OI_OK) throw std::runtime_error(std::string(oi_status_string(cs)) + ": " + oi_last_error());
+        }
+        if (write_plotfile != 0) phi.assign(vol.phase.size(), 0.0);
+        std::vector<double> taus(N, std::numeric_limits<double>::quiet_NaN());
+        std::vector<oi_tort_stats> stats(N);
+        std::vector<std::string> errors(N);
+        std::vector<int> got_phi(N, 0);
+        const size_t plane = (size_t)vol.nx * vol.ny;
+        auto work = [&](int r) {
+          oi_tort* h = nullptr;
+          do {
+            if (transport == "rccl") {
+              const oi_status cs = oi_comm_create(&comms[r], uid, N, r, r);
+              if (cs != OI_OK) { errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error(); break; }
+            }
+            oi_tort_opts o = opts;
+            o.verbose = r == 0 ? tverbose : 0;
+            oi_status cs = oi_tort_create_slab(&h, comms[r], vol.phase.data() + plane * zb[r], 0, vol.nx, vol.ny, vol.nz,
+                                               zb[r], zb[r + 1] - zb[r], phase_id, static_cast<int>(dir), vlo, vhi, &o);
+            if (cs != OI_OK) { errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error(); break; }
+            cs = oi_tort_value(h, 0, &taus[r]);
+            if (cs == OI_BAD_ARG || cs == OI_HIP_ERROR || cs == OI_RCCL_ERROR) {
+              errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error();
+              break;
+            }
+            oi_tort_get_stats(h, &stats[r]);
+            if (write_plotfile != 0 && stats[r].converged)
+              got_phi[r] = oi_tort_get_solution(h, phi.data() + plane * zb[r]) == OI_OK;
+          } while (0);
+          if (h) oi_tort_destroy(h);
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < N; ++r) threads.emplace_back(work, r);
+        for (auto& t : threads) t.join();
+        for (auto* c : comms)
+          if (c) oi_comm_destroy(c);
+        for (int r = 0; r < N; ++r)
+          if (!errors[r].empty()) throw std::runtime_error("slab " + std::to_string(r) + ": " + errors[r]);
+        tau = taus[0];
+        st = stats[0];
+        have_phi = write_plotfile != 0 && std::all_of(got_phi.begin(), got_phi.end(), [](int v) { return v != 0; });
+        if (verbose >= 1) {
+          std::cout << "  z-slabs over " << N << (transport == "local" ? " in-process ranks (one GPU)" : " GPUs") << ":";
+          for (int r = 0; r < N; ++r) std::cout << " [" << zb[r] << "," << zb[r + 1] << ")";
+          std::cout << "\n";
+        }
+      }
       results["Tortuosity_" + dc] = tau;
       if (verbose >= 1) {
-        const oi_tort_stats s = solver.stats();
+        const oi_tort_stats& s_ = st;
         std::cout << "  Active Volume Fraction (percolating phase " << phase_id << "): " << std::defaultfloat
-                  << std::setprecision(6) << s.active_vf << "\n";
-        std::cout << "  Solver iterations: " << s.iterations << "\n";
-        std::cout << "  Final Relative Residual Norm: " << std::scientific << s.final_relres << std::defaultfloat << "\n";
-        std::cout << "  Solver Converged Status: " << (s.converged ? "Yes" : "No") << "\n";
-        std::cout << "    Flux In  = " << std::fixed << std::setprecision(8) << s.flux_in << "\n";
-        std::cout << "    Flux Out = " << std::fixed << std::setprecision(8) << s.flux_out << "\n";
-        std::cout << "  Timings [s]: mask " << std::defaultfloat << s.t_mask_s << ", solve " << s.t_solve_s << ", flux "
-                  << s.t_flux_s << "\n";
+                  << std::setprecision(6) << s_.active_vf << "\n";
+        std::cout << "  Solver iterations: " << s_.iterations << "\n";
+        std::cout << "  Final Relative Residual Norm: " << std::scientific << s_.final_relres << std::defaultfloat << "\n";
+        std::cout << "  Solver Converged Status: " << (s_.converged ? "Yes" : "No") << "\n";
+        std::cout << "    Flux In  = " << std::fixed << std::setprecision(8) << s_.flux_in << "\n";
+        std::cout << "    Flux Out = " << std::fixed << std::setprecision(8) << s_.flux_out << "\n";
+        std::cout << "  Timings [s]: mask " << std::defaultfloat << s_.t_mask_s << ", solve " << s_.t_solve_s << ", flux "
+                  << s_.t_flux_s << "\n";
       }
-      if (write_plotfile != 0 && solver.getSolverConverged()) {
+      if (have_phi) {
         // raw potential field instead of an AMReX plotfile: f64, x fastest, + a one-line header
-        std::vector<double> phi(vol.phase.size());
-        if (oi_tort_get_solution(solver.handle(), phi.data()) == OI_OK) {
-          const auto base = results_dir / ("tortuosity_solution_" + std::to_string(static_cast<int>(dir)));
-          std::ofstream(base.string() + ".raw", std::ios::binary)
-              .write(reinterpret_cast<const char*>(phi.data()), static_cast<std::streamsize>(phi.size() * sizeof(double)));
-          std::ofstream(base.string() + ".txt") << "solution_potential float64 little-endian nx=" << vol.nx
-                                                << " ny=" << vol.ny << " nz=" << vol.nz << " x-fastest\n";
-        }
+        const auto base = results_dir / ("tortuosity_solution_" + std::to_string(static_cast<int>(dir)));
+        std::ofstream(base.string() + ".raw", std::ios::binary)
+            .write(reinterpret_cast<const char*>(phi.data()), static_cast<std::streamsize>(phi.size() * sizeof(double)));
+        std::ofstream(base.string() + ".txt") << "solution_potential float64 little-endian nx=" << vol.nx
+                                              << " ny=" << vol.ny << " nz=" << vol.nz << " x-fastest\n";
       }
       std::cout << "  >>> Calculated Tortuosity (" << dc << "): " << std::fixed << std::setprecision(8) << tau << " <<<\n";
     }

@@ -170,3 +170,36 @@ rev.verbose = 1
     np.testing.assert_allclose(got, [want[0][0], want[1][1], want[2][2], want[0][1], want[0][2], want[1][2]], rtol=0, atol=2e-8)
     full, _ = o.effective_diffusivity(phase, 1, eps=1e-10)
     np.testing.assert_allclose([float(v) for v in rows[2][8:11]], [full[0][0], full[1][1], full[2][2]], rtol=0, atol=2e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precond", ["mg", "jacobi"])
+def test_diffusion_slabs_on_one_gpu(app, tmp_path, goldens, precond):
+    """gpu.ngpus = 3 with the in-process transport: the multi-GPU code path of the app (one host thread per
+    z-slab, RCCL replaced by device-to-device copies) gives the single-GPU results file."""
+    g = goldens["phases"]["1"]
+    text = f"""
+filename = SampleData_2Phase_stack_3d_1bit.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+calculation_method = flow_through
+direction = X Z
+hypre.eps = 1e-10
+gpu.ngpus = 3
+gpu.transport = local
+gpu.precond = {precond}
+write_plotfile = 1
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text), "verbose=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    assert "z-slabs over 3 in-process ranks (one GPU): [0,32) [32,64) [64,100)" in r.stdout
+    lines = open(tmp_path / "res" / "results.txt").read().splitlines()
+    got = {k: float(v) for k, v in (l.split(": ") for l in lines[4:])}
+    assert list(got) == ["VolumeFraction", "Tortuosity_X", "Tortuosity_Z"]
+    assert got["Tortuosity_X"] == pytest.approx(g["tau"][0], rel=1e-7)
+    assert got["Tortuosity_Z"] == pytest.approx(g["tau"][2], rel=1e-7)
+    import numpy as np
+    phi = np.fromfile(tmp_path / "res" / "tortuosity_solution_2.raw").reshape(100, 100, 100)
+    assert phi.min() >= g["vlo"] - 1e-9 and phi.max() <= g["vhi"] + 1e-9 and phi[0].min() == g["vlo"]
+    r = subprocess.run([app, _inputs(tmp_path, text), "gpu.ngpus=4", "gpu.transport=rccl"], capture_output=True, text=True)
+    assert r.returncode == 1 and "GPU(s) are visible" in r.stderr
