@@ -254,6 +254,11 @@ int oi_abi_version(void);
  * (RawReader.cpp:379-491), HDF5Reader::threshold (HDF5Reader.cpp:333-402). */
 oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
                        int* bits_per_sample);
+/* planes [z0, z0 + nz_local) only (nz_local < 0: all from z0); *nz = depth of the FILE.  The file is
+ * memory-mapped, so a rank loading its z-slab of a large stack touches only those planes
+ * (slab-wise load instead of a whole-volume host staging buffer). */
+oi_status oi_read_tiff_planes(const char* path, double threshold, int z0, int nz_local, uint8_t** phase, int* nx, int* ny,
+                              int* nz, int* bits_per_sample);
 /* numbered single-slice files <base><index zero-padded to digits><suffix>, index = start_index ...
  * start_index + num_files - 1: TiffReader::readFileSequence (TiffReader.H:117-123, TiffReader.cpp:85-88,209-285) */
 oi_status oi_read_tiff_sequence(const char* base_pattern, int num_files, int start_index, int digits, const char* suffix,
@@ -266,6 +271,8 @@ enum {
 };
 oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
                       uint8_t** phase);
+oi_status oi_read_raw_planes(const char* path, int nx, int ny, int nz, int dtype, double threshold, int z0, int nz_local,
+                             uint8_t** phase);
 /* HDF5Reader::threshold (HDF5Reader.cpp:111-187,333-402): rank-3 dataset `dataset` (e.g. "image"),
  * dims (Z,Y,X) in C order; classic-format files, contiguous/compact/chunked, deflate + shuffle */
 oi_status oi_read_hdf5(const char* path, const char* dataset, double threshold, uint8_t** phase, int* nx, int* ny,

@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_sequence oi_read_raw oi_read_hdf5 oi_read_dat oi_free_host"
+    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_dat oi_free_host"
 ).split()
 
 
@@ -160,9 +160,11 @@ def lib():
     L.oi_dev_download.argtypes = [vp, vp, C.c_size_t]
     L.oi_device_count.restype = i
     L.oi_read_tiff.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.oi_read_tiff_planes.argtypes = [C.c_char_p, d, i, i, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_tiff_sequence.argtypes = [C.c_char_p, i, i, i, C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
                                         C.POINTER(i)]
     L.oi_read_raw.argtypes = [C.c_char_p, i, i, i, i, d, pp]
+    L.oi_read_raw_planes.argtypes = [C.c_char_p, i, i, i, i, d, i, i, pp]
     L.oi_read_hdf5.argtypes = [C.c_char_p, C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_dat.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_free_host.argtypes = [vp]
@@ -577,24 +579,32 @@ class TiffReader:
         self.sequence = None if num_files is None else (int(num_files), int(start_index), int(digits), suffix)
         self._meta = None
 
-    def threshold(self, raw_threshold=0.5):
-        """-> uint8 (nz, ny, nx): 1 where voxel > threshold else 0 (TiffReader.cpp:449-455)."""
+    def threshold(self, raw_threshold=0.5, z0=0, nz_local=None):
+        """-> uint8 (nz, ny, nx): 1 where voxel > threshold else 0 (TiffReader.cpp:449-455).  z0 / nz_local
+        select the planes [z0, z0 + nz_local) of a stack file (a rank's z-slab; only those pages are read)."""
         p = C.c_void_p()
         nx, ny, nz, bps = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        if self.sequence is None:
+        planes = None
+        if self.sequence is None and (z0 or nz_local is not None):
+            planes = -1 if nz_local is None else int(nz_local)
+            _check(lib().oi_read_tiff_planes(self.filename.encode(), raw_threshold, int(z0), planes, C.byref(p), C.byref(nx),
+                                             C.byref(ny), C.byref(nz), C.byref(bps)))
+            planes = nz.value - int(z0) if planes < 0 else planes
+        elif self.sequence is None:
             _check(lib().oi_read_tiff(self.filename.encode(), raw_threshold, C.byref(p), C.byref(nx), C.byref(ny),
                                       C.byref(nz), C.byref(bps)))
         else:
             nf, si, dg, sfx = self.sequence
             _check(lib().oi_read_tiff_sequence(self.filename.encode(), nf, si, dg, sfx.encode(), raw_threshold, C.byref(p),
                                                C.byref(nx), C.byref(ny), C.byref(nz), C.byref(bps)))
+        depth = nz.value if planes is None else planes
         try:
-            n = nx.value * ny.value * nz.value
+            n = nx.value * ny.value * depth
             out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()
         finally:
             lib().oi_free_host(p)
         self._meta = (nx.value, ny.value, nz.value, bps.value)
-        return out.reshape(nz.value, ny.value, nx.value)
+        return out.reshape(depth, ny.value, nx.value)
 
     def _need(self):
         if self._meta is None:
@@ -625,15 +635,18 @@ class RawReader:
     def __init__(self, filename, width, height, depth, data_type="UINT8"):
         self.filename, self.dims, self.dtype = filename, (width, height, depth), RAW_TYPES[data_type.upper()]
 
-    def threshold(self, threshold_value=0.5):
+    def threshold(self, threshold_value=0.5, z0=0, nz_local=None):
+        """z0 / nz_local: only the planes [z0, z0 + nz_local) (a rank's z-slab; only those bytes are read)."""
         p = C.c_void_p()
         nx, ny, nz = self.dims
-        _check(lib().oi_read_raw(self.filename.encode(), nx, ny, nz, self.dtype, threshold_value, C.byref(p)))
+        nzl = nz - int(z0) if nz_local is None else int(nz_local)
+        _check(lib().oi_read_raw_planes(self.filename.encode(), nx, ny, nz, self.dtype, threshold_value, int(z0), nzl,
+                                        C.byref(p)))
         try:
-            out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nx * ny * nz,)).copy()
+            out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nx * ny * nzl,)).copy()
         finally:
             lib().oi_free_host(p)
-        return out.reshape(nz, ny, nx)
+        return out.reshape(nzl, ny, nx)
 
 
 class DatReader:

@@ -11,6 +11,10 @@
 //               Deflate (8 / 32946, zlib), PackBits (32773), horizontal predictor (317 = 2);
 //               classic TIFF and BigTIFF, both byte orders.  Anything else is reported, never guessed.
 //   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -28,8 +32,37 @@ void set_error(const char* fmt, ...);
 
 namespace {
 
+// read-only view of a file: mapped, so a reader only pages in the bytes it decodes (a z-slab of a
+// multi-gigabyte stack costs its own planes, not the file)
+struct Bytes {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  bool mapped = false;
+  Bytes() = default;
+  Bytes(const Bytes&) = delete;
+  Bytes& operator=(const Bytes&) = delete;
+  ~Bytes() { if (mapped && p) munmap(const_cast<uint8_t*>(p), n); }
+  bool open(const char* path) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); return false; }
+    n = (size_t)st.st_size;
+    if (n == 0) { ::close(fd); p = nullptr; return true; }
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { n = 0; return false; }
+    p = (const uint8_t*)m;
+    mapped = true;
+    return true;
+  }
+  size_t size() const { return n; }
+  const uint8_t* data() const { return p; }
+  uint8_t operator[](size_t i) const { return p[i]; }
+};
+
 struct File {
-  std::vector<uint8_t> d;
+  Bytes d;
   bool le = true;
   bool big = false;  // BigTIFF (magic 43): 8-byte offsets, 20-byte directory entries
   uint16_t u16(size_t o) const { return le ? (uint16_t)(d[o] | d[o + 1] << 8) : (uint16_t)(d[o] << 8 | d[o + 1]); }
@@ -41,19 +74,6 @@ struct File {
     return le ? (uint64_t)u32(o) | (uint64_t)u32(o + 4) << 32 : (uint64_t)u32(o) << 32 | (uint64_t)u32(o + 4);
   }
 };
-
-bool slurp(const char* path, std::vector<uint8_t>& out) {
-  FILE* f = fopen(path, "rb");
-  if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  const long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  if (n < 0) { fclose(f); return false; }
-  out.resize((size_t)n);
-  const size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
-  fclose(f);
-  return got == (size_t)n;
-}
 
 struct Ifd {
   uint32_t w = 0, h = 0, bps = 1, comp = 1, spp = 1, rps = 0, fmt = 1, fill = 1, planar = 1, predictor = 1;
@@ -255,7 +275,7 @@ bool host_is_le() {
 
 // header + directory chain of one file
 oi_status open_tiff(const char* path, File& f, std::vector<Ifd>& pages) {
-  if (!slurp(path, f.d) || f.d.size() < 8) {
+  if (!f.d.open(path) || f.d.size() < 8) {
     oi::set_error("cannot read TIFF file '%s'", path);
     return OI_IO_ERROR;
   }
@@ -380,9 +400,10 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
 
 }  // namespace
 
-extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
-                                  int* bits_per_sample) {
-  if (!path || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
+// planes [z0, z0 + nz_local) of a stack; nz_local < 0 = all planes from z0.  *nz reports the depth of the FILE.
+extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int z0, int nz_local, uint8_t** phase,
+                                         int* nx, int* ny, int* nz, int* bits_per_sample) {
+  if (!path || !phase || !nx || !ny || !nz || z0 < 0) return OI_BAD_ARG;
   *phase = nullptr;
   File f;
   std::vector<Ifd> pages;
@@ -391,17 +412,27 @@ extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** 
   const Ifd& p0 = pages[0];
   if ((st = check_first_page(path, p0)) != OI_OK) return st;
   const size_t W = p0.w, H = p0.h, D = pages.size();
-  uint8_t* out = (uint8_t*)malloc(W * H * D);
+  if (nz_local < 0) nz_local = (int)D - z0;
+  if (nz_local < 1 || (size_t)z0 + (size_t)nz_local > D) {
+    oi::set_error("'%s': planes [%d, %d) are outside the stack of %zu", path, z0, z0 + nz_local, D);
+    return OI_BAD_ARG;
+  }
+  uint8_t* out = (uint8_t*)malloc(W * H * (size_t)nz_local);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   std::vector<uint8_t> buf;
-  for (size_t k = 0; k < D; ++k) {
-    st = decode_page(path, f, pages[k], p0, k, threshold, out + k * W * H, buf);
+  for (size_t k = 0; k < (size_t)nz_local; ++k) {
+    st = decode_page(path, f, pages[z0 + k], p0, z0 + k, threshold, out + k * W * H, buf);
     if (st != OI_OK) { free(out); return st; }
   }
   *phase = out;
   *nx = (int)W; *ny = (int)H; *nz = (int)D;
   if (bits_per_sample) *bits_per_sample = (int)p0.bps;
   return OI_OK;
+}
+
+extern "C" oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
+                                  int* bits_per_sample) {
+  return oi_read_tiff_planes(path, threshold, 0, -1, phase, nx, ny, nz, bits_per_sample);
 }
 
 // Numbered single-slice files <base><index, zero-padded to `digits`><suffix>, index = start_index ..
@@ -439,9 +470,10 @@ extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_fil
   return OI_OK;
 }
 
-extern "C" oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
-                                 uint8_t** phase) {
-  if (!path || !phase || nx < 1 || ny < 1 || nz < 1) return OI_BAD_ARG;
+// planes [z0, z0 + nz_local) of a raw volume of nx * ny * nz voxels (only those bytes are touched)
+extern "C" oi_status oi_read_raw_planes(const char* path, int nx, int ny, int nz, int dtype, double threshold, int z0,
+                                        int nz_local, uint8_t** phase) {
+  if (!path || !phase || nx < 1 || ny < 1 || nz < 1 || z0 < 0 || nz_local < 1 || z0 + nz_local > nz) return OI_BAD_ARG;
   *phase = nullptr;
   size_t bpv = 0;
   bool le = true;
@@ -455,18 +487,19 @@ extern "C" oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int d
     case OI_RAW_FLOAT64_BE: bpv = 8; le = false; break;
     default: oi::set_error("unknown raw data type %d", dtype); return OI_BAD_ARG;
   }
-  std::vector<uint8_t> d;
-  if (!slurp(path, d)) { oi::set_error("cannot read raw file '%s'", path); return OI_IO_ERROR; }
-  const size_t n = (size_t)nx * ny * nz;
-  if (d.size() != n * bpv) {  // the reference insists on an exact size match
+  Bytes d;
+  if (!d.open(path)) { oi::set_error("cannot read raw file '%s'", path); return OI_IO_ERROR; }
+  const size_t ntot = (size_t)nx * ny * nz;
+  if (d.size() != ntot * bpv) {  // the reference insists on an exact size match
     oi::set_error("'%s': size %zu does not match %dx%dx%d x %zu bytes", path, d.size(), nx, ny, nz, bpv);
     return OI_IO_ERROR;
   }
+  const size_t n = (size_t)nx * ny * (size_t)nz_local, first = (size_t)nx * ny * (size_t)z0;
   uint8_t* out = (uint8_t*)malloc(n);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   const bool swap = bpv > 1 && le != host_is_le();
   for (size_t v = 0; v < n; ++v) {
-    const uint8_t* p = d.data() + v * bpv;
+    const uint8_t* p = d.data() + (first + v) * bpv;
     double val = 0.0;
     switch (dtype) {
       case OI_RAW_UINT8: val = (double)p[0]; break;
@@ -484,14 +517,19 @@ extern "C" oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int d
   return OI_OK;
 }
 
+extern "C" oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, double threshold,
+                                 uint8_t** phase) {
+  return oi_read_raw_planes(path, nx, ny, nz, dtype, threshold, 0, nz, phase);
+}
+
 // DatReader (src/io/DatReader.cpp:74-160 readFile, :204-241 threshold): little-endian
 // 3 x int32 header (W, H, D) + uint16 voxels, x fastest; the threshold is compared as
 // uint16 (the reference's DataType), extra trailing bytes are ignored.
 extern "C" oi_status oi_read_dat(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz) {
   if (!path || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
   *phase = nullptr;
-  std::vector<uint8_t> d;
-  if (!slurp(path, d) || d.size() < 12) { oi::set_error("cannot read DAT file '%s'", path); return OI_IO_ERROR; }
+  Bytes d;
+  if (!d.open(path) || d.size() < 12) { oi::set_error("cannot read DAT file '%s'", path); return OI_IO_ERROR; }
   const bool swap = !host_is_le();
   const int32_t w = load_swapped<int32_t>(d.data(), swap), h = load_swapped<int32_t>(d.data() + 4, swap),
                 dep = load_swapped<int32_t>(d.data() + 8, swap);

@@ -210,3 +210,23 @@ def test_tiff_reader_rejects_what_it_cannot_decode(tmp_path):
     with pytest.raises(oia.OpenImpalaError) as e:
         oia.TiffReader(str(p)).threshold(1.0)
     assert "compression" in str(e.value)
+
+
+def test_readers_load_a_z_slab_only(tmp_path):
+    """oi_read_tiff_planes / oi_read_raw_planes: a rank reads its planes, not the volume."""
+    tif = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")
+    full = oia.TiffReader(tif).threshold(0.5)
+    r = oia.TiffReader(tif)
+    assert np.array_equal(r.threshold(0.5, z0=37, nz_local=21), full[37:58])
+    assert r.depth() == 100                      # the file's depth, not the slab's
+    assert np.array_equal(oia.TiffReader(tif).threshold(0.5, z0=90), full[90:])
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TiffReader(tif).threshold(0.5, z0=95, nz_local=6)
+    vals = np.random.default_rng(4).integers(0, 60000, size=(9, 6, 7)).astype("<u2")
+    p = tmp_path / "v.raw"
+    vals.tofile(p)
+    rr = oia.RawReader(str(p), 7, 6, 9, "UINT16_LE")
+    assert np.array_equal(rr.threshold(30000.0, z0=2, nz_local=5), (vals[2:7] > 30000).astype(np.uint8))
+    assert np.array_equal(rr.threshold(30000.0), (vals > 30000).astype(np.uint8))
+    with pytest.raises(oia.OpenImpalaError):
+        rr.threshold(1.0, z0=8, nz_local=2)
