@@ -95,8 +95,10 @@ struct MgCoarse {
   long long csz;
 };
 // fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
+// mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
+// (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
-                   double* out, double* partials, const Ctrl* ctrl, hipStream_t s);
+                   double* out, float* bcoarse, double* partials, const Ctrl* ctrl, hipStream_t s);
 void set_fused_tuning(int tile_rows, int zchunk);
 void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles

@@ -890,6 +890,10 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 //   MODE 1 (pre) :  v = w b / code                         out = b - A v
 //   MODE 2 (post):  v = w b / code + s * xc[parent]        out = v + w (b - A v) / code,
 //                   partial out.b  (= z.r of the preconditioned CG)
+//   MODE 3 (pre + restriction): the residual of MODE 1 is never stored; its 2x2x2 block sums go
+//                   straight into the fp32 right-hand side of the first coarse level (x pairs in the
+//                   thread, y pairs through LDS between neighbouring waves, z pairs across two
+//                   consecutive planes of the march) -- 9.5 B/voxel instead of 17 + 8.5
 // b vanishes on non-free cells and its ghost planes hold the neighbour slabs' values; xc is the
 // fp32 coarse correction of the 2x2x2 aggregates.
 // --------------------------------------------------------------------------------------
@@ -904,14 +908,16 @@ __device__ __forceinline__ double inv_count(unsigned c) {
 template <int R, int MODE>
 __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
                                                        const double* __restrict__ b, MgCoarse C, double omega, double scale,
-                                                       double* __restrict__ out, int zchunk, int tiles_x, int tiles_y,
-                                                       int nzc, double* __restrict__ partials,
+                                                       double* __restrict__ out, float* __restrict__ bcoarse, int zchunk,
+                                                       int tiles_x, int tiles_y, int nzc, double* __restrict__ partials,
                                                        const Ctrl* __restrict__ ctrl) {
   constexpr int BY = kNW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
+  static_assert((kNW & 1) == 0, "rows 2m and 2m+1 of a tile belong to waves w and w+1");
   if (ctrl && ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
   __shared__ double red[kNW];
+  __shared__ double ysum[MODE == 3 ? 2 : 1][MODE == 3 ? R * (kNW / 2) * 64 : 1];
   const int ntiles = tiles_x * tiles_y * nzc;
   int L = blockIdx.x;
   if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
@@ -977,6 +983,27 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     }
   };
 
+  // MODE 3: even waves own the block sums; `own` is their x-pair sum of the plane just finished, `acc`
+  // the running 2x2x(1 or 2) sum.  Plane gzp is consumed one barrier after it was computed.
+  double own[R], acc[R];
+#pragma unroll
+  for (int rr_ = 0; rr_ < R; ++rr_) { own[rr_] = 0.0; acc[rr_] = 0.0; }
+  auto consume = [&](int gzp) {
+    if (MODE != 3 || (w & 1)) return;
+    const double* Y = ysum[MODE == 3 ? (gzp & 1) : 0];
+    const int kg = g.z0 + gzp - 1;  // global fine plane
+    const bool store = (kg & 1) != 0 || gzp == ge - 1;
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      acc[rr_] += own[rr_] + Y[(rr_ * (kNW / 2) + (w >> 1)) * 64 + lane];
+      if (store) {
+        const int I = tx * (kBX / 2) + lane, J = (j0 + w + rr_ * kNW) >> 1;
+        if (I < C.cnx && J < C.cny) bcoarse[(long long)I + (long long)C.cnx * J + C.csz * ((kg >> 1) - C.z0c + 1)] = (float)acc[rr_];
+        acc[rr_] = 0.0;
+      }
+    }
+  };
+
   double2 v_prev[R], v_cur[R], v_nxt[R], b_cur[R], b_nxt[R];
   load_plane(gs - 1, v_prev, b_nxt);
   load_plane(gs, v_cur, b_cur);
@@ -986,10 +1013,13 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
   for (int gz = gs; gz < ge; ++gz) {
     load_plane(gz + 1, v_nxt, b_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, v_nxt);
+    if (gz > gs) consume(gz - 1);
     const double* T = tile[gz & 1];
+    double xsum[R];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
+      xsum[rr_] = 0.0;
       if (in_x && j < g.ny) {
         const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
@@ -1004,23 +1034,35 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
         const double s1 = ((((vc.x + rt.x) + ym.y) + yp.y) + v_prev[rr_].y) + v_nxt[rr_].y;
         double o0 = 0.0, o1 = 0.0;
-        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE == 1 ? bc.x - av : vc.x + omega * (bc.x - av) * inv_count(c0); }
-        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE == 1 ? bc.y - av : vc.y + omega * (bc.y - av) * inv_count(c1); }
+        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + omega * (bc.x - av) * inv_count(c0); }
+        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + omega * (bc.y - av) * inv_count(c1); }
+        if (MODE == 3) { xsum[rr_] = o0 + o1; continue; }
         st2(out + e, o0, o1);
         dot += o0 * bc.x; dot += o1 * bc.y;
+      }
+    }
+    if (MODE == 3) {  // odd waves publish their x-pair sums, even waves keep theirs until the barrier has passed
+      double* Y = ysum[MODE == 3 ? (gz & 1) : 0];
+#pragma unroll
+      for (int rr_ = 0; rr_ < R; ++rr_) {
+        if (w & 1) Y[(rr_ * (kNW / 2) + (w >> 1)) * 64 + lane] = xsum[rr_];
+        else own[rr_] = xsum[rr_];
       }
     }
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) { v_prev[rr_] = v_cur[rr_]; v_cur[rr_] = v_nxt[rr_]; b_cur[rr_] = b_nxt[rr_]; }
     __syncthreads();
   }
+  if (MODE == 3) { consume(ge - 1); return; }
   const double t = block_sum(dot, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
 // mode 1 = pre (out = b - A v), 2 = post (out = z, partial z.b); returns the number of partials
+// mode 3 = pre with the restriction fused in: `bcoarse` receives the block sums of the planes this slab
+// owns (needs an even g.z0: z pairs must not straddle the z chunks)
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
-                   double* out, double* partials, const Ctrl* ctrl, hipStream_t s) {
+                   double* out, float* bcoarse, double* partials, const Ctrl* ctrl, hipStream_t s) {
   constexpr int R = 2;
   const int by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
@@ -1036,13 +1078,20 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
     zchunk = (g.nzl + maxc - 1) / maxc;
     nzc = (g.nzl + zchunk - 1) / zchunk;
   }
+  if (mode == 3 && (zchunk & 1) && zchunk < g.nzl) {  // chunks must hold whole z pairs
+    ++zchunk;
+    nzc = (g.nzl + zchunk - 1) / zchunk;
+  }
   const int blocks = (int)(cols * nzc);
   if (mode == 1)
-    hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, zchunk,
-                       tiles_x, tiles_y, nzc, partials, ctrl);
+    hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+  else if (mode == 3)
+    hipLaunchKernelGGL((k_mg_fine<R, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
   else
-    hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, zchunk,
-                       tiles_x, tiles_y, nzc, partials, ctrl);
+    hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
   return blocks;
 }
 

@@ -594,9 +594,17 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
   const long long nfine = (long long)g.nzl * g.ny * g.nx;
   MgLevelHost& C = Ls[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz};
-  if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, partials, ctrl, s);
-  else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl);
-  if (!restrict_to(mg, &g, code, scratch, nullptr, C, C.b, s)) return -1;
+  const bool transition = mg->comm && C.replicated;  // owned contributions are summed across ranks afterwards
+  if (tiled && (g.z0 & 1) == 0) {
+    // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
+    if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);
+    launch_mg_fine(3, g, code, r, cref, (double)kOmega, (double)mg->scale, nullptr, C.b, partials, ctrl, s);
+    if (!finish_child_array(mg, C, false, C.b, s)) return -1;
+  } else {
+    if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, nullptr, partials, ctrl, s);
+    else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl);
+    if (!restrict_to(mg, &g, code, scratch, nullptr, C, C.b, s)) return -1;
+  }
   if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
   if (mg->wmask & 1u) {
     OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, 1, C.b, C.x2, C.b2);
@@ -605,7 +613,7 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
     cref.xc2 = C.xs;
   }
   if (tiled)  // also leaves the per-block partial sums of z.r
-    return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, partials, ctrl, s);
+    return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, s);
   hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl);
   return launch_dot(g, r, z, partials, s);
 }
