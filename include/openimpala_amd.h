@@ -195,6 +195,10 @@ void oi_tort_set_apply_tuning(int tile_rows);
 /* single-kernel CG iteration: rows per LDS tile (8, 16, 32; <= 0 automatic) and whether x is
  * updated every second iteration with both pending terms (1, default) or every iteration (0) */
 void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
+/* layout of r, q, p in the single-kernel iteration: 1 (default) = COMPACTED -- only the aligned 16-voxel lines
+ * that hold a free voxel are stored (contiguous in HBM, ~40 % less memory at porosity 0.4), 0 = dense with
+ * predicated accesses.  Affects handles created after the call. */
+void oi_tort_set_cg1_layout(int compact_lines);
 
 /* The solver kernels predicate their vector loads/stores on the code byte, so a cache line without a
  * free voxel is never moved.  Fraction of the aligned runs of `group_voxels` voxels along x (this slab)

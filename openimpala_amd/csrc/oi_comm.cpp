@@ -68,6 +68,21 @@ struct RcclComm : oi_comm {
     NCCLC(ncclGroupEnd());
     return OI_OK;
   }
+  oi_status exchange_v(const void* send_lo, size_t n_send_lo, void* recv_lo, size_t n_recv_lo, const void* send_hi,
+                       size_t n_send_hi, void* recv_hi, size_t n_recv_hi, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    NCCLC(ncclGroupStart());
+    if (rank > 0) {
+      if (n_send_lo) NCCLC(ncclSend(send_lo, n_send_lo, ncclInt8, rank - 1, nccl, s));
+      if (n_recv_lo) NCCLC(ncclRecv(recv_lo, n_recv_lo, ncclInt8, rank - 1, nccl, s));
+    }
+    if (rank < size - 1) {
+      if (n_send_hi) NCCLC(ncclSend(send_hi, n_send_hi, ncclInt8, rank + 1, nccl, s));
+      if (n_recv_hi) NCCLC(ncclRecv(recv_hi, n_recv_hi, ncclInt8, rank + 1, nccl, s));
+    }
+    NCCLC(ncclGroupEnd());
+    return OI_OK;
+  }
   oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,
                           hipStream_t s) override {
     if (size == 1) {  // my own planes wrap around
@@ -181,6 +196,29 @@ struct LocalComm : oi_comm {
     if (rank > 0) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank - 1], 0));
     if (rank < size - 1) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank + 1], 0));
     sh->barrier();  // events are re-recorded by the next collective only after everyone has waited
+    return OI_OK;
+  }
+  oi_status exchange_v(const void* send_lo, size_t n_send_lo, void* recv_lo, size_t n_recv_lo, const void* send_hi,
+                       size_t n_send_hi, void* recv_hi, size_t n_recv_hi, hipStream_t s) override {
+    if (size == 1) return OI_OK;
+    (void)n_send_lo; (void)n_send_hi;  // the receiver copies: its sizes are the sender's
+    sh->send_lo[rank] = send_lo;
+    sh->send_hi[rank] = send_hi;
+    HIPC(hipEventRecord(sh->ev_ready[rank], s));
+    sh->barrier();
+    if (rank > 0) {
+      HIPC(hipStreamWaitEvent(s, sh->ev_ready[rank - 1], 0));
+      if (n_recv_lo) HIPC(hipMemcpyAsync(recv_lo, sh->send_hi[rank - 1], n_recv_lo, hipMemcpyDeviceToDevice, s));
+    }
+    if (rank < size - 1) {
+      HIPC(hipStreamWaitEvent(s, sh->ev_ready[rank + 1], 0));
+      if (n_recv_hi) HIPC(hipMemcpyAsync(recv_hi, sh->send_lo[rank + 1], n_recv_hi, hipMemcpyDeviceToDevice, s));
+    }
+    HIPC(hipEventRecord(sh->ev_done[rank], s));
+    sh->barrier();
+    if (rank > 0) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank - 1], 0));
+    if (rank < size - 1) HIPC(hipStreamWaitEvent(s, sh->ev_done[rank + 1], 0));
+    sh->barrier();
     return OI_OK;
   }
   oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,

@@ -19,6 +19,10 @@ struct oi_comm {
   // recv_lo); chain ends skip the missing neighbour.  Asynchronous on `s`.
   virtual oi_status exchange(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
                              size_t bytes, hipStream_t s) = 0;
+  // the same with a size per message (compacted planes differ in length): my lower neighbour's n_send_lo is
+  // its upper neighbour's n_recv_hi, and so on; a zero-length message is skipped on both sides
+  virtual oi_status exchange_v(const void* send_lo, size_t n_send_lo, void* recv_lo, size_t n_recv_lo, const void* send_hi,
+                               size_t n_send_hi, void* recv_hi, size_t n_recv_hi, hipStream_t s) = 0;
   // the same on a RING (rank 0 and rank size-1 are neighbours too): periodic z of the homogenization
   // cell problems.  With one rank the planes wrap onto the rank's own ghosts.
   virtual oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,

@@ -60,8 +60,13 @@ void launch_unpack_mask(const Geom& g, const uint64_t* active, uint8_t* mask_out
                         hipStream_t s);
 
 // r = -A x on free cells, p = z (z = r or r/code), partials {rr, rz}
+// (lineoff != null: r goes to the compacted line layout, see launch_build_lines)
 int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double* r, double* p, int jacobi,
-                     double* partials, hipStream_t s);
+                     double* partials, const int* lineoff, hipStream_t s);
+// Compacted line layout of the single-kernel iteration: only the aligned 16-voxel lines (owned and ghost
+// planes) that hold a free voxel are stored, in (plane, row, line) order.  lineoff[(gz * ny + j) * LW + line],
+// LW = ceil(pitch / 16), is a line's slot or -1; plane_first_dev[gz] (gz = 0 .. nzl + 2) the first slot of a plane.
+hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, hipStream_t s);
 // q = A v, partials {v.q}; returns number of partial blocks
 int launch_apply(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                  const Ctrl* ctrl, hipStream_t s);
@@ -104,14 +109,16 @@ void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
-               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, hipStream_t s);
+               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
+               hipStream_t s);
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);
 void set_cg1_tuning(int tile_rows);  // <= 0: automatic
 void set_cg1_xskip(int on);
 int cg1_xskip();
-void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, hipStream_t s);
+void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, const int* lineoff,
+                     hipStream_t s);
 constexpr int kRec1Alpha = 5;
 constexpr int kRec1Stride = 8;  // doubles per iteration record; [0] = r.r
 // r -= alpha q; partials {rr, rz}

@@ -10,6 +10,8 @@
 // CPU oracle, so single-kernel outputs are bit-identical to it.
 #include "oi_device.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 
 namespace oi {
@@ -364,17 +366,25 @@ __device__ __forceinline__ Pair apply_pair(const Geom& g, const double* __restri
 #define OI_PAIR_LOOP_END }
 
 // r = -A x on free cells (x holds the Dirichlet values), p = z, partials {r.r, r.z}
+// lineoff != null: r is stored in the compacted line layout (see k_cg1), only live pairs are written
 __global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __restrict__ code,
                                                     const double* __restrict__ x, double* __restrict__ r,
-                                                    double* __restrict__ p, int jacobi, double* __restrict__ partials) {
+                                                    double* __restrict__ p, int jacobi, double* __restrict__ partials,
+                                                    const int* __restrict__ lineoff, int LW) {
   double rr = 0.0, rz = 0.0;
   OI_PAIR_LOOP_BEGIN
-  (void)j;
   const Pair q = apply_pair(g, x, e, i, j, c0, c1);
   const double r0 = c0 ? -q.a : 0.0, r1 = c1 ? -q.b : 0.0;
   const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;
   const double z1 = (jacobi && c1) ? r1 / (double)c1 : r1;
-  st2(r + e, r0, r1);
+  if (lineoff) {
+    if (cc) {
+      const long long gz = e / g.plane;
+      st2(r + 16LL * lineoff[(gz * g.ny + j) * LW + (i >> 4)] + (i & 15), r0, r1);
+    }
+  } else {
+    st2(r + e, r0, r1);
+  }
   if (p) st2(p + e, z0, z1);  // the fused variant forms p_0 = z_0 itself
   rr += r0 * r0; rr += r1 * r1;
   rz += r0 * z0; rz += r1 * z1;
@@ -386,10 +396,58 @@ __global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __rest
 }
 
 int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double* r, double* p, int jacobi,
-                     double* partials, hipStream_t s) {
+                     double* partials, const int* lineoff, hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
-  hipLaunchKernelGGL(k_residual0, dim3(blocks), dim3(256), 0, s, g, code, x, r, p, jacobi, partials);
+  hipLaunchKernelGGL(k_residual0, dim3(blocks), dim3(256), 0, s, g, code, x, r, p, jacobi, partials, lineoff,
+                     (g.pitch + 15) / 16);
   return blocks;
+}
+
+// ---- compacted line layout: which aligned 16-voxel lines (owned AND ghost planes) hold a free voxel ----
+__global__ void __launch_bounds__(256) k_line_flags(Geom g, const uint8_t* __restrict__ code, int LW, int* __restrict__ flags) {
+  const long long n = (long long)(g.nzl + 2) * g.ny * LW;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int li = (int)(t % LW);
+    const long long row = t / LW;  // gz * ny + j
+    const long long base = (row / g.ny) * g.plane + (row % g.ny) * g.pitch + 16LL * li;
+    const int len = min(16, g.pitch - 16 * li);
+    int any = 0;
+    for (int v = 0; v < len; ++v) any |= code[base + v] != 0;
+    flags[t] = any;
+  }
+}
+// slot (exclusive scan of the flags) or -1; slot of the first line of every plane into plane_first[0 .. nzl+2]
+__global__ void __launch_bounds__(256) k_line_finalize(long long n, long long per_plane, const int* __restrict__ flags,
+                                                        int* __restrict__ slots, long long* __restrict__ plane_first) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int sl = slots[t];
+    if (t % per_plane == 0) plane_first[t / per_plane] = sl;
+    if (t == n - 1) plane_first[n / per_plane] = sl + flags[t];
+    slots[t] = flags[t] ? sl : -1;
+  }
+}
+// lineoff: (nzl + 2) * ny * LW ints; plane_first_dev: nzl + 3 long longs.  Returns hipSuccess or the failing call's error.
+hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, hipStream_t s) {
+  const int LW = (g.pitch + 15) / 16;
+  const long long n = (long long)(g.nzl + 2) * g.ny * LW;
+  if (n >= (1ll << 31)) return hipErrorInvalidValue;
+  int* flags = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipMalloc((void**)&flags, sizeof(int) * n);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_line_flags, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, g, code, LW, flags);
+  e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flags, lineoff, (int)n, s);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, lineoff, (int)n, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_line_finalize, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, n, (long long)g.ny * LW, flags, lineoff,
+                       plane_first_dev);
+    e = hipStreamSynchronize(s);
+  }
+  if (tmp) (void)hipFree(tmp);
+  (void)hipFree(flags);
+  return e;
 }
 
 // q = A v, partials {v.q}
@@ -577,23 +635,36 @@ __global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ 
   }
 }
 
+// (lineoff != null: p in the compacted line layout, lines that are not stored contribute nothing)
 template <typename PT>
 __global__ void __launch_bounds__(256) k_axpy_ptr(Geom g, double* __restrict__ x, const PT* __restrict__ p,
-                                                   const double* __restrict__ alpha_ptr) {
+                                                   const double* __restrict__ alpha_ptr, const int* __restrict__ lineoff,
+                                                   int LW) {
   const double alpha = *alpha_ptr;
   const long long npairs = (long long)g.nzl * g.plane / 2;
+  const int hp = g.pitch >> 1;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;
        t += (long long)gridDim.x * blockDim.x) {
     const long long e = g.plane + 2 * t;
-    const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + e);
+    long long ev = e;
+    if (lineoff) {
+      const int i = 2 * (int)(t % hp);
+      const long long row = t / hp;  // (gz - 1) * ny + j
+      const int lo = lineoff[(row + g.ny) * LW + (i >> 4)];
+      if (lo < 0) continue;
+      ev = 16LL * lo + (i & 15);
+    }
+    const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + ev);
     st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
   }
 }
 
-void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, hipStream_t s) {
+void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, const int* lineoff,
+                     hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
-  if (p_f32) hipLaunchKernelGGL(k_axpy_ptr<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, alpha_ptr);
-  else hipLaunchKernelGGL(k_axpy_ptr<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, alpha_ptr);
+  const int LW = (g.pitch + 15) / 16;
+  if (p_f32) hipLaunchKernelGGL(k_axpy_ptr<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, alpha_ptr, lineoff, LW);
+  else hipLaunchKernelGGL(k_axpy_ptr<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, alpha_ptr, lineoff, LW);
 }
 
 void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k,
@@ -1118,14 +1189,18 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
 // --------------------------------------------------------------------------------------
 enum { R1_RR = 0, R1_RZ, R1_PQ, R1_ZQ, R1_QDQ, R1_ALPHA, R1_BETA, R1_STRIDE = 8 };
 
-template <int R, int NW, typename PT, bool JACOBI>
+// COMPACT: r, q and p live in the COMPACTED layout -- only the aligned 16-voxel lines that hold a free
+// voxel are stored, in (plane, row, line) order; lineoff[(gz * ny + j) * LW + line] is a line's slot (-1:
+// not stored).  Same bytes as the predicated dense layout, but contiguous in HBM.  x stays dense.
+template <int R, int NW, typename PT, bool JACOBI, bool COMPACT>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                    const double* __restrict__ r_in, double* __restrict__ r_out,
                                                    const double* __restrict__ q_in, double* __restrict__ q_out,
                                                    const PT* __restrict__ p_in, PT* __restrict__ p_out,
                                                    const double* __restrict__ rec, int k, int xskip, int zchunk,
                                                    int tiles_x, int tiles_y, int nzc, int part, int partial_base,
-                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl,
+                                                   const int* __restrict__ lineoff, int LW) {
   constexpr int BY = NW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (ctrl->done) return;
@@ -1166,36 +1241,44 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   // r, q and p vanish on non-free voxels (code 0): their loads and stores are predicated on the code
   // byte, so a cache line without a free voxel is never fetched or written (spheres at porosity 0.4:
   // 41 % of the 128-byte lines)
-  auto pnew_at = [&](long long e) -> double {
+  auto pnew_at = [&](int gz, int jj, int ii) -> double {
+    const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    double z = r_in[e] - alpha_prev * q_in[e];
+    const long long ev = COMPACT ? 16LL * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> 4)] + (ii & 15) : e;
+    double z = r_in[ev] - alpha_prev * q_in[ev];
     if (JACOBI) z = z / (double)c;
-    return PIo<PT>::rnd(z + beta * (double)p_in[e]);
+    return PIo<PT>::rnd(z + beta * (double)p_in[ev]);
   };
-  // code bytes of this thread's voxel pairs in plane gz (fetched one plane ahead of the vectors)
-  auto load_codes = [&](int gz, unsigned short (&cn)[R]) {
+  // code bytes (and, compacted layout, the line slot) of this thread's voxel pairs in plane gz, fetched
+  // one plane ahead of the vectors
+  auto load_codes = [&](int gz, unsigned short (&cn)[R], int (&ln)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * NW;
       cn[rr_] = 0;
-      if (in_x && j < g.ny && gz <= g.nzl + 1)
+      ln[rr_] = 0;
+      if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
+        if (COMPACT) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+      }
     }
   };
   // mode 0: a halo plane owned by another block (nothing stored); 1: an output plane of this
   // block (r_k, p_k stored, x updated at once: keeps p_{k-1} out of the register budget);
   // 2: a ghost plane of the slab, kept current by the block that marches over it (r_k, p_k)
-  auto load_plane = [&](int gz, const unsigned short (&cn)[R], double2 (&pn)[R], double2 (&rn)[R], int mode) {
+  auto load_plane = [&](int gz, const unsigned short (&cn)[R], const int (&ln)[R], double2 (&pn)[R], double2 (&rn)[R],
+                        int mode) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * NW;
       pn[rr_] = make_double2(0.0, 0.0);
       rn[rr_] = make_double2(0.0, 0.0);
       if (cn[rr_]) {  // (implies in_x && j < g.ny)
-        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const double2 rv = ld2(r_in + e), qv = ld2(q_in + e);
-        const double2 pin = PIo<PT>::ld_pair(p_in + e);
+        const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;            // dense: x
+        const long long ev = COMPACT ? 16LL * ln[rr_] + (i & 15) : e;                         // r, q, p
+        const double2 rv = ld2(r_in + ev), qv = ld2(q_in + ev);
+        const double2 pin = PIo<PT>::ld_pair(p_in + ev);
         const double r0 = rv.x - alpha_prev * qv.x, r1 = rv.y - alpha_prev * qv.y;
         rn[rr_] = make_double2(r0, r1);
         double z0 = r0, z1 = r1;
@@ -1206,17 +1289,17 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
         }
         pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
         if (mode != 0) {
-          st2(r_out + e, r0, r1);
+          st2(r_out + ev, r0, r1);
           if (mode == 1 && do_x) {
             const double2 xv = ld2(x + e);
             double a0 = alpha_prev * pin.x, a1 = alpha_prev * pin.y;
             if (xskip) {
-              const double2 pold = PIo<PT>::ld_pair(p_out + e);  // p_{k-2}
+              const double2 pold = PIo<PT>::ld_pair(p_out + ev);  // p_{k-2}
               a0 = alpha_prev2 * pold.x + a0; a1 = alpha_prev2 * pold.y + a1;
             }
             st2(x + e, xv.x + a0, xv.y + a1);
           }
-          PIo<PT>::st_pair(p_out + e, pn[rr_].x, pn[rr_].y);
+          PIo<PT>::st_pair(p_out + ev, pn[rr_].x, pn[rr_].y);
         }
       }
     }
@@ -1228,32 +1311,30 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
       *reinterpret_cast<double2*>(&T[(w + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
-      if (yhalo) {
-        const long long e = (long long)gz * g.plane + (long long)hrow * g.pitch + i;
-        h.x = pnew_at(e); h.y = pnew_at(e + 1);
-      }
+      if (yhalo) { h.x = pnew_at(gz, hrow, i); h.y = pnew_at(gz, hrow, i + 1); }
       *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
-      if (xhalo) h = pnew_at((long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i);
+      if (xhalo) h = pnew_at(gz, xh_row, xh_i);
       T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
     }
   };
 
   double2 pn_prev[R], pn_cur[R], pn_nxt[R], rn_cur[R], rn_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
-  load_codes(gs - 1, cc_nn);
-  load_codes(gs, cc_cur);
-  load_codes(gs + 1, cc_nxt);
-  load_plane(gs - 1, cc_nn, pn_prev, rn_nxt, gs == 1 ? 2 : 0);
-  load_plane(gs, cc_cur, pn_cur, rn_cur, 1);
+  int lo_cur[R], lo_nxt[R], lo_nn[R];
+  load_codes(gs - 1, cc_nn, lo_nn);
+  load_codes(gs, cc_cur, lo_cur);
+  load_codes(gs + 1, cc_nxt, lo_nxt);
+  load_plane(gs - 1, cc_nn, lo_nn, pn_prev, rn_nxt, gs == 1 ? 2 : 0);
+  load_plane(gs, cc_cur, lo_cur, pn_cur, rn_cur, 1);
   stage(gs & 1, gs, pn_cur);
   __syncthreads();
 
   double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    load_codes(gz + 2, cc_nn);
-    load_plane(gz + 1, cc_nxt, pn_nxt, rn_nxt, gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0));
+    load_codes(gz + 2, cc_nn, lo_nn);
+    load_plane(gz + 1, cc_nxt, lo_nxt, pn_nxt, rn_nxt, gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0));
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
     const double* T = tile[gz & 1];
 #pragma unroll
@@ -1273,7 +1354,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
         const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + pn_prev[rr_].y) + pn_nxt[rr_].y;
         const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
         const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
-        st2(q_out + e, q0, q1);
+        st2(q_out + (COMPACT ? 16LL * lo_cur[rr_] + (i & 15) : e), q0, q1);
         double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
         if (JACOBI) {
           if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
@@ -1290,6 +1371,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
     for (int rr_ = 0; rr_ < R; ++rr_) {
       pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; rn_cur[rr_] = rn_nxt[rr_];
       cc_cur[rr_] = cc_nxt[rr_]; cc_nxt[rr_] = cc_nn[rr_];
+      lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
     }
     __syncthreads();
   }
@@ -1320,19 +1402,26 @@ void set_cg1_tuning(int tile_rows) {
   else if (tile_rows == 33) { g_cg1_rows = 4; g_cg1_waves = 8; }
 }
 
+template <int R, int NW, typename PT, bool JAC, bool COMPACT>
+static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
+                         const double* q_in, double* q_out, const void* p_in, void* p_out, const double* rec, int k,
+                         int zchunk, int tiles_x, int tiles_y, int nzc, int part, int partial_base, double* partials,
+                         const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+  hipLaunchKernelGGL((k_cg1<R, NW, PT, JAC, COMPACT>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
+                     q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
+                     partial_base, partials, ctrl, lineoff, (g.pitch + 15) / 16);
+}
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                          const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
                          const double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, int part,
-                         int partial_base, double* partials, const Ctrl* ctrl, hipStream_t s) {
-  if (jacobi)
-    hipLaunchKernelGGL((k_cg1<R, NW, PT, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
-                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
-                       partial_base, partials, ctrl);
-  else
-    hipLaunchKernelGGL((k_cg1<R, NW, PT, false>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
-                       q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
-                       partial_base, partials, ctrl);
+                         int partial_base, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+#define OI_CG1K(JAC, CMP)                                                                                              \
+  launch_cg1_k<R, NW, PT, JAC, CMP>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, \
+                                    tiles_y, nzc, part, partial_base, partials, ctrl, lineoff, s)
+  if (jacobi) { if (lineoff) OI_CG1K(true, true); else OI_CG1K(true, false); }
+  else { if (lineoff) OI_CG1K(false, true); else OI_CG1K(false, false); }
+#undef OI_CG1K
 }
 
 // part: 0 = whole slab, 1 = boundary chunks, 2 = interior chunks (0 blocks when there are none).
@@ -1341,7 +1430,8 @@ static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double*
 // partials [partial_base, partial_base + blocks).
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
-               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, hipStream_t s) {
+               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
+               hipStream_t s) {
   // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
   // off on large planes; locals only, handles may be driven from several host threads
   const int R = g_cg1_auto ? 2 : g_cg1_rows;
@@ -1377,9 +1467,10 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
   do {                                                                                                             \
     if (p_f32) launch_cg1_r<RR, WW, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, \
                                            k, zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl,   \
-                                           s);                                                                     \
+                                           lineoff, s);                                                            \
     else launch_cg1_r<RR, WW, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,   \
-                                      zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl, s);      \
+                                      zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl, lineoff,  \
+                                      s);                                                                          \
   } while (0)
   if (R == 4) OI_CG1(4, 8);
   else if (R == 2 && NW == 16) OI_CG1(2, 16);

@@ -73,6 +73,11 @@ struct oi_tort {
   double *x = nullptr, *r = nullptr, *q = nullptr;
   double *r2 = nullptr, *q2 = nullptr;  // second buffers of the single-kernel variant
   double* rec = nullptr;                // its per-iteration scalar records
+  // compacted line layout of r, q, p in the single-kernel variant (see launch_build_lines)
+  int* lineoff = nullptr;
+  long long* plane_first_dev = nullptr;
+  std::vector<long long> plane_first;   // first slot of every plane, gz = 0 .. nzl + 2
+  long long nvec_cg = 0;                // elements of r / q / p (= g.nvec in the dense layout)
   double* z = nullptr;                  // preconditioned residual of the multigrid variant
   bool lean = false;  // OI_KERNEL_LEAN: no q vector, A p recomputed in the update pass
   oi::MgHierarchy* mg = nullptr;
@@ -195,7 +200,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec,
+  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->plane_first_dev,
                  h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
   for (void* d : dev)
     if (d) (void)hipFree(d);
@@ -233,6 +238,25 @@ static oi_status exchange_planes(oi_tort* h, void* base, size_t plane_bytes) {
   return h->comm->exchange(b + plane_bytes * 1, b + plane_bytes * 0, b + plane_bytes * (size_t)g.nzl,
                            b + plane_bytes * (size_t)(g.nzl + 1), plane_bytes, h->stream);
 }
+
+// ghost planes of a CG vector of the single-kernel variant (dense or compacted), on stream `s`
+static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_t s) {
+  if (!h->comm) return OI_OK;
+  char* b = (char*)base;
+  const Geom& g = h->g;
+  if (!h->lineoff) {
+    const size_t pb = elem * (size_t)g.plane;
+    return h->comm->exchange(b + pb, b, b + pb * (size_t)g.nzl, b + pb * (size_t)(g.nzl + 1), pb, s);
+  }
+  const std::vector<long long>& pf = h->plane_first;
+  const size_t le = 16 * elem;  // bytes per stored line
+  return h->comm->exchange_v(b + le * pf[1], le * (pf[2] - pf[1]), b + le * pf[0], le * (pf[1] - pf[0]),
+                             b + le * pf[g.nzl], le * (pf[g.nzl + 1] - pf[g.nzl]), b + le * pf[g.nzl + 1],
+                             le * (pf[g.nzl + 2] - pf[g.nzl + 1]), s);
+}
+
+static int g_cg1_compact = 1;  // single-kernel variant: store only the lines that hold a free voxel
+extern "C" void oi_tort_set_cg1_layout(int compact_lines) { g_cg1_compact = compact_lines ? 1 : 0; }
 
 // ---- construction ----------------------------------------------------------------------
 static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
@@ -342,16 +366,29 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   h->hist_cap = h->maxiter + 2;
   OIC(dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap));
   OIC(dmalloc(h, &h->x, (size_t)g.nvec));
-  OIC(dmalloc(h, &h->r, (size_t)g.nvec));
-  if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)g.nvec));
+  h->nvec_cg = g.nvec;
+  if (h->cg1 && g_cg1_compact) {
+    // r, q, p of the single-kernel variant: only the 16-voxel lines that hold a free voxel
+    const long long nlines = (long long)(g.nzl + 2) * g.ny * ((g.pitch + 15) / 16);
+    if (nlines < (1ll << 31)) {
+      OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
+      OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));
+      HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, s));
+      h->plane_first.resize((size_t)g.nzl + 3);
+      HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
+      h->nvec_cg = std::max<long long>(16, 16 * h->plane_first[g.nzl + 2]);
+    }
+  }
+  OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
+  if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)h->nvec_cg));
   if (h->cg1) {
-    OIC(dmalloc(h, &h->r2, (size_t)g.nvec));
-    OIC(dmalloc(h, &h->q2, (size_t)g.nvec));
+    OIC(dmalloc(h, &h->r2, (size_t)h->nvec_cg));
+    OIC(dmalloc(h, &h->q2, (size_t)h->nvec_cg));
     OIC(dmalloc(h, &h->rec, (size_t)kRec1Stride * h->hist_cap));
   }
   for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
-    HIPC(hipMalloc(&h->p[b], (size_t)g.nvec * h->p_elem));
-    h->bytes_device += (size_t)g.nvec * h->p_elem;
+    HIPC(hipMalloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
+    h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
   }
   if (h->opts.precond == OI_PRECOND_MG) {
     OIC(dmalloc(h, &h->z, (size_t)g.nvec));
@@ -536,22 +573,22 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   *h->h_ctrl = c;
   HIPC(hipMemcpyAsync(h->ctrl, h->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
   HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * h->hist_cap, s));
-  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, s));
-  if (h->q) HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
-  HIPC(hipMemsetAsync(h->p[0], 0, h->p_elem * g.nvec, s));
-  if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * g.nvec, s));
+  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * h->nvec_cg, s));
+  if (h->q) HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * h->nvec_cg, s));
+  HIPC(hipMemsetAsync(h->p[0], 0, h->p_elem * h->nvec_cg, s));
+  if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * h->nvec_cg, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
   int nb;
   h->xskip = h->cg1 ? cg1_xskip() : 0;
   if (h->cg1) {
     // kernel 0 reads buffer 1: r_{-1} := r_0 with alpha_{-1} = 0, q_{-1} = p_{-1} = 0
-    HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * g.nvec, s));
-    HIPC(hipMemsetAsync(h->q2, 0, sizeof(double) * g.nvec, s));
+    HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * h->nvec_cg, s));
+    HIPC(hipMemsetAsync(h->q2, 0, sizeof(double) * h->nvec_cg, s));
     HIPC(hipMemsetAsync(h->rec, 0, sizeof(double) * kRec1Stride * h->hist_cap, s));
-    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, s); }
-    OIC(exchange_planes(h, h->r2, sizeof(double) * g.plane));
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, h->lineoff, s); }
+    OIC(exchange_cg_vec(h, h->r2, sizeof(double), s));
   } else {
-    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, s); }
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, nullptr, s); }
     // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
     OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
     if (h->fused || h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
@@ -576,7 +613,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       {
         PROF(K_CG1);
         nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                        h->partials, h->ctrl, 0, 0, 0, s);
+                        h->partials, h->ctrl, 0, 0, 0, h->lineoff, s);
       }
       { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 1, s); }
     } else {
@@ -586,21 +623,16 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       {
         PROF(K_CG1);
         nb_b = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 1, 0, s);
+                          h->partials, h->ctrl, 1, 1, 0, h->lineoff, s);
       }
       HIPC(hipEventRecord(h->ev_boundary, s));
       HIPC(hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
-      {
-        char* qbytes = (char*)qb[out];
-        const size_t pb = sizeof(double) * g.plane;
-        OIC(h->comm->exchange(qbytes + pb, qbytes, qbytes + pb * (size_t)g.nzl, qbytes + pb * (size_t)(g.nzl + 1), pb,
-                              h->comm_stream));  // the ONE plane exchange per iteration
-      }
+      OIC(exchange_cg_vec(h, qb[out], sizeof(double), h->comm_stream));  // the ONE plane exchange per iteration
       HIPC(hipEventRecord(h->ev_exchanged, h->comm_stream));
       {
         PROF(K_CG1);
         nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 2, nb_b, s);
+                          h->partials, h->ctrl, 1, 2, nb_b, h->lineoff, s);
       }
       { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s); }
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
@@ -709,7 +741,7 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
     // pairwise x updates: an odd final state still lacks alpha_{K-1} p_{K-1}
     PROF(K_AXPY);
     launch_axpy_ptr(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->rec + (size_t)kRec1Stride * (K - 1) + kRec1Alpha,
-                    h->stream);
+                    h->lineoff, h->stream);
   }
   if (h->fused && !h->cg1 && K > 0) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
@@ -935,19 +967,29 @@ extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q,
   if (!h->q) { oi::set_error("the capacity mode keeps no A p vector: use another kernel variant for the stand-alone apply"); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
+  // the compacted single-kernel layout keeps r / q as line lists: the stand-alone apply gets dense scratch
+  struct Scratch { double *a = nullptr, *b = nullptr; ~Scratch() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } scratch;
+  double *vr = h->r, *vq = h->q;
+  if (h->lineoff) {
+    HIPC(hipMalloc((void**)&scratch.a, sizeof(double) * g.nvec));
+    HIPC(hipMalloc((void**)&scratch.b, sizeof(double) * g.nvec));
+    HIPC(hipMemsetAsync(scratch.a, 0, sizeof(double) * g.nvec, h->stream));
+    HIPC(hipMemsetAsync(scratch.b, 0, sizeof(double) * g.nvec, h->stream));
+    vr = scratch.a; vq = scratch.b;
+  }
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
   double* dense = nullptr;
   HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
   oi_status rc = OI_OK;
   do {
     if (hipMemcpyAsync(dense, v, n * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
-    launch_pitch_copy_in(g, dense, h->r, h->stream);
-    rc = exchange_planes(h, h->r, sizeof(double) * g.plane);
+        hipMemsetAsync(vr, 0, sizeof(double) * g.nvec, h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+    launch_pitch_copy_in(g, dense, vr, h->stream);
+    rc = exchange_planes(h, vr, sizeof(double) * g.plane);
     if (rc != OI_OK) break;
-    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
-    else launch_apply_tiled(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
-    launch_pitch_copy_out(g, h->q, dense, h->stream);
+    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, vr, vq, h->partials, nullptr, h->stream);
+    else launch_apply_tiled(g, h->code, vr, vq, h->partials, nullptr, h->stream);
+    launch_pitch_copy_out(g, vq, dense, h->stream);
     if (hipMemcpyAsync(q, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) rc = OI_HIP_ERROR;
   } while (0);
@@ -963,15 +1005,25 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
   if (!h->q) { oi::set_error("the capacity mode keeps no A p vector: use another kernel variant for the stand-alone apply"); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
+  // the compacted single-kernel layout keeps r / q as line lists: the stand-alone apply gets dense scratch
+  struct Scratch { double *a = nullptr, *b = nullptr; ~Scratch() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } scratch;
+  double *vr = h->r, *vq = h->q;
+  if (h->lineoff) {
+    HIPC(hipMalloc((void**)&scratch.a, sizeof(double) * g.nvec));
+    HIPC(hipMalloc((void**)&scratch.b, sizeof(double) * g.nvec));
+    HIPC(hipMemsetAsync(scratch.a, 0, sizeof(double) * g.nvec, h->stream));
+    HIPC(hipMemsetAsync(scratch.b, 0, sizeof(double) * g.nvec, h->stream));
+    vr = scratch.a; vq = scratch.b;
+  }
   // a smooth non-trivial field: the ramp (p = x0); one untimed launch warms the code path
-  launch_init_field(g, h->active, h->r, h->stream);
+  launch_init_field(g, h->active, vr, h->stream);
   hipEvent_t a, b;
   HIPC(hipEventCreate(&a));
   HIPC(hipEventCreate(&b));
   for (int i = -1; i < reps; ++i) {
     if (i == 0) HIPC(hipEventRecord(a, h->stream));
-    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
-    else launch_apply_tiled(g, h->code, h->r, h->q, h->partials, nullptr, h->stream);
+    if (variant == OI_KERNEL_UNFUSED) launch_apply(g, h->code, vr, vq, h->partials, nullptr, h->stream);
+    else launch_apply_tiled(g, h->code, vr, vq, h->partials, nullptr, h->stream);
   }
   HIPC(hipEventRecord(b, h->stream));
   HIPC(hipEventSynchronize(b));

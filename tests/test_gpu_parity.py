@@ -386,3 +386,24 @@ def test_remspot_on_the_device_equals_the_sequential_pass():
     t = oia.TortuosityMI355(buf, 1, 0, shape=ph.shape, eps=1e-10, remspot_passes=1)
     assert np.array_equal(t.mask(), ref["mask"])
     t.destroy(); buf.free()
+
+
+def test_single_kernel_layouts_compacted_and_dense(sample, goldens):
+    """r, q, p of the single-kernel iteration as compacted lines (default) or dense arrays with predicated
+    accesses: identical iterates (same arithmetic, different addresses), less memory."""
+    g = goldens["phases"]["1"]
+    out = {}
+    try:
+        for layout in (1, 0):
+            oia.set_cg1_layout(layout)
+            t = oia.TortuosityMI355(sample, 1, 1, g["vlo"], g["vhi"], eps=1e-10, kernel=oia.KERNEL_FUSED1, precond=oia.PRECOND_JACOBI)
+            tau = t.value()
+            out[layout] = (tau, t.getSolverIterations(), t.stats().final_relres, t.stats().bytes_device, t.solution())
+            assert t.apply(np.where(t.mask() > 0, 1.0, 0.0)).shape == sample.shape   # stand-alone apply works in both
+            t.destroy()
+    finally:
+        oia.set_cg1_layout(1)
+    assert out[1][0] == out[0][0] and out[1][1] == out[0][1] and out[1][2] == out[0][2]
+    assert np.array_equal(out[1][4], out[0][4])
+    assert out[1][0] == pytest.approx(g["tau"][1], rel=1e-7)
+    assert out[1][3] < 0.8 * out[0][3]
