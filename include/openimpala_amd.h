@@ -197,7 +197,9 @@ void oi_tort_set_apply_tuning(int tile_rows);
 void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
 /* layout of r, q, p in the single-kernel iteration: 1 (default) = COMPACTED -- only the aligned 16-voxel lines
  * that hold a free voxel are stored (contiguous in HBM, ~40 % less memory at porosity 0.4), 0 = dense with
- * predicated accesses.  Affects handles created after the call. */
+ * predicated accesses.  Affects handles created after the call.  Bit 1 (value 2) switches the kernel from
+ * whole-line to pair-granular accesses inside live lines (an A/B switch: whole lines avoid partial-line
+ * stores and measure 8-15 % faster). */
 void oi_tort_set_cg1_layout(int compact_lines);
 
 /* The solver kernels predicate their vector loads/stores on the code byte, so a cache line without a

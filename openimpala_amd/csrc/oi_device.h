@@ -116,6 +116,7 @@ void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* 
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);
 void set_cg1_tuning(int tile_rows);  // <= 0: automatic
 void set_cg1_xskip(int on);
+void set_cg1_fullline(int on);  // compacted layout: whole-line reads and writes (default on)
 int cg1_xskip();
 void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, const int* lineoff,
                      hipStream_t s);

@@ -1200,7 +1200,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
                                                    const double* __restrict__ rec, int k, int xskip, int zchunk,
                                                    int tiles_x, int tiles_y, int nzc, int part, int partial_base,
                                                    double* __restrict__ partials, const Ctrl* __restrict__ ctrl,
-                                                   const int* __restrict__ lineoff, int LW) {
+                                                   const int* __restrict__ lineoff, int LW, int fullline) {
   constexpr int BY = NW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (ctrl->done) return;
@@ -1257,10 +1257,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * NW;
       cn[rr_] = 0;
-      ln[rr_] = 0;
+      ln[rr_] = -1;
       if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
         if (COMPACT) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+      }
+      if (!COMPACT) {  // dense layout: a 16-voxel line is live when any of its 8 lanes holds a free voxel
+        const unsigned long long m = __ballot(cn[rr_] != 0);
+        ln[rr_] = (in_x && j < g.ny && gz <= g.nzl + 1 && ((m >> (lane & ~7)) & 0xffull)) ? 0 : -1;
       }
     }
   };
@@ -1274,7 +1278,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
       const int j = j0 + w + rr_ * NW;
       pn[rr_] = make_double2(0.0, 0.0);
       rn[rr_] = make_double2(0.0, 0.0);
-      if (cn[rr_]) {  // (implies in_x && j < g.ny)
+      // compacted layout: every lane of a stored line takes part, so lines are read AND written whole (a
+      // pair without a free voxel reads and writes zeros) -- no partial-line stores for HBM to merge
+      if (fullline ? ln[rr_] >= 0 : cn[rr_] != 0) {  // (implies in_x && j < g.ny)
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;            // dense: x
         const long long ev = COMPACT ? 16LL * ln[rr_] + (i & 15) : e;                         // r, q, p
         const double2 rv = ld2(r_in + ev), qv = ld2(q_in + ev);
@@ -1341,6 +1347,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * NW;
       const unsigned short cc = cc_cur[rr_];
+      if (fullline && !cc && lo_cur[rr_] >= 0)  // whole lines
+        st2(q_out + (COMPACT ? 16LL * lo_cur[rr_] + (i & 15) : (long long)gz * g.plane + (long long)j * g.pitch + i), 0.0, 0.0);
       if (cc) {  // q and every partial sum vanish where both voxels are non-free
         const int base = (w + rr_ * NW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
@@ -1390,6 +1398,8 @@ static int g_cg1_rows = 2;   // rows per thread
 static int g_cg1_waves = 8;  // waves per block: tile height = waves * rows
 static bool g_cg1_auto = true;
 static int g_cg1_xskip = 1;
+static int g_cg1_fullline = 1;  // compacted layout: read and write stored lines whole
+void set_cg1_fullline(int on) { g_cg1_fullline = on ? 1 : 0; }
 int cg1_xskip() { return g_cg1_xskip; }
 void set_cg1_xskip(int on) { g_cg1_xskip = on ? 1 : 0; }
 void set_cg1_tuning(int tile_rows) {
@@ -1409,7 +1419,7 @@ static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double*
                          const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
   hipLaunchKernelGGL((k_cg1<R, NW, PT, JAC, COMPACT>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
                      q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
-                     partial_base, partials, ctrl, lineoff, (g.pitch + 15) / 16);
+                     partial_base, partials, ctrl, lineoff, (g.pitch + 15) / 16, g_cg1_fullline);
 }
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,

@@ -256,7 +256,11 @@ static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_
 }
 
 static int g_cg1_compact = 1;  // single-kernel variant: store only the lines that hold a free voxel
-extern "C" void oi_tort_set_cg1_layout(int compact_lines) { g_cg1_compact = compact_lines ? 1 : 0; }
+extern "C" void oi_tort_set_cg1_layout(int compact_lines) {
+  // bit 0: compacted lines; bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch)
+  g_cg1_compact = (compact_lines & 1) ? 1 : 0;
+  oi::set_cg1_fullline((compact_lines & 2) ? 0 : 1);
+}
 
 // ---- construction ----------------------------------------------------------------------
 static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
