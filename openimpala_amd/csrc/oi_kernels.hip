@@ -482,6 +482,15 @@ int launch_apply(const Geom& g, const uint8_t* code, const double* v, double* q,
 // --------------------------------------------------------------------------------------
 __device__ __forceinline__ double safe_div(double a, double b) { return b != 0.0 ? a / b : 0.0; }
 
+// CG vectors vanish on non-free voxels, so a 128-byte line (8 lanes x 16 B) none of whose lanes holds a free
+// voxel is neither read nor written.  Inside a LIVE line every lane takes part (a pair without a free voxel
+// moves zeros): HBM then never has to merge a partial-line store, which measures 8-15 % faster than
+// predicating pair by pair.  Must be called by all lanes of the wave that are in the loop.
+__device__ __forceinline__ bool line_live(bool pair_live) {
+  const unsigned long long m = __ballot(pair_live);
+  return ((m >> (threadIdx.x & 56)) & 0xffull) != 0;
+}
+
 __global__ void __launch_bounds__(256) k_update_p(Geom g, const uint8_t* __restrict__ code,
                                                    const double* __restrict__ r, double* __restrict__ p, int jacobi,
                                                    const double* __restrict__ hist, int k,
@@ -490,7 +499,7 @@ __global__ void __launch_bounds__(256) k_update_p(Geom g, const uint8_t* __restr
   const double beta = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * (k - 1) + H_RZ]);
   OI_PAIR_LOOP_BEGIN
   (void)i; (void)j;
-  if (!cc) continue;  // r and p vanish on non-free voxels: such pairs are neither read nor written
+  if (!line_live(cc != 0)) continue;  // r and p vanish on non-free voxels: dead lines are neither read nor written
   const double2 rv = ld2(r + e), pv = ld2(p + e);
   const double z0 = (jacobi && c0) ? rv.x / (double)c0 : rv.x;
   const double z1 = (jacobi && c1) ? rv.y / (double)c1 : rv.y;
@@ -518,12 +527,13 @@ __global__ void __launch_bounds__(256) k_update_xr(Geom g, const uint8_t* __rest
   double rr = 0.0, rz = 0.0;
   constexpr int U = 4;
   const long long npairs = (long long)g.nzl * g.plane / 2;
-  const long long per = (npairs + gridDim.x - 1) / gridDim.x;
+  const long long per = (((npairs + gridDim.x - 1) / gridDim.x) + 7) & ~7ll;  // chunks start on a line boundary
   const long long b0 = per * blockIdx.x, b1 = min(b0 + per, npairs);
   // r, q, p vanish on non-free voxels (code 0): pairs without a free voxel are neither read nor written
   auto body = [&](long long t) {
     const long long e = g.plane + 2 * t;
-    if (*reinterpret_cast<const unsigned short*>(code + e) == 0) return;
+    const unsigned short cc_ = *reinterpret_cast<const unsigned short*>(code + e);
+    if (!line_live(cc_ != 0)) return;
     const double2 rv = ld2(r + e), qv = ld2(q + e);
     if (WITH_X) {
       const double2 xv = ld2(x + e), pv = ld2(p + e);
@@ -544,16 +554,20 @@ __global__ void __launch_bounds__(256) k_update_xr(Geom g, const uint8_t* __rest
   for (; t + (U - 1) * 256 < b1; t += U * 256) {
     double2 rv[U], qv[U];
     unsigned short cu[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cu[u] = *reinterpret_cast<const unsigned short*>(code + g.plane + 2 * (t + u * 256));
+    bool lv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      rv[u] = make_double2(0.0, 0.0); qv[u] = make_double2(0.0, 0.0);
-      if (cu[u]) { rv[u] = ld2(r + g.plane + 2 * (t + u * 256)); qv[u] = ld2(q + g.plane + 2 * (t + u * 256)); }
+      cu[u] = *reinterpret_cast<const unsigned short*>(code + g.plane + 2 * (t + u * 256));
+      lv[u] = line_live(cu[u] != 0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!cu[u]) continue;
+      rv[u] = make_double2(0.0, 0.0); qv[u] = make_double2(0.0, 0.0);
+      if (lv[u]) { rv[u] = ld2(r + g.plane + 2 * (t + u * 256)); qv[u] = ld2(q + g.plane + 2 * (t + u * 256)); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!lv[u]) continue;
       const long long e = g.plane + 2 * (t + u * 256);
       if (WITH_X) {
         const double2 xv = ld2(x + e), pv = ld2(p + e);
@@ -752,19 +766,21 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     return PIo<PT>::rnd(z + beta * (double)p_in[e]);
   };
   // p_new of plane gz for this thread's R pairs (and the p_in values for the x update)
-  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], unsigned short (&cn)[R]) {
+  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], unsigned short (&cn)[R], bool (&lv)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       pin[rr_] = make_double2(0.0, 0.0);
       pn[rr_] = make_double2(0.0, 0.0);
       cn[rr_] = 0;
+      lv[rr_] = false;
       if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
         cn[rr_] = cc;
         if (PURE && LEAN == 0) { pn[rr_] = ld2(r + e); continue; }
-        if (!cc) continue;
+        lv[rr_] = line_live(cc != 0);  // whole lines: every lane of a live line reads (and later writes)
+        if (!lv[rr_]) continue;
         if (PURE) { pn[rr_] = ld2(r + e); continue; }
         const double2 rv = ld2(r + e);
         pin[rr_] = PIo<PT>::ld_pair(p_in + e);
@@ -799,28 +815,29 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
 
   double2 pn_prev[R], pn_cur[R], pn_nxt[R], pin_cur[R], pin_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R];
-  load_plane(gs - 1, pn_prev, pin_nxt, cc_nxt);
+  bool lv_cur[R], lv_nxt[R];
+  load_plane(gs - 1, pn_prev, pin_nxt, cc_nxt, lv_nxt);
   if (!PURE && gs == 1) {  // lo ghost plane of p stays current
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
-      if (cc_nxt[rr_]) PIo<PT>::st_pair(p_out + (long long)j * g.pitch + i, pn_prev[rr_].x, pn_prev[rr_].y);
+      if (lv_nxt[rr_]) PIo<PT>::st_pair(p_out + (long long)j * g.pitch + i, pn_prev[rr_].x, pn_prev[rr_].y);
     }
   }
-  load_plane(gs, pn_cur, pin_cur, cc_cur);
+  load_plane(gs, pn_cur, pin_cur, cc_cur, lv_cur);
   stage(gs & 1, gs, pn_cur);
   __syncthreads();
 
   double pq = 0.0, pz = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt);
+    load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt, lv_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
     const double* T = tile[gz & 1];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       const unsigned short cc = cc_cur[rr_];
-      if ((PURE && LEAN == 0) ? (in_x && j < g.ny) : (cc != 0)) {
+      if ((PURE && LEAN == 0) ? (in_x && j < g.ny) : lv_cur[rr_]) {
         const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
         const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
@@ -857,12 +874,13 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         }
         pq += pc.x * q0; pq += pc.y * q1;
       }
-      if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && cc_nxt[rr_])  // hi ghost plane of p stays current
+      if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && lv_nxt[rr_])  // hi ghost plane of p stays current
         PIo<PT>::st_pair(p_out + (long long)(gz + 1) * g.plane + (long long)j * g.pitch + i, pn_nxt[rr_].x, pn_nxt[rr_].y);
     }
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; pin_cur[rr_] = pin_nxt[rr_]; cc_cur[rr_] = cc_nxt[rr_];
+      lv_cur[rr_] = lv_nxt[rr_];
     }
     __syncthreads();
   }
@@ -1030,7 +1048,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
-        if (cc) {  // b and the output vanish on non-free voxels: lines without one are not moved
+        if (line_live(cc != 0)) {  // b and the output vanish on non-free voxels: lines without one are not moved
           const double2 bv = ld2(b + e);
           bn[rr_] = bv;
           vn[rr_] = make_double2(vval(bv.x, cc & 0xffu, i, j, gz), vval(bv.y, cc >> 8, i + 1, j, gz));
@@ -1099,7 +1117,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
-        if (!cc) continue;
+        if (!line_live(cc != 0)) continue;  // (live lines are written whole)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 vc = v_cur[rr_], bc = b_cur[rr_];
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
