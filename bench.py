@@ -222,7 +222,6 @@ def main():
     # dominant kernel of the timed region, from the HIP events on the solver's stream
     main_k = max((k for k in ktimes if k in BYTES_PER_VOXEL), key=lambda k: ktimes[k][0])
     ms_launch = ktimes[main_k][0] / max(1, ktimes[main_k][1])
-    achieved = BYTES_PER_VOXEL[main_k] * (n * n * nzl) / ms_launch / 1e6
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_file):
@@ -233,21 +232,24 @@ def main():
                 traffic = ent["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
-    # The kernels predicate vector loads/stores on the code byte: 128-byte lines (16 doubles) without a free
-    # voxel are never moved.  `achieved` / `frac` keep SURVEY 8(d)'s DENSE definition (every voxel streams its
-    # 61 B); `moved_*` is the same launch priced on the lines it cannot skip -- the number that says how close
-    # the memory system itself is to its peak.
+    # The CG-form kernels never move a 128-byte line (16 doubles) of r/q/p/x that holds no free voxel, and move
+    # live lines whole.  ALGORITHMIC bytes of a launch = the code byte of every voxel + the kernel's vector
+    # bytes (SURVEY 8(d) accounting, 60 of the 61 B) for every voxel of a LIVE line; `dense_equivalent` prices the
+    # same launch as if every voxel streamed its 61 B (what earlier bench lines of this round reported, and
+    # what the metric Mvoxel-iters/s counts) -- it may exceed the HBM peak and is not a bandwidth.
     live16 = t.live_fraction(16)
-    moved = (1.0 + (BYTES_PER_VOXEL[main_k] - 1.0) * live16) * n * n * nzl
+    dense_bytes = BYTES_PER_VOXEL[main_k] * n * n * nzl
+    alg_bytes = (1.0 + (BYTES_PER_VOXEL[main_k] - 1.0) * live16) * n * n * nzl
+    achieved = alg_bytes / ms_launch / 1e6
     roofline = {"bound": "hbm", "kernel": main_k, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": BYTES_PER_VOXEL[main_k] * n * n * nzl,
-                "live_line_fraction": live16, "moved_bytes_per_launch_model": moved,
-                "moved_GBps": moved / ms_launch / 1e6, "moved_frac_of_peak": moved / ms_launch / 1e6 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg_bytes, "live_line_fraction": live16,
+                "dense_equivalent": {"bytes_per_voxel_iter": alg_bytes_iter, "bytes_per_launch": dense_bytes,
+                                     "GBps": dense_bytes / ms_launch / 1e6,
+                                     "frac_of_peak": dense_bytes / ms_launch / 1e6 / HBM_PEAK_GBS,
+                                     "survey_89B_model_frac": value * 1e6 * 89.0 / world / (HBM_PEAK_GBS * 1e9)},
                 "ms_per_launch": ms_launch,
-                "bytes_per_voxel_iter": alg_bytes_iter,
-                "iteration_GBps": alg_bytes_iter * n * n * nzl / (dt / args.steps) / 1e9,
-                "survey_89B_model_frac": value * 1e6 * 89.0 / world / (HBM_PEAK_GBS * 1e9)}
+                "bytes_per_voxel_iter_in_live_lines": alg_bytes_iter}
     t.cg_finish()
 
     # ---- wall time to relative residual 1e-6 (second half of the BASELINE metric) ----
