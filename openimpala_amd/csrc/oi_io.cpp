@@ -12,6 +12,7 @@
 //               classic TIFF and BigTIFF, both byte orders.  Anything else is reported, never guessed.
 //   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -20,14 +21,20 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/openimpala_amd.h"
 
 namespace oi {
 void set_error(const char* fmt, ...);
+const char* last_error();
 }
 
 namespace {
@@ -273,6 +280,18 @@ bool host_is_le() {
   return *reinterpret_cast<const uint8_t*>(&one) == 1;
 }
 
+// host cores this process may use (cgroup / affinity aware enough: sched_getaffinity)
+unsigned host_threads() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int n = CPU_COUNT(&set);
+    if (n > 0) return (unsigned)n;
+  }
+  const unsigned h = std::thread::hardware_concurrency();
+  return h ? h : 1;
+}
+
 // header + directory chain of one file
 oi_status open_tiff(const char* path, File& f, std::vector<Ifd>& pages) {
   if (!f.d.open(path) || f.d.size() < 8) {
@@ -372,9 +391,28 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
         src = buf.data();
         avail = buf.size();
       }
+      // unsigned 8 / 16-bit samples (what tomograms are): `(double)v > threshold` is `v > floor(threshold)`,
+      // a compare the compiler vectorises; every other type takes the generic per-sample path below
+      const bool fast = (p0.bps == 8 || p0.bps == 16) && pg.fmt == 1 && avail >= row_bytes * rows_here;
+      const long long ithr = threshold < 0.0 ? -1 : (threshold >= 65535.0 ? 65535 : (long long)std::floor(threshold));
       for (size_t r = 0; r < rows_here; ++r) {
         const size_t y = cy * ch + r;
         if (y >= H) break;
+        if (fast) {
+          const size_t x0 = cx * cw, nxr = std::min(cw, W - x0);
+          uint8_t* dst = slice + y * W + x0;
+          if (p0.bps == 8) {
+            const uint8_t* sp = src + r * row_bytes;
+            for (size_t c = 0; c < nxr; ++c) dst[c] = (long long)sp[c] > ithr ? 1 : 0;
+          } else {
+            const uint8_t* sp = src + r * row_bytes;
+            for (size_t c = 0; c < nxr; ++c) {
+              const unsigned v = f.le ? (unsigned)(sp[2 * c] | sp[2 * c + 1] << 8) : (unsigned)(sp[2 * c] << 8 | sp[2 * c + 1]);
+              dst[c] = (long long)v > ithr ? 1 : 0;
+            }
+          }
+          continue;
+        }
         for (size_t c = 0; c < cw; ++c) {
           const size_t x = cx * cw + c;
           if (x >= W) break;
@@ -419,10 +457,32 @@ extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int
   }
   uint8_t* out = (uint8_t*)malloc(W * H * (size_t)nz_local);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
-  std::vector<uint8_t> buf;
-  for (size_t k = 0; k < (size_t)nz_local; ++k) {
-    st = decode_page(path, f, pages[z0 + k], p0, z0 + k, threshold, out + k * W * H, buf);
-    if (st != OI_OK) { free(out); return st; }
+  // pages are independent: decode them on the host cores this process may use
+  std::string first_error;
+  std::mutex mu;
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  auto worker = [&]() {
+    std::vector<uint8_t> buf;
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= (size_t)nz_local || failed.load()) return;
+      const oi_status s1 = decode_page(path, f, pages[z0 + k], p0, z0 + k, threshold, out + k * W * H, buf);
+      if (s1 != OI_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed.exchange((int)s1)) first_error = oi::last_error();  // (the message is thread-local)
+      }
+    }
+  };
+  const unsigned nthreads = std::max(1u, std::min<unsigned>({host_threads(), 16u, (unsigned)nz_local}));
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  if (failed.load()) {
+    free(out);
+    oi::set_error("%s", first_error.c_str());
+    return (oi_status)failed.load();
   }
   *phase = out;
   *nx = (int)W; *ny = (int)H; *nz = (int)D;
