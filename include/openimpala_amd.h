@@ -283,6 +283,9 @@ oi_status oi_read_raw_planes(const char* path, int nx, int ny, int nz, int dtype
  * dims (Z,Y,X) in C order; classic-format files, contiguous/compact/chunked, deflate + shuffle */
 oi_status oi_read_hdf5(const char* path, const char* dataset, double threshold, uint8_t** phase, int* nx, int* ny,
                        int* nz);
+/* planes [z0, z0 + nz_local) only (nz_local < 0: all from z0): the hyperslab a rank reads (HDF5Reader.cpp:255-331) */
+oi_status oi_read_hdf5_planes(const char* path, const char* dataset, double threshold, int z0, int nz_local,
+                              uint8_t** phase, int* nx, int* ny, int* nz);
 /* DatReader::threshold (DatReader.cpp:74-160,204-241): 3 x int32 header + uint16 voxels */
 oi_status oi_read_dat(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz);
 void oi_free_host(void* p);

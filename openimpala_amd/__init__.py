@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_dat oi_free_host"
+    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host"
 ).split()
 
 
@@ -168,6 +168,7 @@ def lib():
     L.oi_read_raw.argtypes = [C.c_char_p, i, i, i, i, d, pp]
     L.oi_read_raw_planes.argtypes = [C.c_char_p, i, i, i, i, d, i, i, pp]
     L.oi_read_hdf5.argtypes = [C.c_char_p, C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.oi_read_hdf5_planes.argtypes = [C.c_char_p, C.c_char_p, d, i, i, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_read_dat.argtypes = [C.c_char_p, d, pp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_free_host.argtypes = [vp]
     L.oi_free_host.restype = None
@@ -687,14 +688,16 @@ class HDF5Reader:
     def __init__(self, filename, hdf5dataset="image"):
         self.filename, self.dataset = filename, hdf5dataset
 
-    def threshold(self, raw_threshold=0.5):
+    def threshold(self, raw_threshold=0.5, z0=0, nz_local=None):
+        """z0 / nz_local: only the planes [z0, z0 + nz_local) of the dataset (a rank's z-slab)."""
         p = C.c_void_p()
         nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
-        _check(lib().oi_read_hdf5(self.filename.encode(), self.dataset.encode(), raw_threshold, C.byref(p),
-                                  C.byref(nx), C.byref(ny), C.byref(nz)))
+        _check(lib().oi_read_hdf5_planes(self.filename.encode(), self.dataset.encode(), raw_threshold, int(z0),
+                                         -1 if nz_local is None else int(nz_local), C.byref(p), C.byref(nx), C.byref(ny),
+                                         C.byref(nz)))
+        depth = nz.value - int(z0) if nz_local is None else int(nz_local)
         try:
-            n = nx.value * ny.value * nz.value
-            out = _take_bytes(p, n)
+            out = _take_bytes(p, nx.value * ny.value * depth)
         finally:
             lib().oi_free_host(p)
-        return out.reshape(nz.value, ny.value, nx.value)
+        return out.reshape(depth, ny.value, nx.value)

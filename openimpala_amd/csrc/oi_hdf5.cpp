@@ -8,6 +8,10 @@
 // B-tree + local heap), contiguous, compact and chunked (v1 chunk B-tree) layouts, optional
 // deflate / shuffle filters (zlib).  "Latest format" files (superblock v2/v3, v2 object
 // headers, fractal-heap groups) are reported as unsupported, never guessed.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -27,8 +31,32 @@ namespace {
 
 constexpr uint64_t kUndef = ~0ULL;
 
+// read-only memory map of the file: a plane-range read only pages in the bytes it decodes
+struct Mapped {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  Mapped() = default;
+  Mapped(const Mapped&) = delete;
+  Mapped& operator=(const Mapped&) = delete;
+  ~Mapped() { if (p) munmap(const_cast<uint8_t*>(p), n); }
+  bool open(const char* path) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { ::close(fd); return false; }
+    n = (size_t)st.st_size;
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { n = 0; return false; }
+    p = (const uint8_t*)m;
+    return true;
+  }
+  size_t size() const { return n; }
+  const uint8_t& operator[](size_t i) const { return p[i]; }
+};
+
 struct H5 {
-  std::vector<uint8_t> f;
+  Mapped f;
   uint64_t base = 0;
   std::string err;
 
@@ -221,27 +249,17 @@ bool for_each_chunk(const H5& h, const Dataset& d, uint64_t node, F&& fn, int de
   return true;
 }
 
-bool slurp(const char* path, std::vector<uint8_t>& out) {
-  FILE* fp = fopen(path, "rb");
-  if (!fp) return false;
-  fseek(fp, 0, SEEK_END);
-  const long n = ftell(fp);
-  fseek(fp, 0, SEEK_SET);
-  if (n < 0) { fclose(fp); return false; }
-  out.resize((size_t)n);
-  const size_t got = n ? fread(out.data(), 1, (size_t)n, fp) : 0;
-  fclose(fp);
-  return got == (size_t)n;
-}
 
 }  // namespace
 
-extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double threshold, uint8_t** phase, int* nx,
-                                  int* ny, int* nz) {
-  if (!path || !dataset || !phase || !nx || !ny || !nz) return OI_BAD_ARG;
+// planes [z0, z0 + nz_local) of the dataset (nz_local < 0: all from z0; the hyperslab each rank of the reference
+// reads, HDF5Reader.cpp:255-331); *nz = depth of the dataset
+extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, double threshold, int z0, int nz_local,
+                                         uint8_t** phase, int* nx, int* ny, int* nz) {
+  if (!path || !dataset || !phase || !nx || !ny || !nz || z0 < 0) return OI_BAD_ARG;
   *phase = nullptr;
   H5 h;
-  if (!slurp(path, h.f)) { oi::set_error("cannot read HDF5 file '%s'", path); return OI_IO_ERROR; }
+  if (!h.f.open(path)) { oi::set_error("cannot read HDF5 file '%s'", path); return OI_IO_ERROR; }
   static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
   uint64_t sb = kUndef;
   for (uint64_t off = 0; off + 8 <= h.f.size(); off = off ? off * 2 : 512)  // signature at 0, 512, 1024, ...
@@ -297,7 +315,13 @@ extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double 
     oi::set_error("'%s': invalid dataset dimensions", path);
     return OI_IO_ERROR;
   }
-  const uint64_t n = X * Y * Z, es = (uint64_t)d.type_size;
+  if (nz_local < 0) nz_local = (int)Z - z0;
+  if (nz_local < 1 || (uint64_t)z0 + (uint64_t)nz_local > Z) {
+    oi::set_error("'%s': planes [%d, %d) are outside the dataset of %llu", path, z0, z0 + nz_local, (unsigned long long)Z);
+    return OI_BAD_ARG;
+  }
+  const uint64_t za = (uint64_t)z0, zb = za + (uint64_t)nz_local;  // planes [za, zb)
+  const uint64_t n = X * Y * (zb - za), es = (uint64_t)d.type_size;
   uint8_t* out = (uint8_t*)calloc(n, 1);  // unallocated storage reads as fill value 0
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   auto fail = [&](const char* msg) { free(out); oi::set_error("'%s' [%s]: %s", path, dataset, msg); return OI_IO_ERROR; };
@@ -307,8 +331,9 @@ extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double 
     if (d.layout == 1 && d.data_addr == kUndef) {  // never written: all fill value
       for (uint64_t v = 0; v < n; ++v) out[v] = 0.0 > threshold ? 1 : 0;
     } else {
-      if (!h.ok(src, n * es)) return fail("raw data outside the file");
-      for (uint64_t v = 0; v < n; ++v) out[v] = elem_as_double(&h.f[src + v * es], d) > threshold ? 1 : 0;
+      if (!h.ok(src, X * Y * Z * es)) return fail("raw data outside the file");
+      const uint64_t first = X * Y * za;
+      for (uint64_t v = 0; v < n; ++v) out[v] = elem_as_double(&h.f[src + (first + v) * es], d) > threshold ? 1 : 0;
     }
   } else if (d.layout == 2) {
     if (d.chunk_rank != 4) return fail("chunk rank does not match the dataset rank");
@@ -321,6 +346,7 @@ extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double 
     std::string cerr;
     if (d.chunk_btree != kUndef) {
       good = for_each_chunk(h, d, h.base + d.chunk_btree, [&](const uint64_t* offs, uint64_t addr, uint64_t nbytes) {
+        if (offs[0] >= zb || offs[0] + cz <= za) return true;  // chunk outside the requested planes
         if (!h.ok(addr, nbytes)) { cerr = "chunk outside the file"; return false; }
         const uint8_t* src = &h.f[addr];
         if (d.f_deflate) {
@@ -334,12 +360,14 @@ extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double 
             for (uint64_t b = 0; b < es; ++b) tmp[e * es + b] = src[b * ne + e];
           src = tmp.data();
         }
-        for (uint64_t k = 0; k < cz && offs[0] + k < Z; ++k)
+        for (uint64_t k = 0; k < cz && offs[0] + k < zb; ++k) {
+          if (offs[0] + k < za) continue;
           for (uint64_t j = 0; j < cy && offs[1] + j < Y; ++j)
             for (uint64_t i = 0; i < cx && offs[2] + i < X; ++i) {
               const uint64_t se = (k * cy + j) * cx + i;
-              out[((offs[0] + k) * Y + offs[1] + j) * X + offs[2] + i] = elem_as_double(src + se * es, d) > threshold ? 1 : 0;
+              out[((offs[0] + k - za) * Y + offs[1] + j) * X + offs[2] + i] = elem_as_double(src + se * es, d) > threshold ? 1 : 0;
             }
+        }
         return true;
       });
     }
@@ -350,4 +378,9 @@ extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double 
   *phase = out;
   *nx = (int)X; *ny = (int)Y; *nz = (int)Z;
   return OI_OK;
+}
+
+extern "C" oi_status oi_read_hdf5(const char* path, const char* dataset, double threshold, uint8_t** phase, int* nx,
+                                  int* ny, int* nz) {
+  return oi_read_hdf5_planes(path, dataset, threshold, 0, -1, phase, nx, ny, nz);
 }

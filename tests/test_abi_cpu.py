@@ -230,3 +230,15 @@ def test_readers_load_a_z_slab_only(tmp_path):
     assert np.array_equal(rr.threshold(30000.0), (vals > 30000).astype(np.uint8))
     with pytest.raises(oia.OpenImpalaError):
         rr.threshold(1.0, z0=8, nz_local=2)
+    # HDF5: contiguous and chunked + filtered layouts (the chunk index is walked, only chunks that meet the planes are decoded)
+    from h5write import write_h5
+    hv = np.random.default_rng(8).integers(0, 4000, size=(11, 10, 13)).astype("<u2")
+    for n_, (chunks, gz, sh) in enumerate(((None, False, False), ((4, 5, 8), True, True), ((3, 10, 13), False, False))):
+        hp = tmp_path / f"s{n_}.h5"
+        write_h5(str(hp), hv, names=("image",), chunks=chunks, gzip=gz, shuffle=sh)
+        hr = oia.HDF5Reader(str(hp), "image")
+        assert np.array_equal(hr.threshold(2000.0, z0=3, nz_local=6), (hv[3:9] > 2000).astype(np.uint8)), chunks
+        assert np.array_equal(hr.threshold(2000.0, z0=9), (hv[9:] > 2000).astype(np.uint8))
+        assert np.array_equal(hr.threshold(2000.0), (hv > 2000).astype(np.uint8))
+        with pytest.raises(oia.OpenImpalaError):
+            hr.threshold(1.0, z0=10, nz_local=2)
