@@ -1,0 +1,170 @@
+// tTortuosity.cpp -- the reference's own test of the hot path (src/props/tTortuosity.cpp) restated over the
+// drop-in class: same inputs keys (tests/inputs/tTortuosity.inputs), same sequence of checks, same verdict.
+//
+//   read the TIFF, threshold            tTortuosity.cpp:196-227   -> oi_read_tiff, "phase field uniform" check
+//   volume fraction (+ expected_vf)     :229-256                  -> oi_volume_fraction
+//   construct the solver                :266-283                  -> OpenImpala::TortuosityMI355
+//   checkMatrixProperties()             :285-296
+//   value(), finite?                    :298-325
+//   expected_tau within tau_tolerance   :327-346
+// Exit code 0 = PASS, 1 = FAIL (the reference aborts on FAIL).
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <filesystem>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../include/TortuosityMI355.H"
+#include "Inputs.H"
+
+namespace {
+struct Status {
+  bool passed = true;
+  std::vector<std::string> reasons;
+  void fail(const std::string& why) { passed = false; reasons.push_back(why); }
+};
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  if (argc < 2) {
+    std::cerr << "usage: tTortuosity <inputs file> [key=value ...]\n";
+    return 2;
+  }
+  Status st;
+  try {
+    oi::Inputs in;
+    in.load_file(argv[1]);
+    for (int a = 2; a < argc; ++a) in.add_argument(argv[a]);
+    std::string tifffile, resultsdir = "./tortuosity_results", direction_str = "X", solver_str = "FlexGMRES";
+    int phase_id = 1, box_size = 32, verbose = 1, write_plotfile = 0;
+    double expected_vf = -1.0, expected_tau = -1.0, vf_tol = 1e-9, tau_tol = 1e-5, threshold = 0.5, v_lo = 0.0, v_hi = 1.0;
+    in.get("tifffile", tifffile);
+    in.query("resultsdir", resultsdir);
+    in.query("phase_id", phase_id);
+    in.query("direction", direction_str);
+    in.query("solver", solver_str);
+    in.query("box_size", box_size);
+    in.query("verbose", verbose);
+    in.query("write_plotfile", write_plotfile);
+    in.query("expected_vf", expected_vf);
+    in.query("expected_tau", expected_tau);
+    in.query("vf_tolerance", vf_tol);
+    in.query("tau_tolerance", tau_tol);
+    in.query("threshold_val", threshold);
+    in.query("v_lo", v_lo);
+    in.query("v_hi", v_hi);
+    oi_tort_opts opts;
+    oi_tort_default_opts(&opts);
+    in.query("hypre.eps", opts.eps);
+    in.query("tortuosity.remspot_passes", opts.remspot_passes);
+    opts.precond = OI_PRECOND_MG;  // one multigrid cycle per Krylov iteration, as FlexGMRES + SMG in the reference
+    int hypre_maxiter = 0;
+    if (in.query("hypre.maxiter", hypre_maxiter) && hypre_maxiter > 0) opts.maxiter = hypre_maxiter;  // counts the same kind of iteration
+
+    OpenImpala::Direction dir = OpenImpala::Direction::X;
+    if (direction_str == "Y" || direction_str == "y") dir = OpenImpala::Direction::Y;
+    else if (direction_str == "Z" || direction_str == "z") dir = OpenImpala::Direction::Z;
+    else if (!(direction_str == "X" || direction_str == "x")) throw std::runtime_error("Invalid direction string: " + direction_str);
+    using TM = OpenImpala::TortuosityMI355;
+    TM::SolverType solver = TM::SolverType::FlexGMRES;
+    if (solver_str == "Jacobi") solver = TM::SolverType::Jacobi;
+    else if (solver_str == "GMRES") solver = TM::SolverType::GMRES;
+    else if (solver_str == "PCG") solver = TM::SolverType::PCG;
+    else if (solver_str == "BiCGSTAB") solver = TM::SolverType::BiCGSTAB;
+    else if (solver_str != "FlexGMRES") throw std::runtime_error("Invalid solver string: " + solver_str);
+
+    if (verbose >= 1)
+      std::cout << "\n--- Tortuosity Test Configuration ---\n  TIF File:          " << tifffile << "\n  Phase ID:          " << phase_id
+                << "\n  Direction:         " << direction_str << "\n  Solver:            " << solver_str
+                << "\n  Box Size:          " << box_size << " (ignored: no BoxArray)\n  Threshold Value:   " << threshold << "\n";
+
+    // ---- read + threshold (:196-227) ----
+    uint8_t* phase = nullptr;
+    int nx = 0, ny = 0, nz = 0, bps = 0;
+    oi_status rs = oi_read_tiff(tifffile.c_str(), threshold, &phase, &nx, &ny, &nz, &bps);
+    if (rs != OI_OK) throw std::runtime_error(std::string("reading the TIFF failed: ") + oi_last_error());
+    std::unique_ptr<uint8_t, void (*)(uint8_t*)> phase_guard(phase, [](uint8_t* p) { oi_free_host(p); });
+    const size_t n = (size_t)nx * ny * nz;
+    uint8_t lo = 255, hi = 0;
+    for (size_t v = 0; v < n; ++v) { lo = std::min(lo, phase[v]); hi = std::max(hi, phase[v]); }
+    if (lo == hi) st.fail("Phase field uniform after thresholding.");
+
+    // ---- volume fraction (:229-256) ----
+    double actual_vf = 0.0;
+    if (st.passed) {
+      int64_t pc = 0, tc = 0;
+      if (oi_volume_fraction(phase, n, phase_id, &pc, &tc) != OI_OK) throw std::runtime_error(oi_last_error());
+      actual_vf = tc > 0 ? (double)pc / (double)tc : 0.0;
+      std::cout << " Volume Fraction (Phase " << phase_id << "): " << std::fixed << std::setprecision(8) << actual_vf << "\n";
+      if (expected_vf >= 0.0) {
+        if (std::abs(actual_vf - expected_vf) > vf_tol)
+          st.fail("Volume fraction mismatch. Expected: " + std::to_string(expected_vf) + ", Actual: " + std::to_string(actual_vf));
+        else
+          std::cout << " Volume Fraction Check:      PASS\n";
+      }
+    }
+
+    // ---- solver (:258-346) ----
+    double actual_tau = std::numeric_limits<double>::quiet_NaN();
+    if (st.passed && actual_vf > std::numeric_limits<double>::epsilon()) {
+      if (!resultsdir.empty()) std::filesystem::create_directories(resultsdir);
+      std::unique_ptr<TM> tort;
+      try {
+        tort = std::make_unique<TM>(phase, nx, ny, nz, actual_vf, phase_id, dir, solver, resultsdir, v_lo, v_hi, verbose,
+                                    write_plotfile != 0, &opts);
+      } catch (const std::exception& e) {
+        st.fail(std::string("TortuosityMI355 construction failed: ") + e.what());
+      }
+      if (st.passed && tort) {
+        std::cout << " Performing mathematical checks on the matrix...\n";
+        if (!tort->checkMatrixProperties()) st.fail("Matrix/vector failed property checks.");
+        else std::cout << " Matrix property checks:     PASS\n";
+      }
+      if (st.passed && tort) {
+        try {
+          actual_tau = tort->value();
+          if (std::isnan(actual_tau) || std::isinf(actual_tau))
+            st.fail("Calculated tortuosity is NaN or Inf! Indicates potential solver or calculation failure.");
+          else
+            std::cout << " Value Calculation Check:    PASS (Result is finite)\n";
+          std::cout << " Solver iterations: " << tort->getSolverIterations() << ", final relative residual "
+                    << std::scientific << tort->getFinalRelativeResidualNorm() << ", converged "
+                    << (tort->getSolverConverged() ? "yes" : "no") << "\n Flux in / out: " << std::fixed << std::setprecision(8)
+                    << tort->getFluxIn() << " / " << tort->getFluxOut() << "\n";
+        } catch (const std::exception& e) {
+          st.fail(std::string("Exception during Tortuosity calculation: ") + e.what());
+        }
+      }
+      if (st.passed && !(std::isnan(actual_tau) || std::isinf(actual_tau))) {
+        std::cout << " Final Calculated Tortuosity: " << std::fixed << std::setprecision(8) << actual_tau << "\n";
+        if (expected_tau >= 0.0) {
+          if (std::abs(actual_tau - expected_tau) > tau_tol)
+            st.fail("Tortuosity mismatch. Diff: " + std::to_string(std::abs(actual_tau - expected_tau)) + " > Tolerance: " +
+                    std::to_string(tau_tol));
+          else
+            std::cout << " Tortuosity Value Check:    PASS\n";
+        } else {
+          std::cout << " Tortuosity Value Check:    SKIPPED\n";
+        }
+      }
+    } else if (st.passed) {
+      std::cout << " Skipping Tortuosity calculation because Volume Fraction is effectively zero (" << actual_vf << ").\n";
+      if (expected_tau >= 0.0) st.fail("Volume Fraction is zero, but an expected_tau > 0 was provided.");
+    }
+  } catch (const std::exception& e) {
+    st.fail(std::string("exception: ") + e.what());
+  }
+  std::cout << "\n--- Test Summary ---\n";
+  if (st.passed) {
+    std::cout << " TEST RESULT: PASS\n";
+    return 0;
+  }
+  for (const auto& r : st.reasons) std::cout << "   - " << r << "\n";
+  std::cout << " TEST RESULT: FAIL\n";
+  return 1;
+}

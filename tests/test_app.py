@@ -203,3 +203,37 @@ write_plotfile = 1
     assert phi.min() >= g["vlo"] - 1e-9 and phi.max() <= g["vhi"] + 1e-9 and phi[0].min() == g["vlo"]
     r = subprocess.run([app, _inputs(tmp_path, text), "gpu.ngpus=4", "gpu.transport=rccl"], capture_output=True, text=True)
     assert r.returncode == 1 and "GPU(s) are visible" in r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_tTortuosity_inputs(tmp_path, goldens):
+    """apps/tTortuosity restates the reference's own test of this path (src/props/tTortuosity.cpp) over the drop-in
+    class; fed the reference's tests/inputs/tTortuosity.inputs values (phase 0, X, FlexGMRES, eps 1e-10, maxiter
+    1000) plus the expected values BASELINE.md pins, it must say PASS -- and FAIL on a wrong expectation."""
+    exe = os.path.join(ROOT, "apps", "tTortuosity")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    g = goldens["phases"]["0"]
+    text = f"""
+tifffile = {GOLDEN}/SampleData_2Phase_stack_3d_1bit.tif
+resultsdir = {tmp_path}/res
+phase_id = 0          # ID of the phase to calculate tortuosity for
+direction = X         # X, Y, or Z
+solver = FlexGMRES
+hypre.maxiter = 1000     # Max solver iterations
+hypre.eps = 1e-10        # Solver relative tolerance
+verbose = 2
+tortuosity.remspot_passes = 0
+expected_vf = {g["volume_fraction"]}
+vf_tolerance = 1e-6
+expected_tau = {g["tau"][0]}
+tau_tolerance = 1e-5
+"""
+    r = subprocess.run([exe, _inputs(tmp_path, text)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr
+    for line in ("Volume Fraction Check:      PASS", "Matrix property checks:     PASS", "Value Calculation Check:    PASS",
+                 "Tortuosity Value Check:    PASS", "TEST RESULT: PASS"):
+        assert line in r.stdout, line
+    r = subprocess.run([exe, _inputs(tmp_path, text), "expected_tau=1.5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Tortuosity mismatch" in r.stdout and "TEST RESULT: FAIL" in r.stdout
+    r = subprocess.run([exe, _inputs(tmp_path, text), "threshold_val=5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Phase field uniform after thresholding." in r.stdout
