@@ -907,6 +907,28 @@ void set_apply_tuning(int tile_rows) {
   if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_pure_rows = tile_rows / 8;
 }
 
+// Planes per block of the z-marching kernels.  Large volumes: >= ~4096 blocks, but chunks of >= 64 planes so the
+// two redundant halo planes per chunk stay near 3 %.  Small volumes (the reference's 100^3 sample gives 7 tile
+// columns) would leave most of the 256 CUs idle behind a few long marches: there the chunks shrink, down to 8
+// planes, until ~1024 blocks exist -- the march is latency-bound, so halo planes are cheap next to idle CUs.
+static int pick_zchunk(const Geom& g, long long cols) {
+  long long want = (4096 + cols - 1) / cols;
+  if (want < 1) want = 1;
+  long long zc = (g.nzl + want - 1) / want;
+  if (zc < 64) {
+    const long long blocks64 = cols * ((g.nzl + 63) / 64);
+    if (blocks64 >= 1024) {
+      zc = 64;
+    } else {
+      zc = ((long long)g.nzl * cols + 1023) / 1024;
+      if (zc < 8) zc = 8;
+      if (zc > 64) zc = 64;
+      zc = (zc + 1) & ~1ll;  // even: z pairs of the fused restriction stay inside a chunk
+    }
+  }
+  return (int)zc;
+}
+
 template <int R, bool PURE, typename PT, int LEAN>
 static void launch_tiled_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
                            void* p_out, double* q, int jacobi, const double* hist, int k, int zchunk, int tiles_x,
@@ -924,12 +946,7 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
   const long long cols = (long long)tiles_x * tiles_y;
   int zchunk = g_fused_zchunk;
   if (zchunk <= 0) {
-    // >= ~4096 blocks when the volume allows it, but chunks of >= 64 planes so the two
-    // redundant halo planes per chunk stay near 3 %
-    long long want = (4096 + cols - 1) / cols;
-    if (want < 1) want = 1;
-    zchunk = (int)((g.nzl + want - 1) / want);
-    if (zchunk < 64) zchunk = 64;
+    zchunk = pick_zchunk(g, cols);
   }
   if (zchunk > g.nzl) zchunk = g.nzl;
   int nzc = (g.nzl + zchunk - 1) / zchunk;
@@ -1156,10 +1173,7 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
   const int by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
-  long long want = (4096 + cols - 1) / cols;
-  if (want < 1) want = 1;
-  int zchunk = (int)((g.nzl + want - 1) / want);
-  if (zchunk < 64) zchunk = 64;
+  int zchunk = pick_zchunk(g, cols);
   if (zchunk > g.nzl) zchunk = g.nzl;
   int nzc = (g.nzl + zchunk - 1) / zchunk;
   if (cols * nzc > kMaxPartials) {
@@ -1476,10 +1490,7 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
     if (zchunk > 64) zchunk = 64;
     if (zchunk < 16) zchunk = 16;
   } else {
-    long long want = (4096 + cols - 1) / cols;
-    if (want < 1) want = 1;
-    zchunk = (int)((g.nzl + want - 1) / want);
-    if (zchunk < 64) zchunk = 64;
+    zchunk = pick_zchunk(g, cols);
   }
   if (zchunk > g.nzl) zchunk = g.nzl;
   int nzc = (g.nzl + zchunk - 1) / zchunk;
