@@ -206,12 +206,11 @@ write_plotfile = 1
 
 
 @pytest.mark.gpu
-def test_reference_tTortuosity_inputs(tmp_path, goldens):
+def test_reference_tTortuosity_inputs(app, tmp_path, goldens):
     """apps/tTortuosity restates the reference's own test of this path (src/props/tTortuosity.cpp) over the drop-in
     class; fed the reference's tests/inputs/tTortuosity.inputs values (phase 0, X, FlexGMRES, eps 1e-10, maxiter
     1000) plus the expected values BASELINE.md pins, it must say PASS -- and FAIL on a wrong expectation."""
-    exe = os.path.join(ROOT, "apps", "tTortuosity")
-    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    exe = os.path.join(ROOT, "apps", "tTortuosity")   # built by the `app` fixture (make -C apps)
     g = goldens["phases"]["0"]
     text = f"""
 tifffile = {GOLDEN}/SampleData_2Phase_stack_3d_1bit.tif
