@@ -1003,14 +1003,6 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 // b vanishes on non-free cells and its ghost planes hold the neighbour slabs' values; xc is the
 // fp32 coarse correction of the 2x2x2 aggregates.
 // --------------------------------------------------------------------------------------
-// 1 / c for a neighbour count c in 1..6: v_rcp_f32 plus one Newton step in fp64 (relative error
-// < 1e-13) instead of the ~40-instruction IEEE fp64 division; the smoother only needs a fixed
-// positive diagonal scaling, applied identically everywhere
-__device__ __forceinline__ double inv_count(unsigned c) {
-  const double d = (double)c, y = (double)__builtin_amdgcn_rcpf((float)c);
-  return y * (2.0 - d * y);
-}
-
 template <int R, int MODE>
 __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
                                                        const double* __restrict__ b, MgCoarse C, double omega, double scale,
@@ -1024,6 +1016,9 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
   __shared__ double red[kNW];
   __shared__ double ysum[MODE == 3 ? 2 : 1][MODE == 3 ? R * (kNW / 2) * 64 : 1];
+  __shared__ double wtab[8];  // omega / c for the neighbour counts c = 1..6 (0 for c = 0): one LDS read replaces a division
+  if (threadIdx.x < 8) wtab[threadIdx.x] = threadIdx.x ? omega / (double)threadIdx.x : 0.0;
+  __syncthreads();
   const int ntiles = tiles_x * tiles_y * nzc;
   int L = blockIdx.x;
   if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
@@ -1040,21 +1035,20 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
 
   // v at one voxel (the pad column and the ghost planes beyond the domain hold code 0, so the coarse
   // correction is never indexed for them; ghost planes of a neighbour slab map to its ghost coarse plane)
-  auto vval = [&](double bv, unsigned c, int ii, int jj, int gz) -> double {
-    if (!c) return 0.0;
-    double v = omega * bv * inv_count(c);
-    if (MODE == 2) {
-      const long long cm = (long long)(ii >> 1) + (long long)C.cnx * (jj >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
-      float cv = C.xc[cm];
-      if (C.xc2) cv += C.xc2[cm];
-      v += scale * (double)cv;
-    }
-    return v;
+  // scaled coarse correction of the aggregate that holds voxel (ii, jj, gz)
+  auto corr_at = [&](int ii, int jj, int gz) -> double {
+    const long long cm = (long long)(ii >> 1) + (long long)C.cnx * (jj >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+    float cv = C.xc[cm];
+    if (C.xc2) cv += C.xc2[cm];
+    return scale * (double)cv;
   };
   auto v_at = [&](int ii, int jj, int gz) -> double {
     const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
     const unsigned c = code[e];
-    return c ? vval(b[e], c, ii, jj, gz) : 0.0;
+    if (!c) return 0.0;
+    double v = b[e] * wtab[c];
+    if (MODE == 2) v += corr_at(ii, jj, gz);
+    return v;
   };
   auto load_plane = [&](int gz, double2 (&vn)[R], double2 (&bn)[R]) {
 #pragma unroll
@@ -1068,7 +1062,13 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         if (line_live(cc != 0)) {  // b and the output vanish on non-free voxels: lines without one are not moved
           const double2 bv = ld2(b + e);
           bn[rr_] = bv;
-          vn[rr_] = make_double2(vval(bv.x, cc & 0xffu, i, j, gz), vval(bv.y, cc >> 8, i + 1, j, gz));
+          double v0 = bv.x * wtab[cc & 0xffu], v1 = bv.y * wtab[cc >> 8];
+          if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
+            const double cr = corr_at(i, j, gz);
+            if (cc & 0xffu) v0 += cr;
+            if (cc >> 8) v1 += cr;
+          }
+          vn[rr_] = make_double2(v0, v1);
         }
       }
     }
@@ -1140,8 +1140,8 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
         const double s1 = ((((vc.x + rt.x) + ym.y) + yp.y) + v_prev[rr_].y) + v_nxt[rr_].y;
         double o0 = 0.0, o1 = 0.0;
-        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + omega * (bc.x - av) * inv_count(c0); }
-        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + omega * (bc.y - av) * inv_count(c1); }
+        if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + (bc.x - av) * wtab[c0]; }
+        if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + (bc.y - av) * wtab[c1]; }
         if (MODE == 3) { xsum[rr_] = o0 + o1; continue; }
         st2(out + e, o0, o1);
         dot += o0 * bc.x; dot += o1 * bc.y;
