@@ -122,8 +122,13 @@ __global__ void __launch_bounds__(256) k_ed_apply(Geom g, const uint8_t* __restr
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(t % g.nx), j = (int)((t / g.nx) % g.ny), gz = 1 + (int)(t / ((long long)g.nx * g.ny));
     const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    // q vanishes on inactive cells and its buffer holds zeros there: groups of 8 lanes (64 B of q) without an
+    // active cell are skipped, the others are written whole
+    const bool act = code[e] != 0;
+    const unsigned long long mlive = __ballot(act);
+    if (((mlive >> (threadIdx.x & 56)) & 0xffull) == 0) continue;
     double out = 0.0;
-    if (code[e]) {
+    if (act) {
       const double c = v[e];
       const double s = ((((v[eidx(g, gz, j, i - 1)] + v[eidx(g, gz, j, i + 1)]) + v[eidx(g, gz, j - 1, i)]) +
                          v[eidx(g, gz, j + 1, i)]) + v[e - g.plane]) + v[e + g.plane];
