@@ -1,10 +1,10 @@
 """Design experiment behind openimpala_amd/csrc/oi_mg.hip: scipy prototype of the 2x2x2 aggregation
 multigrid preconditioner on the oracle's system (CPU only, test/experiment infrastructure).
 Output of one run is kept in profiles/r01/mg_prototype.txt."""
-import sys, time; import os; sys.path.insert(0,os.path.join(os.path.dirname(os.path.abspath(__file__)),'..'))
+import sys, time; import os; sys.path.insert(0,os.path.join(os.path.dirname(os.path.abspath(__file__)),'..','..'))
 import numpy as np, scipy.sparse as sp
 from oracle import oracle as o
-ph0 = o.read_tiff_phase(os.path.join(os.path.dirname(os.path.abspath(__file__)),'..','tests','golden')+'/SampleData_2Phase_stack_3d_1bit.tif')
+ph0 = o.read_tiff_phase(os.path.join(os.path.dirname(os.path.abspath(__file__)),'..','golden')+'/SampleData_2Phase_stack_3d_1bit.tif')
 def build(ph, pid, d, vlo, vhi):
     mask,_=o.active_mask(ph,pid,d); code=o.codes(mask,d); nz,ny,nx=ph.shape
     free=(code>0); idx=-np.ones(ph.size,np.int64); fidx=np.nonzero(free.reshape(-1))[0]; idx[fidx]=np.arange(fidx.size)
