@@ -184,7 +184,8 @@ oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int
 oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q, int variant);
 oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
 /* run the stand-alone stencil apply `reps` times on device-resident vectors and
- * return the HIP-event time of the launches (ms per launch) */
+ * return the HIP-event time of the launches (ms per launch); variant OI_KERNEL_LEAN = the apply as the CG
+ * uses it (a vector that vanishes off the free set, live-line predication) */
 oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_launch);
 
 /* process-wide tuning of the fused CG kernel: rows per LDS tile (4 or 8) and planes per

@@ -84,6 +84,9 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
+// the same for a CG vector (vanishing on non-free voxels): lines without a free voxel are skipped
+int launch_apply_cgvec(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials, const Ctrl* ctrl,
+                       hipStream_t s);
 // q-free CG iteration of the capacity mode (x, r, p only): p.Ap without storing q, then
 // x += alpha p, r -= alpha A p with A p recomputed on the fly; partials {p.q} / {r.r, r.z}
 int launch_lean_dot(const Geom& g, const uint8_t* code, const double* p, double* partials, const Ctrl* ctrl,

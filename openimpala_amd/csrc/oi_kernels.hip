@@ -709,6 +709,7 @@ constexpr int kBX = 128;            // tile width in voxels = 64 lanes x 2
 constexpr int kLP = kBX + 4;        // LDS row pitch in doubles
 constexpr int kNW = 8;              // waves per block
 
+// LEAN = 3 (with PURE): the stand-alone apply for a CG vector, predicated on live lines like the CG kernels.
 // LEAN (with PURE) turns the apply into the two stencil passes of the q-free CG iteration, the
 // capacity mode that stores x, r, p only (25 B/voxel): LEAN = 1 reduces p.Ap without storing q;
 // LEAN = 2 recomputes q = A p on the fly and applies x += alpha p, r -= alpha q (`q` argument = r
@@ -766,18 +767,27 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     return PIo<PT>::rnd(z + beta * (double)p_in[e]);
   };
   // p_new of plane gz for this thread's R pairs (and the p_in values for the x update)
-  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], unsigned short (&cn)[R], bool (&lv)[R]) {
+  // code bytes of this thread's pairs in plane gz, fetched ONE PLANE AHEAD of the vectors: the predicate of
+  // the vector loads is then in registers when they are issued (one memory latency per plane, not two)
+  auto load_codes = [&](int gz, unsigned short (&cn)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      cn[rr_] = 0;
+      if (in_x && j < g.ny && gz <= g.nzl + 1)
+        cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
+    }
+  };
+  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], const unsigned short (&cn)[R], bool (&lv)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       pin[rr_] = make_double2(0.0, 0.0);
       pn[rr_] = make_double2(0.0, 0.0);
-      cn[rr_] = 0;
       lv[rr_] = false;
       if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
-        cn[rr_] = cc;
+        const unsigned short cc = cn[rr_];
         if (PURE && LEAN == 0) { pn[rr_] = ld2(r + e); continue; }
         lv[rr_] = line_live(cc != 0);  // whole lines: every lane of a live line reads (and later writes)
         if (!lv[rr_]) continue;
@@ -814,8 +824,11 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
   };
 
   double2 pn_prev[R], pn_cur[R], pn_nxt[R], pin_cur[R], pin_nxt[R];
-  unsigned short cc_cur[R], cc_nxt[R];
+  unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
   bool lv_cur[R], lv_nxt[R];
+  load_codes(gs - 1, cc_nxt);
+  load_codes(gs, cc_cur);
+  load_codes(gs + 1, cc_nn);
   load_plane(gs - 1, pn_prev, pin_nxt, cc_nxt, lv_nxt);
   if (!PURE && gs == 1) {  // lo ghost plane of p stays current
 #pragma unroll
@@ -825,11 +838,14 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     }
   }
   load_plane(gs, pn_cur, pin_cur, cc_cur, lv_cur);
+#pragma unroll
+  for (int rr_ = 0; rr_ < R; ++rr_) cc_nxt[rr_] = cc_nn[rr_];  // codes of plane gs + 1
   stage(gs & 1, gs, pn_cur);
   __syncthreads();
 
   double pq = 0.0, pz = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
+    load_codes(gz + 2, cc_nn);
     load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt, lv_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
     const double* T = tile[gz & 1];
@@ -864,7 +880,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
           pz += r0 * z0; pz += r1 * z1;
           continue;
         }
-        if (LEAN == 0) st2(q + e, q0, q1);
+        if (LEAN == 0 || LEAN == 3) st2(q + e, q0, q1);
         if (!PURE) {
           PIo<PT>::st_pair(p_out + e, pc.x, pc.y);
           if (k > 0) {
@@ -880,6 +896,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; pin_cur[rr_] = pin_nxt[rr_]; cc_cur[rr_] = cc_nxt[rr_];
+      cc_nxt[rr_] = cc_nn[rr_];
       lv_cur[rr_] = lv_nxt[rr_];
     }
     __syncthreads();
@@ -968,6 +985,11 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
   return blocks;
 }
 
+// q = A v for a CG vector (v vanishes on non-free voxels): the stand-alone apply with live-line predication
+int launch_apply_cgvec(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials, const Ctrl* ctrl,
+                       hipStream_t s) {
+  return launch_tiled<true, double, 3>(g, code, nullptr, v, nullptr, nullptr, q, 0, nullptr, 0, partials, ctrl, s);
+}
 // q-free CG passes (capacity mode): p.Ap, then x += alpha p, r -= alpha A p with partials {rr, rz}
 int launch_lean_dot(const Geom& g, const uint8_t* code, const double* p, double* partials, const Ctrl* ctrl,
                     hipStream_t s) {
@@ -1050,7 +1072,17 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     if (MODE == 2) v += corr_at(ii, jj, gz);
     return v;
   };
-  auto load_plane = [&](int gz, double2 (&vn)[R], double2 (&bn)[R]) {
+  // code bytes one plane ahead of the vectors (see k_fused_a)
+  auto load_codes = [&](int gz, unsigned short (&cn)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const int j = j0 + w + rr_ * kNW;
+      cn[rr_] = 0;
+      if (in_x && j < g.ny && gz <= g.nzl + 1)
+        cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
+    }
+  };
+  auto load_plane = [&](int gz, const unsigned short (&cn)[R], double2 (&vn)[R], double2 (&bn)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
@@ -1058,7 +1090,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       bn[rr_] = make_double2(0.0, 0.0);
       if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        const unsigned short cc = cn[rr_];
         if (line_live(cc != 0)) {  // b and the output vanish on non-free voxels: lines without one are not moved
           const double2 bv = ld2(b + e);
           bn[rr_] = bv;
@@ -1111,13 +1143,18 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
   };
 
   double2 v_prev[R], v_cur[R], v_nxt[R], b_cur[R], b_nxt[R];
-  load_plane(gs - 1, v_prev, b_nxt);
-  load_plane(gs, v_cur, b_cur);
+  unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
+  load_codes(gs - 1, cc_nn);
+  load_codes(gs, cc_cur);
+  load_codes(gs + 1, cc_nxt);
+  load_plane(gs - 1, cc_nn, v_prev, b_nxt);
+  load_plane(gs, cc_cur, v_cur, b_cur);
   stage(gs & 1, gs, v_cur);
   __syncthreads();
   double dot = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    load_plane(gz + 1, v_nxt, b_nxt);
+    load_codes(gz + 2, cc_nn);
+    load_plane(gz + 1, cc_nxt, v_nxt, b_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, v_nxt);
     if (gz > gs) consume(gz - 1);
     const double* T = tile[gz & 1];
@@ -1133,7 +1170,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
+        const unsigned short cc = cc_cur[rr_];
         if (!line_live(cc != 0)) continue;  // (live lines are written whole)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 vc = v_cur[rr_], bc = b_cur[rr_];
@@ -1156,7 +1193,10 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       }
     }
 #pragma unroll
-    for (int rr_ = 0; rr_ < R; ++rr_) { v_prev[rr_] = v_cur[rr_]; v_cur[rr_] = v_nxt[rr_]; b_cur[rr_] = b_nxt[rr_]; }
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      v_prev[rr_] = v_cur[rr_]; v_cur[rr_] = v_nxt[rr_]; b_cur[rr_] = b_nxt[rr_];
+      cc_cur[rr_] = cc_nxt[rr_]; cc_nxt[rr_] = cc_nn[rr_];
+    }
     __syncthreads();
   }
   if (MODE == 3) { consume(ge - 1); return; }
