@@ -165,6 +165,14 @@ int main(int argc, char* argv[]) {
     if (!in.query("hypre.eps", hopts.eps)) in.query("hypre_eps", hopts.eps);
     in.query("gpu.maxiter", hopts.maxiter);
     in.query("gpu.device", hopts.device);
+    {  // gpu.precond = mg (default: one periodic multigrid cycle per PCG iteration, the role of PFMG in the reference) | none
+      std::string hp = "mg";
+      in.query("gpu.precond", hp);
+      const std::string hl = lower(hp);
+      if (hl == "mg" || hl == "multigrid") hopts.precond = OI_PRECOND_MG;
+      else if (hl == "none" || hl == "jacobi") hopts.precond = OI_PRECOND_NONE;  // (the diagonal is constant: Jacobi = none)
+      else throw std::runtime_error("gpu.precond must be mg, jacobi or none (got '" + hp + "')");
+    }
     const char* axis_names[3] = {"X", "Y", "Z"};
     // three chi_k solves + tensor on one (sub-)volume; false when a solve does not converge (:545-548)
     auto homogenize = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9]) -> bool {

@@ -101,6 +101,7 @@ struct MgCoarse {
   const float* xc2;  // second W-cycle visit, may be null
   int cnx, cny, z0c;
   long long csz;
+  int cnzl = 0, periodic = 0;  // owned coarse planes; 1 = periodic cell problem (plain fine kernels only)
 };
 // fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in

@@ -26,6 +26,7 @@
 
 #include "oi_comm.h"
 #include "oi_device.h"
+#include "oi_mg.h"
 
 using namespace oi;
 
@@ -185,6 +186,8 @@ struct oi_effdiff {
   hipStream_t stream = nullptr;
   uint8_t* code = nullptr;
   double *chi[3] = {nullptr, nullptr, nullptr}, *r = nullptr, *p = nullptr, *q = nullptr;
+  double* z = nullptr;              // preconditioned residual (OI_PRECOND_MG)
+  oi::MgHierarchy* mg = nullptr;    // periodic aggregation-multigrid hierarchy of the cell problems
   double *partials = nullptr, *hist = nullptr, *scal = nullptr;
   Ctrl* ctrl = nullptr;
   unsigned long long* counter = nullptr;
@@ -199,7 +202,8 @@ extern "C" void oi_effdiff_destroy(oi_effdiff* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* dev[] = {h->code, h->chi[0], h->chi[1], h->chi[2], h->r, h->p, h->q, h->partials, h->hist, h->scal, h->ctrl, h->counter};
+  if (h->mg) oi::mg_destroy(h->mg);
+  void* dev[] = {h->code, h->chi[0], h->chi[1], h->chi[2], h->r, h->p, h->q, h->z, h->partials, h->hist, h->scal, h->ctrl, h->counter};
   for (void* d : dev)
     if (d) (void)hipFree(d);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -293,6 +297,15 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   if (tmp) HIPC(hipFree(tmp));
   if (h->comm) OIC(h->comm->allreduce_sum_u64_host(&cnt, 1, s));
   h->n_active = (long long)cnt;
+  // one multigrid cycle per PCG iteration (what PFMG is to the reference's FlexGMRES, EffectiveDiffusivityHypre.cpp:
+  // 578-600); tiny or empty volumes keep plain CG
+  if (o.precond == OI_PRECOND_MG && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4) {
+    HIPC(hipMalloc((void**)&h->z, sizeof(double) * g.nvec));
+    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
+    size_t mg_bytes = 0;
+    h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);
+    if (!h->mg) return OI_HIP_ERROR;
+  }
   *out = h.release();
   return OI_OK;
 }
@@ -349,13 +362,20 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
   if (!conv) {
     c.tol2 = (h->opts.eps * bnorm) * (h->opts.eps * bnorm);
     HIPC(hipMemcpyAsync(h->ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice, s));
-    const int batch = h->opts.check_every > 0 ? h->opts.check_every : 16;
+    const int batch = h->opts.check_every > 0 ? h->opts.check_every : (h->mg ? 4 : 16);
     int issued = 0;
     Ctrl seen = c;
     while (!seen.done && issued < h->maxiter) {
       for (int b = 0; b < batch && issued < h->maxiter; ++b, ++issued) {
         const int k = issued;
-        if (k > 0) launch_update_p(g, h->code, h->r, h->p, 0, h->hist, k, h->ctrl, s);
+        if (h->mg) {  // z = M^-1 r, r.z into hist[k], p = z + beta p
+          OIC(wrap_z(h, h->r, sizeof(double) * g.plane));
+          const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, 0, s);
+          if (nbz < 0) return OI_RCCL_ERROR;
+          OIC(reduce_to(h, nbz, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+          if (k > 0) launch_update_p(g, h->code, h->z, h->p, 0, h->hist, k, h->ctrl, s);
+          else HIPC(hipMemcpyAsync(h->p, h->z, sizeof(double) * g.nvec, hipMemcpyDeviceToDevice, s));
+        } else if (k > 0) launch_update_p(g, h->code, h->r, h->p, 0, h->hist, k, h->ctrl, s);
         OIC(wrap_z(h, h->p, sizeof(double) * g.plane));
         hipLaunchKernelGGL(k_ed_apply, dim3(nb0), dim3(256), 0, s, g, h->code, h->p, h->q, h->partials, h->ctrl);
         OIC(reduce_to(h, nb0, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));

@@ -11,7 +11,9 @@ namespace oi {
 struct MgHierarchy;
 // builds every coarse operator from the fine code bytes of this slab (ghost code planes valid);
 // collective over `comm` when it has more than one rank
-MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, hipStream_t s, size_t* bytes_out);
+// periodic != 0: the homogenization cell problem (code = 6 on active cells, x / y / z wrap; the ghost planes of `code`
+// and of every fine vector handed to the cycle hold the periodic images / ring neighbours' planes)
+MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int periodic, hipStream_t s, size_t* bytes_out);
 void mg_destroy(MgHierarchy* mg);
 // z = M^-1 r; r, scratch, z are fine vectors (pitched, ghost planes); scratch is overwritten and
 // r's ghost planes must hold the neighbours' values (z's are NOT filled).

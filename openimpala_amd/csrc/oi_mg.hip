@@ -53,6 +53,8 @@ constexpr long long kReplicateCells = 1ll << 18;
 
 struct Dims {
   int nx, ny, nzl, z0;  // owned planes [z0, z0 + nzl) of the level's global z range
+  int nzg;              // planes of the whole level
+  int periodic;         // 1: the homogenization cell problem (x, y wrap by index, z through the ghost planes)
   long long sz;         // plane stride = nx * ny; arrays hold nzl + 2 planes (ghosts at 0 and nzl + 1)
 };
 
@@ -77,18 +79,35 @@ struct LevelT : Dims {
 // smoother only needs a fixed positive diagonal scaling
 __device__ __forceinline__ float rcp(float d) { return __builtin_amdgcn_rcpf(d); }
 
-// sum over the six links of weight * neighbour value.  No edge tests: the weights on the domain
-// faces are zero and every index stays inside the ghosted array.
+// indices of the -x / +x / -y / +y neighbours of cell (i, j) at m.  Non-periodic levels need no edge tests (the
+// weights on the domain faces are zero and every index stays inside the ghosted array); periodic levels wrap.
+#define OI_MG_NBRS(L)                                                                              \
+  const long long mxm = (L.periodic && i == 0) ? m + (L.nx - 1) : m - 1;                            \
+  const long long mxp = (L.periodic && i == L.nx - 1) ? m - (L.nx - 1) : m + 1;                     \
+  const long long mym = (L.periodic && j == 0) ? m + sy * (L.ny - 1) : m - sy;                      \
+  const long long myp = (L.periodic && j == L.ny - 1) ? m - sy * (L.ny - 1) : m + sy;
+
+// sum over the six links of weight * neighbour value (the weight of a link lives with its lower cell)
 template <class W, class D>
-__device__ __forceinline__ float offdiag(const LevelT<W, D>& L, long long m, float vxm, float vxp, float vym, float vyp,
-                                         float vzm, float vzp) {
-  float s = (float)L.wx[m - 1] * vxm;
+__device__ __forceinline__ float offdiag(const LevelT<W, D>& L, long long m, long long mxm, long long mym, float vxm,
+                                         float vxp, float vym, float vyp, float vzm, float vzp) {
+  float s = (float)L.wx[mxm] * vxm;
   s += (float)L.wx[m] * vxp;
-  s += (float)L.wy[m - L.nx] * vym;
+  s += (float)L.wy[mym] * vym;
   s += (float)L.wy[m] * vyp;
   s += (float)L.wz[m - L.sz] * vzm;
   s += (float)L.wz[m] * vzp;
   return s;
+}
+
+// local plane of the coarse level C that holds the parent of plane kk (local, ghosts 0 and nzl + 1) of level L
+__device__ __forceinline__ int parent_plane(const Dims& L, const Dims& C, int kk) {
+  const int kg = L.z0 + kk - 1;
+  if (L.periodic) {  // the planes beyond the two ends are images: their parents sit in C's ghost planes
+    if (kg < 0) return 0;
+    if (kg >= L.nzg) return C.nzl + 1;
+  }
+  return (kg >> 1) - C.z0 + 1;
 }
 
 // ------------------------------ hierarchy construction ------------------------------
@@ -101,25 +120,32 @@ __global__ void __launch_bounds__(256) k_mg_build1(Geom g, const uint8_t* __rest
   OI_MG_CELL(L)
   (void)sy;
   auto fr = [&](int ii, int jj, int gz) -> int {  // free?  gz: local plane incl. the ghosts 0 and nzl + 1
+    if (L.periodic) {
+      ii = ii < 0 ? ii + g.nx : (ii >= g.nx ? ii - g.nx : ii);
+      jj = jj < 0 ? jj + g.ny : (jj >= g.ny ? jj - g.ny : jj);
+    }
     if (ii < 0 || jj < 0 || ii >= g.nx || jj >= g.ny) return 0;
     return code[(long long)gz * g.plane + (long long)jj * g.pitch + ii] != 0;
   };
   const int Kg = L.z0 + k - 1;
   int lx = 0, ly = 0, lz = 0, d = 0;
   for (int c = 0; c < 2; ++c) {
-    const int gz = 2 * Kg + c - g.z0 + 1;
+    const int kgf = 2 * Kg + c, gz = kgf - g.z0 + 1;
     if (gz < 1 || gz > g.nzl) continue;
     for (int b = 0; b < 2; ++b)
       for (int a = 0; a < 2; ++a) {
         const int ii = 2 * i + a, jj = 2 * j + b;
-        if (!fr(ii, jj, gz)) continue;
+        if (ii >= g.nx || jj >= g.ny || !fr(ii, jj, gz)) continue;
         const int cd = code[(long long)gz * g.plane + (long long)jj * g.pitch + ii];
-        // free neighbours inside the same block stay off the coarse diagonal
-        const int inside = fr(a ? ii - 1 : ii + 1, jj, gz) + fr(ii, b ? jj - 1 : jj + 1, gz) + fr(ii, jj, c ? gz - 1 : gz + 1);
+        // a child's partner inside the block (missing for the single child of an odd-sized level) keeps the link
+        // off the coarse diagonal; the link through the block's + face becomes the coarse link
+        const bool px = a == 1 || ii + 1 < g.nx, py = b == 1 || jj + 1 < g.ny, pz = c == 1 || kgf + 1 < g.nz;
+        const int inside = (px ? fr(a ? ii - 1 : ii + 1, jj, gz) : 0) + (py ? fr(ii, b ? jj - 1 : jj + 1, gz) : 0) +
+                           (pz ? fr(ii, jj, c ? gz - 1 : gz + 1) : 0);
         d += cd - inside;
-        if (a == 1) lx += fr(ii + 1, jj, gz);
-        if (b == 1) ly += fr(ii, jj + 1, gz);
-        if (c == 1) lz += fr(ii, jj, gz + 1);
+        if (a == 1 || !px) lx += fr(ii + 1, jj, gz);
+        if (b == 1 || !py) ly += fr(ii, jj + 1, gz);
+        if (c == 1 || !pz) lz += fr(ii, jj, gz + 1);
       }
   }
   wx[m] = (float)lx; wy[m] = (float)ly; wz[m] = (float)lz; diag[m] = (float)d;
@@ -143,11 +169,14 @@ __global__ void __launch_bounds__(256) k_mg_build(LevelT<W, D> F, Dims L, int kf
         if (ii >= F.nx || jj >= F.ny) continue;
         const long long fm = (long long)ii + (long long)F.nx * jj + F.sz * kl;
         d += (float)F.diag[fm];
-        // links towards +x/+y/+z: the ones inside the block (a/b/c == 0; weight 0 when the partner
-        // lies beyond the domain) leave the diagonal twice, the ones on the block face become the coarse link
-        if (a == 0) d -= 2.f * (float)F.wx[fm]; else lx += (float)F.wx[fm];
-        if (b == 0) d -= 2.f * (float)F.wy[fm]; else ly += (float)F.wy[fm];
-        if (c == 0) d -= 2.f * (float)F.wz[fm]; else lz += (float)F.wz[fm];
+        // links towards +x/+y/+z: the ones inside the block (a/b/c == 0 with a partner in the block) leave the
+        // diagonal twice, the ones through the block's + face become the coarse link -- unless the level is a
+        // single periodic block in that direction: then the wrap link is inside the block as well
+        const bool px = a == 0 && ii + 1 < F.nx, py = b == 0 && jj + 1 < F.ny, pz = c == 0 && (2 * Kg + c) + 1 < F.nzg;
+        const float fx = (float)F.wx[fm], fy = (float)F.wy[fm], fz = (float)F.wz[fm];
+        if (px || (L.periodic && L.nx == 1)) d -= 2.f * fx; else lx += fx;
+        if (py || (L.periodic && L.ny == 1)) d -= 2.f * fy; else ly += fy;
+        if (pz || (L.periodic && L.nzg == 1)) d -= 2.f * fz; else lz += fz;
       }
   }
   wx[m] = lx; wy[m] = ly; wz[m] = lz; diag[m] = d;
@@ -172,7 +201,8 @@ __global__ void __launch_bounds__(256) k_mg_pre(LevelT<W, D> L, int kfirst, cons
   float res = 0.f;
   if (d > 0.f) {
     auto xs = [&](long long mm) -> float { const float dd = (float)L.diag[mm]; return dd > 0.f ? kOmega * b[mm] * rcp(dd) : 0.f; };
-    const float s = offdiag(L, m, xs(m - 1), xs(m + 1), xs(m - sy), xs(m + sy), xs(m - sz), xs(m + sz));
+    OI_MG_NBRS(L)
+    const float s = offdiag(L, m, mxm, mym, xs(mxm), xs(mxp), xs(mym), xs(myp), xs(m - sz), xs(m + sz));
     res = b[m] - (d * xs(m) - s);
   }
   r[m] = res;
@@ -185,7 +215,10 @@ __global__ void __launch_bounds__(256) k_mg_resid(LevelT<W, D> L, int kfirst, co
   OI_MG_CELL(L)
   const float d = (float)L.diag[m];
   float res = 0.f;
-  if (d > 0.f) res = b[m] - (d * x[m] - offdiag(L, m, x[m - 1], x[m + 1], x[m - sy], x[m + sy], x[m - sz], x[m + sz]));
+  if (d > 0.f) {
+    OI_MG_NBRS(L)
+    res = b[m] - (d * x[m] - offdiag(L, m, mxm, mym, x[mxm], x[mxp], x[mym], x[myp], x[m - sz], x[m + sz]));
+  }
   r[m] = res;
 }
 
@@ -242,7 +275,7 @@ __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, con
   auto x2 = [&](long long mm, int ii, int jj, int kk) -> float {
     const float dd = (float)L.diag[mm];
     if (!(dd > 0.f)) return 0.f;
-    const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * (((L.z0 + kk - 1) >> 1) - C.z0 + 1);
+    const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
     float c = xc[cm];
     if (xc2) c += xc2[cm];
     return kOmega * b[mm] * rcp(dd) + scale * c;
@@ -250,9 +283,12 @@ __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, con
   float o = 0.f;
   const float d = (float)L.diag[m];
   if (d > 0.f) {
+    OI_MG_NBRS(L)
+    const bool per = L.periodic != 0;
+    const int ixm = i > 0 ? i - 1 : L.nx - 1, ixp = i < L.nx - 1 ? i + 1 : 0, jym = j > 0 ? j - 1 : L.ny - 1, jyp = j < L.ny - 1 ? j + 1 : 0;
     const float c = x2(m, i, j, k);
-    const float s = offdiag(L, m, i > 0 ? x2(m - 1, i - 1, j, k) : 0.f, i < L.nx - 1 ? x2(m + 1, i + 1, j, k) : 0.f,
-                            j > 0 ? x2(m - sy, i, j - 1, k) : 0.f, j < L.ny - 1 ? x2(m + sy, i, j + 1, k) : 0.f,
+    const float s = offdiag(L, m, mxm, mym, (per || i > 0) ? x2(mxm, ixm, j, k) : 0.f, (per || i < L.nx - 1) ? x2(mxp, ixp, j, k) : 0.f,
+                            (per || j > 0) ? x2(mym, i, jym, k) : 0.f, (per || j < L.ny - 1) ? x2(myp, i, jyp, k) : 0.f,
                             x2(m - sz, i, j, k - 1), x2(m + sz, i, j, k + 1));
     o = c + kOmega * (b[m] - (d * c - s)) * rcp(d);
   }
@@ -271,7 +307,8 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
       o = kOmega * b[m] * rcp(d);
     } else {
       const float c = xin[m];
-      o = c + kOmega * (b[m] - (d * c - offdiag(L, m, xin[m - 1], xin[m + 1], xin[m - sy], xin[m + sy], xin[m - sz], xin[m + sz]))) * rcp(d);
+      OI_MG_NBRS(L)
+      o = c + kOmega * (b[m] - (d * c - offdiag(L, m, mxm, mym, xin[mxm], xin[mxp], xin[mym], xin[myp], xin[m - sz], xin[m + sz]))) * rcp(d);
     }
   }
   xout[m] = o;
@@ -281,7 +318,7 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
 // fine vectors live in the pitched / ghost-plane layout; b vanishes on non-free cells and its
 // ghost planes hold the neighbours' values.   r1 = b - A (w b / code)
 __global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
-                                                      double* __restrict__ r1, const Ctrl* __restrict__ ctrl) {
+                                                      double* __restrict__ r1, const Ctrl* __restrict__ ctrl, int periodic) {
   if (ctrl && ctrl->done) return;
   const long long n = (long long)g.nzl * g.ny * g.nx;
   const double w = (double)kOmega;
@@ -292,8 +329,16 @@ __global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __re
     const unsigned c = code[e];
     double res = 0.0;
     if (c) {
-      const double s = ((((i > 0 ? xs(e - 1) : 0.0) + (i < g.nx - 1 ? xs(e + 1) : 0.0)) + (j > 0 ? xs(e - g.pitch) : 0.0)) +
-                        (j < g.ny - 1 ? xs(e + g.pitch) : 0.0)) + xs(e - g.plane) + xs(e + g.plane);
+      double s;
+      if (periodic) {  // x, y wrap by index; the ghost planes hold the periodic images in z
+        const long long exm = i > 0 ? e - 1 : e + (g.nx - 1), exp_ = i < g.nx - 1 ? e + 1 : e - (g.nx - 1);
+        const long long eym = j > 0 ? e - g.pitch : e + (long long)g.pitch * (g.ny - 1);
+        const long long eyp = j < g.ny - 1 ? e + g.pitch : e - (long long)g.pitch * (g.ny - 1);
+        s = (((xs(exm) + xs(exp_)) + xs(eym)) + xs(eyp)) + xs(e - g.plane) + xs(e + g.plane);
+      } else {
+        s = ((((i > 0 ? xs(e - 1) : 0.0) + (i < g.nx - 1 ? xs(e + 1) : 0.0)) + (j > 0 ? xs(e - g.pitch) : 0.0)) +
+             (j < g.ny - 1 ? xs(e + g.pitch) : 0.0)) + xs(e - g.plane) + xs(e + g.plane);
+      }
       res = b[e] - ((double)c * xs(e) - s);
     }
     r1[e] = res;
@@ -310,7 +355,10 @@ __global__ void __launch_bounds__(256) k_mg_fine_post(Geom g, const uint8_t* __r
     const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+    const int kg = g.z0 + gz - 1;
+    int cp = (kg >> 1) - C.z0c + 1;
+    if (C.periodic) cp = kg < 0 ? 0 : (kg >= g.nz ? C.cnzl + 1 : cp);  // images beyond the ends: parents in the coarse ghosts
+    const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * cp;
     float cv = C.xc[cm];
     if (C.xc2) cv += C.xc2[cm];
     return w * b[e] / (double)c + sc * (double)cv;
@@ -322,9 +370,14 @@ __global__ void __launch_bounds__(256) k_mg_fine_post(Geom g, const uint8_t* __r
     double out = 0.0;
     if (c) {
       const double xc0 = x2(i, j, gz);
-      const double s = ((((i > 0 ? x2(i - 1, j, gz) : 0.0) + (i < g.nx - 1 ? x2(i + 1, j, gz) : 0.0)) +
-                         (j > 0 ? x2(i, j - 1, gz) : 0.0)) + (j < g.ny - 1 ? x2(i, j + 1, gz) : 0.0)) +
-                       x2(i, j, gz - 1) + x2(i, j, gz + 1);
+      double s;
+      if (C.periodic)
+        s = (((x2(i > 0 ? i - 1 : g.nx - 1, j, gz) + x2(i < g.nx - 1 ? i + 1 : 0, j, gz)) + x2(i, j > 0 ? j - 1 : g.ny - 1, gz)) +
+             x2(i, j < g.ny - 1 ? j + 1 : 0, gz)) + x2(i, j, gz - 1) + x2(i, j, gz + 1);
+      else
+        s = ((((i > 0 ? x2(i - 1, j, gz) : 0.0) + (i < g.nx - 1 ? x2(i + 1, j, gz) : 0.0)) +
+              (j > 0 ? x2(i, j - 1, gz) : 0.0)) + (j < g.ny - 1 ? x2(i, j + 1, gz) : 0.0)) +
+            x2(i, j, gz - 1) + x2(i, j, gz + 1);
       out = xc0 + w * (b[e] - ((double)c * xc0 - s)) / (double)c;
     }
     z[e] = out;
@@ -379,6 +432,7 @@ struct MgLevelHost {
 struct MgHierarchy {
   std::vector<MgLevelHost> levels;  // levels[0] = first COARSE level
   oi_comm* comm = nullptr;          // neighbours of the slab partition (null: whole volume)
+  bool periodic = false;            // homogenization cell problem: x, y, z wrap (z-slabs then form a ring)
   size_t bytes = 0;
   unsigned wmask = kWCycleMask;
   float scale = kScale;
@@ -419,10 +473,22 @@ void mg_destroy(MgHierarchy* mg) {
 
 // ghost planes of a per-level array from the z-neighbours (no-op without neighbours / on replicated levels)
 static bool ghost_exchange(MgHierarchy* mg, const MgLevelHost& L, void* base, size_t elem, hipStream_t s) {
-  if (!mg->comm || L.replicated) return true;
   char* p = (char*)base;
   const size_t pb = (size_t)L.d.sz * elem;
-  if (mg->comm->exchange(p + pb, p, p + pb * (size_t)L.d.nzl, p + pb * (size_t)(L.d.nzl + 1), pb, s) != OI_OK) {
+  if (!mg->comm || L.replicated) {
+    if (!mg->periodic) return true;
+    // the whole level lives here: its first / last plane are each other's periodic images
+    if (hipMemcpyAsync(p, p + pb * (size_t)L.d.nzl, pb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(p + pb * (size_t)(L.d.nzl + 1), p + pb, pb, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      mg->failed = true;
+      return false;
+    }
+    return true;
+  }
+  const oi_status st = mg->periodic
+                           ? mg->comm->exchange_ring(p + pb, p, p + pb * (size_t)L.d.nzl, p + pb * (size_t)(L.d.nzl + 1), pb, s)
+                           : mg->comm->exchange(p + pb, p, p + pb * (size_t)L.d.nzl, p + pb * (size_t)(L.d.nzl + 1), pb, s);
+  if (st != OI_OK) {
     mg->failed = true;
     return false;
   }
@@ -439,15 +505,13 @@ static void child_span(const MgLevelHost& C, int pz0, int pnzl, int* kfirst, int
 // after the owned contributions of a right-hand side / operator array are in place: sum across ranks
 // (first replicated level) or fetch the ghost planes (slab level)
 static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool parent_replicated, float* a, hipStream_t s) {
-  if (!mg->comm || parent_replicated) return true;
-  if (C.replicated) {
+  if (mg->comm && !parent_replicated && C.replicated) {
     if (mg->comm->allreduce_sum_f32(a + C.d.sz, (size_t)C.d.sz * C.d.nzl, s) != OI_OK) {
       mg->failed = true;
       return false;
     }
-    return true;
   }
-  return ghost_exchange(mg, C, a, sizeof(float), s);
+  return ghost_exchange(mg, C, a, sizeof(float), s);  // neighbours' planes, or the periodic images, or nothing to do
 }
 
 #define MGC(call)                                                            \
@@ -460,9 +524,10 @@ static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool paren
     }                                                                        \
   } while (0)
 
-MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, hipStream_t s, size_t* bytes_out) {
+MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int periodic, hipStream_t s, size_t* bytes_out) {
   MgHierarchy* mg = new MgHierarchy();
   mg->comm = (comm && comm->size > 1) ? comm : nullptr;
+  mg->periodic = periodic != 0;
   int pnx = g.nx, pny = g.ny, pnz = g.nz, pz0 = g.z0, pnzl = g.nzl;
   bool prep = false;  // parent replicated?
   long long replicate_cells = kReplicateCells;
@@ -474,6 +539,8 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, hipStre
     MgLevelHost L;
     L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
     L.d.sz = (long long)L.d.nx * L.d.ny;
+    L.d.nzg = L.nz;
+    L.d.periodic = periodic ? 1 : 0;
     L.compact = l < kCompactLevels;
     // keep the slab partition while every rank's slab starts on an even plane, holds at least two
     // planes and the level is worth distributing; otherwise this and all deeper levels are replicated
@@ -604,8 +671,9 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   auto& Ls = mg->levels;
   const long long nfine = (long long)g.nzl * g.ny * g.nx;
   MgLevelHost& C = Ls[0];
-  MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz};
+  MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   const bool transition = mg->comm && C.replicated;  // owned contributions are summed across ranks afterwards
+  if (mg->periodic) tiled = 0;  // the LDS-tiled fine kernels have no x/y wrap: the periodic problem uses the plain ones
   if (tiled && (g.z0 & 1) == 0) {
     // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
     if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);
@@ -613,7 +681,7 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
     if (!finish_child_array(mg, C, false, C.b, s)) return -1;
   } else {
     if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, nullptr, partials, ctrl, s);
-    else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl);
+    else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl, mg->periodic ? 1 : 0);
     if (!restrict_to(mg, &g, code, scratch, nullptr, C, C.b, s)) return -1;
   }
   if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;

@@ -399,7 +399,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
     size_t mg_bytes = 0;
     h->mg_tiled = getenv("OI_MG_PLAIN") ? 0 : 1;
-    h->mg = mg_setup(g, h->code, h->comm, s, &mg_bytes);
+    h->mg = mg_setup(g, h->code, h->comm, 0, s, &mg_bytes);
     if (!h->mg) return OI_HIP_ERROR;
     h->bytes_device += mg_bytes;
     if (h->opts.verbose > 1)

@@ -119,3 +119,61 @@ def test_gpu_homogenization_on_a_ring_of_slabs(sample_phase, nranks):
     for k in range(3):
         chi, ok, _, _ = o.effdiff_solve(sub, 1, k, eps=1e-10)
         np.testing.assert_allclose(np.concatenate([out[r]["chi"][k] for r in range(nranks)]), chi, rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,pid", [((40, 36, 44), 1), ((25, 31, 33), 0), ((16, 18, 130), 1), ((64, 64, 64), 1)])
+def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
+    """OI_PRECOND_MG on the periodic cell problems: the aggregation hierarchy wraps in x, y (by index) and z (ghost
+    planes), odd sizes leave single-child aggregates next to the wrap.  Same chi and tensor, far fewer iterations."""
+    import openimpala_amd as oia
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
+    want, its = o.effective_diffusivity(sub, pid, eps=1e-10)
+    h = oia.EffectiveDiffusivityMI355(sub, pid, eps=1e-10, precond=oia.PRECOND_MG)
+    for k in range(3):
+        conv, it, rel = h.solve(k)
+        assert conv and rel <= 1e-10 and it < max(12, its[k] // 2), (k, it, its[k])
+        chi, ok, _, _ = o.effdiff_solve(sub, pid, k, eps=1e-10)
+        np.testing.assert_allclose(h.getChiSolution(k), chi, rtol=0, atol=2e-9)
+    np.testing.assert_allclose(h.tensor(), want, rtol=0, atol=2e-9)
+    h.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks,nzs", [(2, 48), (3, 37), (4, 64)])
+def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, monkeypatch, nranks, nzs):
+    """The same on a ring of z-slabs: slab-partitioned periodic levels (ring exchange of their ghost planes) and the
+    replicated tail; same iteration counts as on one GPU."""
+    import threading
+    import openimpala_amd as oia
+    monkeypatch.setenv("OI_MG_REPLICATE_CELLS", "600")
+    sub = np.ascontiguousarray(sample_phase[:nzs, :28, :44])
+    want, _ = o.effective_diffusivity(sub, 1, eps=1e-10)
+    single = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-10, precond=oia.PRECOND_MG)
+    its1 = [single.solve(k)[1] for k in range(3)]
+    single.destroy()
+    comms = oia.Comm.create_local(nranks)
+    out, err = [None] * nranks, []
+
+    def work(r):
+        try:
+            z0, z1 = oia.slab_range(nzs, nranks, r)
+            h = oia.EffectiveDiffusivityMI355(np.ascontiguousarray(sub[z0:z1]), 1, eps=1e-10, precond=oia.PRECOND_MG,
+                                              comm=comms[r], z0=z0, nz_global=nzs)
+            res = [h.solve(k) for k in range(3)]
+            out[r] = dict(res=res, D=h.tensor())
+            h.destroy()
+        except Exception as e:
+            err.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "slab threads hung"
+    assert not err, err
+    for c in comms:
+        c.destroy()
+    assert all(conv for conv, _, _ in out[0]["res"])
+    assert all(abs(it - i1) <= 2 for (_, it, _), i1 in zip(out[0]["res"], its1)), ([r[1] for r in out[0]["res"]], its1)
+    np.testing.assert_allclose(out[0]["D"], want, rtol=0, atol=2e-9)
