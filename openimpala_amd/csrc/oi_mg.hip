@@ -25,6 +25,9 @@
 // right-hand side is summed across ranks (one all-reduce per visit) and every rank runs the
 // same small cycle.  The arithmetic per cell does not depend on the partition.
 //
+// Periodic variant (homogenization cell problems, oi_effdiff.hip): levels wrap in x and y by index and in z through
+// the ghost planes (self-images, or the ring of slabs); the fine level then uses the plain kernels below.
+//
 // Measured on the oracle prototype (tests/experiments/mg_prototype.py, profiles/r01/mg_prototype.txt):
 // 20-61 PCG iterations to 1e-6 against 474-1777 with Jacobi, independent of the grid size.
 #include <hip/hip_runtime.h>
