@@ -407,3 +407,24 @@ def test_single_kernel_layouts_compacted_and_dense(sample, goldens):
     assert np.array_equal(out[1][4], out[0][4])
     assert out[1][0] == pytest.approx(g["tau"][1], rel=1e-7)
     assert out[1][3] < out[0][3]   # (the 100^3 sample is fine-grained: most lines hold a free voxel)
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (9, 7, 12), (4, 4, 4), (5, 6, 4), (6, 4, 17), (12, 5, 5), (7, 33, 9)])
+def test_multigrid_on_tiny_and_odd_volumes(shape):
+    """Hierarchies that end after one or two levels, single-child aggregates, levels one block wide (REV samples
+    can be this small): both multigrid paths still give the oracle's answers."""
+    ph = (np.random.default_rng(5).random(shape) < 0.75).astype(np.uint8)
+    want, _ = o.effective_diffusivity(ph, 1, eps=1e-10)
+    h = oia.EffectiveDiffusivityMI355(ph, 1, eps=1e-10, precond=oia.PRECOND_MG)
+    assert all(h.solve(k)[0] for k in range(3))
+    np.testing.assert_allclose(h.tensor(), want, rtol=0, atol=1e-8)
+    h.destroy()
+    for d in range(3):
+        ref = o.tortuosity(ph, 1, d, eps=1e-10)
+        t = oia.TortuosityMI355(ph, 1, d, eps=1e-10, precond=oia.PRECOND_MG)
+        tau = t.value()
+        if ref["status"] == 0:
+            assert t.status == oia.OI_OK and tau == pytest.approx(ref["tau"], rel=1e-7)
+        else:
+            assert math.isnan(tau) or t.status == ref["status"]
+        t.destroy()
