@@ -200,7 +200,9 @@ void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
  * that hold a free voxel are stored (contiguous in HBM, ~40 % less memory at porosity 0.4), 0 = dense with
  * predicated accesses.  Affects handles created after the call.  Bit 1 (value 2) switches the kernel from
  * whole-line to pair-granular accesses inside live lines (an A/B switch: whole lines avoid partial-line
- * stores and measure 8-15 % faster). */
+ * stores and measure 8-15 % faster).  The multigrid-preconditioned two-kernel iteration (r, q, z, p) takes the
+ * same compacted layout when the dense vectors would not fit in device memory (a third less memory, ~5 %
+ * slower per iteration); bit 2 (value 4) makes it take the compacted lines always. */
 void oi_tort_set_cg1_layout(int compact_lines);
 
 /* The solver kernels predicate their vector loads/stores on the code byte, so a cache line without a

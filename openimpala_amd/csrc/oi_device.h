@@ -80,7 +80,7 @@ int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, c
 // p_in / p_out are double* or, with p_f32 != 0, float* (fp32 STORAGE of the search direction)
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
                    void* p_out, int p_f32, double* q, int jacobi, const double* hist, int k, double* partials,
-                   const Ctrl* ctrl, hipStream_t s);
+                   const Ctrl* ctrl, const int* lineoff /* != null: r, p, q in the compacted line layout */, hipStream_t s);
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
@@ -107,7 +107,8 @@ struct MgCoarse {
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
 // (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
-                   double* out, float* bcoarse, double* partials, const Ctrl* ctrl, hipStream_t s);
+                   double* out, float* bcoarse, double* partials, const Ctrl* ctrl, const int* lineoff /* b, out compacted */,
+                   hipStream_t s);
 void set_fused_tuning(int tile_rows, int zchunk);
 void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
@@ -127,10 +128,12 @@ void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const d
 constexpr int kRec1Alpha = 5;
 constexpr int kRec1Stride = 8;  // doubles per iteration record; [0] = r.r
 // r -= alpha q; partials {rr, rz}
+// (nslots >= 0: r, q are compacted line lists; the owned planes are slots [first_slot, first_slot + nslots))
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi,
-                    const double* hist, int k, double* partials, const Ctrl* ctrl, hipStream_t s);
+                    const double* hist, int k, double* partials, const Ctrl* ctrl, long long first_slot, long long nslots,
+                    hipStream_t s);
 // x += alpha_k p  (deferred update flush of the fused variant)
-void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k,
+void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k, const int* lineoff,
                       hipStream_t s);
 // dst[slot..slot+ncomp) = sum of partials (deterministic order); optional convergence test on
 // dst[check_rr_index]: sets ctrl->done = iter_done when <= tol2

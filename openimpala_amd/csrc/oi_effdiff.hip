@@ -370,7 +370,7 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
         const int k = issued;
         if (h->mg) {  // z = M^-1 r, r.z into hist[k], p = z + beta p
           OIC(wrap_z(h, h->r, sizeof(double) * g.plane));
-          const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, 0, s);
+          const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, 0, nullptr, s);
           if (nbz < 0) return OI_RCCL_ERROR;
           OIC(reduce_to(h, nbz, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
           if (k > 0) launch_update_p(g, h->code, h->z, h->p, 0, h->hist, k, h->ctrl, s);

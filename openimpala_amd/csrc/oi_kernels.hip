@@ -611,8 +611,34 @@ int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, c
   return launch_update_any<true>(g, code, x, r, p, q, jacobi, hist, k, partials, ctrl, s);
 }
 
+// r -= alpha q over COMPACTED vectors (every stored line is live: a plain stream); partials {r.r, r.r}
+__global__ void __launch_bounds__(256) k_update_r_lines(long long npairs, double* __restrict__ r, const double* __restrict__ q,
+                                                         const double* __restrict__ hist, int k, double* __restrict__ partials,
+                                                         const Ctrl* __restrict__ ctrl) {
+  if (ctrl->done) return;
+  const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
+  double rr = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += (long long)gridDim.x * blockDim.x) {
+    const double2 rv = ld2(r + 2 * t), qv = ld2(q + 2 * t);
+    const double r0 = rv.x - alpha * qv.x, r1 = rv.y - alpha * qv.y;
+    st2(r + 2 * t, r0, r1);
+    rr += r0 * r0; rr += r1 * r1;
+  }
+  __shared__ double red[4];
+  const double a = block_sum(rr, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = a; }
+}
+
+// (first_slot / nslots: the compacted layout's owned planes -- r and q then are line lists and no Jacobi scaling applies)
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi, const double* hist,
-                    int k, double* partials, const Ctrl* ctrl, hipStream_t s) {
+                    int k, double* partials, const Ctrl* ctrl, long long first_slot, long long nslots, hipStream_t s) {
+  if (nslots >= 0) {
+    const long long npairs = nslots * 8;
+    const int blocks = cap_blocks(npairs, 1024, 2048);
+    hipLaunchKernelGGL(k_update_r_lines, dim3(blocks), dim3(256), 0, s, npairs, r + 16 * first_slot, q + 16 * first_slot, hist, k,
+                       partials, ctrl);
+    return blocks;
+  }
   return launch_update_any<false>(g, code, nullptr, r, nullptr, q, jacobi, hist, k, partials, ctrl, s);
 }
 
@@ -638,13 +664,22 @@ template <> struct PIo<float> {
 
 template <typename PT>
 __global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ x, const PT* __restrict__ p,
-                                                    const double* __restrict__ hist, int k) {
+                                                    const double* __restrict__ hist, int k, const int* __restrict__ lineoff,
+                                                    int LW) {
   const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
   const long long npairs = (long long)g.nzl * g.plane / 2;
+  const int hp = g.pitch >> 1;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;
        t += (long long)gridDim.x * blockDim.x) {
     const long long e = g.plane + 2 * t;
-    const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + e);
+    long long ev = e;
+    if (lineoff) {  // p in the compacted line layout: lines that are not stored contribute nothing
+      const int i = 2 * (int)(t % hp);
+      const int lo = lineoff[(t / hp + g.ny) * LW + (i >> 4)];
+      if (lo < 0) continue;
+      ev = 16LL * lo + (i & 15);
+    }
+    const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + ev);
     st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
   }
 }
@@ -681,11 +716,12 @@ void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const d
   else hipLaunchKernelGGL(k_axpy_ptr<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, alpha_ptr, lineoff, LW);
 }
 
-void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k,
+void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k, const int* lineoff,
                       hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
-  if (p_f32) hipLaunchKernelGGL(k_axpy_hist<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, hist, k);
-  else hipLaunchKernelGGL(k_axpy_hist<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, hist, k);
+  const int LW = (g.pitch + 15) / 16;
+  if (p_f32) hipLaunchKernelGGL(k_axpy_hist<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, hist, k, lineoff, LW);
+  else hipLaunchKernelGGL(k_axpy_hist<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, hist, k, lineoff, LW);
 }
 
 // --------------------------------------------------------------------------------------
@@ -720,12 +756,14 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
                                                        PT* __restrict__ p_out, double* __restrict__ q, int jacobi,
                                                        const double* __restrict__ hist, int k, int zchunk,
                                                        int tiles_x, int tiles_y, int nzc,
-                                                       double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+                                                       double* __restrict__ partials, const Ctrl* __restrict__ ctrl,
+                                                       const int* __restrict__ lineoff, int LW) {
   constexpr int BY = kNW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (ctrl && ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
   __shared__ double red[kNW];
+  // lineoff != null (CG form only): r (z), p_in, p_out and q live in the compacted line layout of k_cg1; x is dense
 
   // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2), so
   // give every XCD one contiguous range of logical tiles (x fastest, then y, then z chunk).
@@ -757,28 +795,34 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
   // CG vectors (z, p, q) vanish on non-free voxels: in the CG form their loads and stores are predicated
   // on the code byte, so cache lines without a free voxel are never moved.  The PURE apply takes any v
   // (the solution with its Dirichlet values included) and reads everything.
-  auto pnew_at = [&](long long e) -> double {
+  auto pnew_at = [&](int gz, int jj, int ii) -> double {
+    const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
     if (PURE && LEAN == 0) return r[e];
     if (PURE) return code[e] ? r[e] : 0.0;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    double z = r[e];
+    const long long ev = lineoff ? 16LL * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> 4)] + (ii & 15) : e;
+    double z = r[ev];
     if (jacobi) z = z / (double)c;
-    return PIo<PT>::rnd(z + beta * (double)p_in[e]);
+    return PIo<PT>::rnd(z + beta * (double)p_in[ev]);
   };
   // p_new of plane gz for this thread's R pairs (and the p_in values for the x update)
   // code bytes of this thread's pairs in plane gz, fetched ONE PLANE AHEAD of the vectors: the predicate of
   // the vector loads is then in registers when they are issued (one memory latency per plane, not two)
-  auto load_codes = [&](int gz, unsigned short (&cn)[R]) {
+  auto load_codes = [&](int gz, unsigned short (&cn)[R], int (&ln)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       cn[rr_] = 0;
-      if (in_x && j < g.ny && gz <= g.nzl + 1)
+      ln[rr_] = 0;
+      if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
+        if (!PURE && lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+      }
     }
   };
-  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], const unsigned short (&cn)[R], bool (&lv)[R]) {
+  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], const unsigned short (&cn)[R], const int (&ln)[R],
+                        bool (&lv)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
@@ -792,8 +836,9 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         lv[rr_] = line_live(cc != 0);  // whole lines: every lane of a live line reads (and later writes)
         if (!lv[rr_]) continue;
         if (PURE) { pn[rr_] = ld2(r + e); continue; }
-        const double2 rv = ld2(r + e);
-        pin[rr_] = PIo<PT>::ld_pair(p_in + e);
+        const long long ev = lineoff ? 16LL * ln[rr_] + (i & 15) : e;
+        const double2 rv = ld2(r + ev);
+        pin[rr_] = PIo<PT>::ld_pair(p_in + ev);
         double z0 = rv.x, z1 = rv.y;
         if (jacobi) {
           if (cc & 0xff) z0 = rv.x / (double)(cc & 0xff);
@@ -811,42 +856,41 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
       *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
-      if (yhalo) {
-        const long long e = (long long)gz * g.plane + (long long)hrow * g.pitch + i;
-        h.x = pnew_at(e); h.y = pnew_at(e + 1);
-      }
+      if (yhalo) { h.x = pnew_at(gz, hrow, i); h.y = pnew_at(gz, hrow, i + 1); }
       *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
-      if (xhalo) h = pnew_at((long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i);
+      if (xhalo) h = pnew_at(gz, xh_row, xh_i);
       T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
     }
   };
 
   double2 pn_prev[R], pn_cur[R], pn_nxt[R], pin_cur[R], pin_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
+  int lo_cur[R], lo_nxt[R], lo_nn[R];
   bool lv_cur[R], lv_nxt[R];
-  load_codes(gs - 1, cc_nxt);
-  load_codes(gs, cc_cur);
-  load_codes(gs + 1, cc_nn);
-  load_plane(gs - 1, pn_prev, pin_nxt, cc_nxt, lv_nxt);
+  load_codes(gs - 1, cc_nxt, lo_nxt);
+  load_codes(gs, cc_cur, lo_cur);
+  load_codes(gs + 1, cc_nn, lo_nn);
+  load_plane(gs - 1, pn_prev, pin_nxt, cc_nxt, lo_nxt, lv_nxt);
   if (!PURE && gs == 1) {  // lo ghost plane of p stays current
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
-      if (lv_nxt[rr_]) PIo<PT>::st_pair(p_out + (long long)j * g.pitch + i, pn_prev[rr_].x, pn_prev[rr_].y);
+      if (lv_nxt[rr_])
+        PIo<PT>::st_pair(p_out + (lineoff ? 16LL * lo_nxt[rr_] + (i & 15) : (long long)j * g.pitch + i), pn_prev[rr_].x, pn_prev[rr_].y);
     }
   }
-  load_plane(gs, pn_cur, pin_cur, cc_cur, lv_cur);
+  load_plane(gs, pn_cur, pin_cur, cc_cur, lo_cur, lv_cur);
 #pragma unroll
-  for (int rr_ = 0; rr_ < R; ++rr_) cc_nxt[rr_] = cc_nn[rr_];  // codes of plane gs + 1
+  for (int rr_ = 0; rr_ < R; ++rr_) { cc_nxt[rr_] = cc_nn[rr_]; lo_nxt[rr_] = lo_nn[rr_]; }  // plane gs + 1
   stage(gs & 1, gs, pn_cur);
   __syncthreads();
 
   double pq = 0.0, pz = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    load_codes(gz + 2, cc_nn);
-    load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt, lv_nxt);
+    load_codes(gz + 2, cc_nn, lo_nn);
+    load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt, lo_nxt, lv_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
     const double* T = tile[gz & 1];
 #pragma unroll
@@ -860,6 +904,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+        const long long ev = (!PURE && lineoff) ? 16LL * lo_cur[rr_] + (i & 15) : e;  // q, p_out (x stays at e)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 pc = pn_cur[rr_];
         const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
@@ -880,9 +925,9 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
           pz += r0 * z0; pz += r1 * z1;
           continue;
         }
-        if (LEAN == 0 || LEAN == 3) st2(q + e, q0, q1);
+        if (LEAN == 0 || LEAN == 3) st2(q + ev, q0, q1);
         if (!PURE) {
-          PIo<PT>::st_pair(p_out + e, pc.x, pc.y);
+          PIo<PT>::st_pair(p_out + ev, pc.x, pc.y);
           if (k > 0) {
             const double2 xv = ld2(x + e);
             st2(x + e, xv.x + alpha_prev * pin_cur[rr_].x, xv.y + alpha_prev * pin_cur[rr_].y);
@@ -891,12 +936,14 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         pq += pc.x * q0; pq += pc.y * q1;
       }
       if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && lv_nxt[rr_])  // hi ghost plane of p stays current
-        PIo<PT>::st_pair(p_out + (long long)(gz + 1) * g.plane + (long long)j * g.pitch + i, pn_nxt[rr_].x, pn_nxt[rr_].y);
+        PIo<PT>::st_pair(p_out + (lineoff ? 16LL * lo_nxt[rr_] + (i & 15) : (long long)(gz + 1) * g.plane + (long long)j * g.pitch + i),
+                         pn_nxt[rr_].x, pn_nxt[rr_].y);
     }
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; pin_cur[rr_] = pin_nxt[rr_]; cc_cur[rr_] = cc_nxt[rr_];
       cc_nxt[rr_] = cc_nn[rr_];
+      lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
       lv_cur[rr_] = lv_nxt[rr_];
     }
     __syncthreads();
@@ -949,15 +996,16 @@ static int pick_zchunk(const Geom& g, long long cols) {
 template <int R, bool PURE, typename PT, int LEAN>
 static void launch_tiled_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
                            void* p_out, double* q, int jacobi, const double* hist, int k, int zchunk, int tiles_x,
-                           int tiles_y, int nzc, double* partials, const Ctrl* ctrl, hipStream_t s) {
+                           int tiles_y, int nzc, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
   hipLaunchKernelGGL((k_fused_a<R, PURE, PT, LEAN>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
-                     (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+                     (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff,
+                     (g.pitch + 15) / 16);
 }
 
 template <bool PURE, typename PT, int LEAN = 0>
 static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
                         double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
-                        hipStream_t s) {
+                        hipStream_t s, const int* lineoff = nullptr) {
   const int R = PURE ? g_pure_rows : g_fused_rows, by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
@@ -975,13 +1023,13 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
   const int blocks = (int)(cols * nzc);
   if (R == 4)
     launch_tiled_r<4, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
-                                      nzc, partials, ctrl, s);
+                                      nzc, partials, ctrl, lineoff, s);
   else if (R == 2)
     launch_tiled_r<2, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
-                                      nzc, partials, ctrl, s);
+                                      nzc, partials, ctrl, lineoff, s);
   else
     launch_tiled_r<1, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
-                                      nzc, partials, ctrl, s);
+                                      nzc, partials, ctrl, lineoff, s);
   return blocks;
 }
 
@@ -1002,9 +1050,9 @@ int launch_lean_update(const Geom& g, const uint8_t* code, const double* p, doub
 
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
                    int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
-                   hipStream_t s) {
-  if (p_f32) return launch_tiled<false, float>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s);
-  return launch_tiled<false, double>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s);
+                   const int* lineoff, hipStream_t s) {
+  if (p_f32) return launch_tiled<false, float>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s, lineoff);
+  return launch_tiled<false, double>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s, lineoff);
 }
 
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
@@ -1030,10 +1078,11 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
                                                        const double* __restrict__ b, MgCoarse C, double omega, double scale,
                                                        double* __restrict__ out, float* __restrict__ bcoarse, int zchunk,
                                                        int tiles_x, int tiles_y, int nzc, double* __restrict__ partials,
-                                                       const Ctrl* __restrict__ ctrl) {
+                                                       const Ctrl* __restrict__ ctrl, const int* __restrict__ lineoff, int LW) {
   constexpr int BY = kNW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   static_assert((kNW & 1) == 0, "rows 2m and 2m+1 of a tile belong to waves w and w+1");
+  // lineoff != null: b and out live in the compacted line layout of k_cg1
   if (ctrl && ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double tile[2][(BY + 2) * kLP];
   __shared__ double red[kNW];
@@ -1068,21 +1117,25 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    double v = b[e] * wtab[c];
+    const long long ev = lineoff ? 16LL * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> 4)] + (ii & 15) : e;
+    double v = b[ev] * wtab[c];
     if (MODE == 2) v += corr_at(ii, jj, gz);
     return v;
   };
   // code bytes one plane ahead of the vectors (see k_fused_a)
-  auto load_codes = [&](int gz, unsigned short (&cn)[R]) {
+  auto load_codes = [&](int gz, unsigned short (&cn)[R], int (&ln)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       cn[rr_] = 0;
-      if (in_x && j < g.ny && gz <= g.nzl + 1)
+      ln[rr_] = 0;
+      if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
+        if (lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+      }
     }
   };
-  auto load_plane = [&](int gz, const unsigned short (&cn)[R], double2 (&vn)[R], double2 (&bn)[R]) {
+  auto load_plane = [&](int gz, const unsigned short (&cn)[R], const int (&ln)[R], double2 (&vn)[R], double2 (&bn)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
@@ -1092,7 +1145,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
         if (line_live(cc != 0)) {  // b and the output vanish on non-free voxels: lines without one are not moved
-          const double2 bv = ld2(b + e);
+          const double2 bv = ld2(b + (lineoff ? 16LL * ln[rr_] + (i & 15) : e));
           bn[rr_] = bv;
           double v0 = bv.x * wtab[cc & 0xffu], v1 = bv.y * wtab[cc >> 8];
           if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
@@ -1144,17 +1197,18 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
 
   double2 v_prev[R], v_cur[R], v_nxt[R], b_cur[R], b_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
-  load_codes(gs - 1, cc_nn);
-  load_codes(gs, cc_cur);
-  load_codes(gs + 1, cc_nxt);
-  load_plane(gs - 1, cc_nn, v_prev, b_nxt);
-  load_plane(gs, cc_cur, v_cur, b_cur);
+  int lo_cur[R], lo_nxt[R], lo_nn[R];
+  load_codes(gs - 1, cc_nn, lo_nn);
+  load_codes(gs, cc_cur, lo_cur);
+  load_codes(gs + 1, cc_nxt, lo_nxt);
+  load_plane(gs - 1, cc_nn, lo_nn, v_prev, b_nxt);
+  load_plane(gs, cc_cur, lo_cur, v_cur, b_cur);
   stage(gs & 1, gs, v_cur);
   __syncthreads();
   double dot = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    load_codes(gz + 2, cc_nn);
-    load_plane(gz + 1, cc_nxt, v_nxt, b_nxt);
+    load_codes(gz + 2, cc_nn, lo_nn);
+    load_plane(gz + 1, cc_nxt, lo_nxt, v_nxt, b_nxt);
     if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, v_nxt);
     if (gz > gs) consume(gz - 1);
     const double* T = tile[gz & 1];
@@ -1180,7 +1234,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + (bc.x - av) * wtab[c0]; }
         if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + (bc.y - av) * wtab[c1]; }
         if (MODE == 3) { xsum[rr_] = o0 + o1; continue; }
-        st2(out + e, o0, o1);
+        st2(out + (lineoff ? 16LL * lo_cur[rr_] + (i & 15) : e), o0, o1);
         dot += o0 * bc.x; dot += o1 * bc.y;
       }
     }
@@ -1196,6 +1250,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     for (int rr_ = 0; rr_ < R; ++rr_) {
       v_prev[rr_] = v_cur[rr_]; v_cur[rr_] = v_nxt[rr_]; b_cur[rr_] = b_nxt[rr_];
       cc_cur[rr_] = cc_nxt[rr_]; cc_nxt[rr_] = cc_nn[rr_];
+      lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
     }
     __syncthreads();
   }
@@ -1208,7 +1263,8 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
 // mode 3 = pre with the restriction fused in: `bcoarse` receives the block sums of the planes this slab
 // owns (needs an even g.z0: z pairs must not straddle the z chunks)
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
-                   double* out, float* bcoarse, double* partials, const Ctrl* ctrl, hipStream_t s) {
+                   double* out, float* bcoarse, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+  const int LW = (g.pitch + 15) / 16;
   constexpr int R = 2;
   const int by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
@@ -1228,13 +1284,13 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
   const int blocks = (int)(cols * nzc);
   if (mode == 1)
     hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW);
   else if (mode == 3)
     hipLaunchKernelGGL((k_mg_fine<R, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW);
   else
     hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl);
+                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW);
   return blocks;
 }
 

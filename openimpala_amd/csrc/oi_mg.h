@@ -19,8 +19,9 @@ void mg_destroy(MgHierarchy* mg);
 // r's ghost planes must hold the neighbours' values (z's are NOT filled).
 // Also leaves the per-block partial sums of z.r in `partials`; returns their number (-1: transport failure).
 // tiled = 0 selects the plain (cache-served) fine-level kernels kept as a cross-check.
+// lineoff != null: r and z are in the compacted line layout (launch_build_lines); needs tiled != 0 and an even g.z0
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
-              double* partials, const Ctrl* ctrl, int tiled, hipStream_t s);
+              double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s);
 int mg_levels(const MgHierarchy* mg);
 int mg_replicated_from(const MgHierarchy* mg);  // first level (1 = first coarse) solved redundantly on every rank, -1 = none
 // partial sums of a.b over the owned planes; returns the number of partials

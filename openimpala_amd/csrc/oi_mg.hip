@@ -670,7 +670,7 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
 // r's ghost planes must hold the neighbours' values.  Returns the number of z.r partials, -1 on a
 // transport failure.
 static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
-                            double* partials, const Ctrl* ctrl, int tiled, hipStream_t s) {
+                            double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s) {
   auto& Ls = mg->levels;
   const long long nfine = (long long)g.nzl * g.ny * g.nx;
   MgLevelHost& C = Ls[0];
@@ -680,10 +680,11 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   if (tiled && (g.z0 & 1) == 0) {
     // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
     if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);
-    launch_mg_fine(3, g, code, r, cref, (double)kOmega, (double)mg->scale, nullptr, C.b, partials, ctrl, s);
+    launch_mg_fine(3, g, code, r, cref, (double)kOmega, (double)mg->scale, nullptr, C.b, partials, ctrl, lineoff, s);
     if (!finish_child_array(mg, C, false, C.b, s)) return -1;
   } else {
-    if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, nullptr, partials, ctrl, s);
+    if (lineoff) { oi::set_error("compacted vectors need the fused fine-level kernels (even first plane)"); return -1; }
+    if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, nullptr, partials, ctrl, nullptr, s);
     else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl, mg->periodic ? 1 : 0);
     if (!restrict_to(mg, &g, code, scratch, nullptr, C, C.b, s)) return -1;
   }
@@ -695,14 +696,14 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
     cref.xc2 = C.xs;
   }
   if (tiled)  // also leaves the per-block partial sums of z.r
-    return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, s);
+    return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
   hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl);
   return launch_dot(g, r, z, partials, s);
 }
 
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
-              double* partials, const Ctrl* ctrl, int tiled, hipStream_t s) {
-  if (mg->comm || !mg->use_graph) return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, s);
+              double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s) {
+  if (mg->comm || !mg->use_graph || lineoff) return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, lineoff, s);
   const void* key[6] = {code, r, scratch, z, partials, ctrl};
   bool same = mg->graph_exec != nullptr && mg->graph_tiled == tiled;
   for (int i = 0; same && i < 6; ++i) same = key[i] == mg->graph_key[i];
@@ -712,9 +713,9 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
       mg->use_graph = false;
       (void)hipGetLastError();
-      return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, s);
+      return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
     }
-    const int nb = mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, s);
+    const int nb = mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (e == hipSuccess && nb >= 0) e = hipGraphInstantiate(&mg->graph_exec, graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
@@ -723,7 +724,7 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
       mg->graph_exec = nullptr;
       mg->use_graph = false;
       (void)hipGetLastError();
-      return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, s);
+      return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
     }
     if (getenv("OI_MG_DEBUG")) fprintf(stderr, "[openimpala_amd] multigrid cycle captured into a hipGraph (%d partials)\n", nb);
     mg->graph_nb = nb;
@@ -733,7 +734,7 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
   if (hipGraphLaunch(mg->graph_exec, s) != hipSuccess) {
     (void)hipGetLastError();
     mg->use_graph = false;
-    return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, s);
+    return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
   }
   return mg->graph_nb;
 }

@@ -256,9 +256,14 @@ static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_
 }
 
 static int g_cg1_compact = 1;  // single-kernel variant: store only the lines that hold a free voxel
+// multigrid-preconditioned iteration: 1 = compacted lines always, 0 = only when the dense vectors would not fit
+// (the dense kernels are ~5% faster per iteration, the compacted vectors take a third less memory)
+static int g_mg_compact = 0;
 extern "C" void oi_tort_set_cg1_layout(int compact_lines) {
-  // bit 0: compacted lines; bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch)
+  // bit 0: compacted lines; bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch);
+  // bit 2 set: the multigrid-preconditioned iteration takes the compacted lines even when dense vectors fit
   g_cg1_compact = (compact_lines & 1) ? 1 : 0;
+  g_mg_compact = (compact_lines & 4) ? 1 : 0;
   oi::set_cg1_fullline((compact_lines & 2) ? 0 : 1);
 }
 
@@ -371,10 +376,27 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap));
   OIC(dmalloc(h, &h->x, (size_t)g.nvec));
   h->nvec_cg = g.nvec;
-  if (h->cg1 && g_cg1_compact) {
-    // r, q, p of the single-kernel variant: only the 16-voxel lines that hold a free voxel
+  const bool want_mg = h->opts.precond == OI_PRECOND_MG;
+  h->mg_tiled = getenv("OI_MG_PLAIN") ? 0 : 1;
+  // the multigrid-preconditioned two-kernel iteration takes the compacted layout when its fine-level
+  // kernels are the tiled ones with the restriction fused in (even first plane, see mg_vcycle)
+  const bool mg_compact = want_mg && h->fused && h->mg_tiled && (g.z0 & 1) == 0;
+  if ((h->cg1 || (want_mg && h->fused)) && g_cg1_compact) {
+    // r, q, p (and z): only the 16-voxel lines that hold a free voxel
     const long long nlines = (long long)(g.nzl + 2) * g.ny * ((g.pitch + 15) / 16);
-    if (nlines < (1ll << 31)) {
+    // neighbours exchange ghost planes as line lists: every slab takes the same layout
+    int dense = ((h->cg1 || mg_compact) && nlines < (1ll << 31)) ? 0 : 1;
+    if (h->comm) OIC(h->comm->allreduce_max_i32_host(&dense, 1, s));
+    if (!dense && !h->cg1 && !g_mg_compact) {
+      // r, q, z, two p and ~4 bytes per voxel of hierarchy still to come: stay dense when that fits with room to spare
+      size_t free_b = 0, total_b = 0;
+      HIPC(hipMemGetInfo(&free_b, &total_b));
+      const double need = (double)g.nvec * (3.0 * sizeof(double) + 2.0 * h->p_elem + 4.0);
+      int tight = need > 0.85 * (double)free_b ? 1 : 0;
+      if (h->comm) OIC(h->comm->allreduce_max_i32_host(&tight, 1, s));
+      dense = tight ? 0 : 1;
+    }
+    if (!dense) {
       OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
       OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));
       HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, s));
@@ -394,11 +416,10 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     HIPC(hipMalloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
     h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
   }
-  if (h->opts.precond == OI_PRECOND_MG) {
-    OIC(dmalloc(h, &h->z, (size_t)g.nvec));
-    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
+  if (want_mg) {
+    OIC(dmalloc(h, &h->z, (size_t)h->nvec_cg));
+    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
     size_t mg_bytes = 0;
-    h->mg_tiled = getenv("OI_MG_PLAIN") ? 0 : 1;
     h->mg = mg_setup(g, h->code, h->comm, 0, s, &mg_bytes);
     if (!h->mg) return OI_HIP_ERROR;
     h->bytes_device += mg_bytes;
@@ -592,10 +613,10 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
     { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, h->lineoff, s); }
     OIC(exchange_cg_vec(h, h->r2, sizeof(double), s));
   } else {
-    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, nullptr, s); }
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, h->lineoff, s); }
     // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
     OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
-    if (h->fused || h->mg) OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+    if (h->fused || h->mg) OIC(exchange_cg_vec(h, h->r, sizeof(double), s));
   }
   h->iters_issued = 0;
   h->iters_done = 0;
@@ -648,25 +669,31 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     void* p_out = h->p[k & 1];
     const double* zsrc = h->r;
     if (h->mg) {  // preconditioned residual from the multigrid V-cycle, and r.z into hist[k]
-      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, s); }
+      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, h->lineoff, s); }
       if (nb < 0) return OI_RCCL_ERROR;
       OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
-      OIC(exchange_planes(h, h->z, sizeof(double) * g.plane));
+      OIC(exchange_cg_vec(h, h->z, sizeof(double), s));
       zsrc = h->z;
     }
     {
       PROF(K_FUSED_A);
       nb = launch_fused_a(g, h->code, h->x, zsrc, p_in, p_out, h->p_f32 ? 1 : 0, h->q, h->jacobi, h->hist, k, h->partials,
-                          h->ctrl, s);
+                          h->ctrl, h->lineoff, s);
     }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
-    { PROF(K_UPDATE_R); nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, s); }
+    {
+      PROF(K_UPDATE_R);
+      // compacted: one flat stream over the stored lines of the owned planes
+      const long long first = h->lineoff ? h->plane_first[1] : 0;
+      const long long nslots = h->lineoff ? h->plane_first[g.nzl + 1] - h->plane_first[1] : -1;
+      nb = launch_update_r(g, h->code, h->r, h->q, h->jacobi, h->hist, k, h->partials, h->ctrl, first, nslots, s);
+    }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));
-    OIC(exchange_planes(h, h->r, sizeof(double) * g.plane));
+    OIC(exchange_cg_vec(h, h->r, sizeof(double), s));
   } else if (h->mg) {
     // PCG with the multigrid V-cycle: z = M^-1 r, r.z, p = z + beta p, q = A p, x/r update
     double* p = (double*)h->p[0];
-    { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, s); }
+    { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, nullptr, s); }
     if (nb < 0) return OI_RCCL_ERROR;
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
     if (k > 0) {
@@ -750,7 +777,7 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
   if (h->fused && !h->cg1 && K > 0) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
     PROF(K_AXPY);
-    launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->hist, K - 1, h->stream);
+    launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->hist, K - 1, h->lineoff, h->stream);
   }
   double rr = 0.0;
   const double* rr_src = h->cg1 ? h->rec + (size_t)kRec1Stride * K : h->hist + H_STRIDE * K + H_RR;

@@ -409,6 +409,27 @@ def test_single_kernel_layouts_compacted_and_dense(sample, goldens):
     assert out[1][3] < out[0][3]   # (the 100^3 sample is fine-grained: most lines hold a free voxel)
 
 
+@pytest.mark.parametrize("p_storage", [oia.STORE_F64, oia.STORE_F32])
+def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_storage):
+    """r, q, z, p of the multigrid-preconditioned two-kernel iteration as compacted lines (taken when the dense
+    vectors would not fit; forced here with layout bit 2) or dense: identical iterates, less memory."""
+    g = goldens["phases"]["1"]
+    out = {}
+    try:
+        for layout in (5, 1):
+            oia.set_cg1_layout(layout)
+            t = oia.TortuosityMI355(sample, 1, 2, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG, p_storage=p_storage)
+            tau = t.value()
+            out[layout] = (tau, t.getSolverIterations(), t.stats().final_relres, t.stats().bytes_device, t.solution())
+            t.destroy()
+    finally:
+        oia.set_cg1_layout(1)
+    assert out[5][0] == out[1][0] and out[5][1] == out[1][1] and out[5][2] == out[1][2]
+    assert np.array_equal(out[5][4], out[1][4])
+    assert out[5][0] == pytest.approx(g["tau"][2], rel=1e-7)
+    assert out[5][3] < out[1][3]
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 8), (9, 7, 12), (4, 4, 4), (5, 6, 4), (6, 4, 17), (12, 5, 5), (7, 33, 9)])
 def test_multigrid_on_tiny_and_odd_volumes(shape):
     """Hierarchies that end after one or two levels, single-child aggregates, levels one block wide (REV samples

@@ -9,6 +9,8 @@ eps = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-6
 structure = sys.argv[3] if len(sys.argv) > 3 else "spheres"
 d = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 shape = (n, n, n)
+if "OI_LAYOUT" in os.environ:  # 0 = dense CG vectors, 1 = compacted lines (default)
+    oia.set_cg1_layout(int(os.environ["OI_LAYOUT"]))
 if structure == "spheres":
     buf = oia.gen_spheres_device(shape, 20251031, max(4, 24 * n // 1024), 0.4)
 elif structure == "blobs":
@@ -28,5 +30,5 @@ dt = time.perf_counter() - t0
 k = {a: round(v[0] / max(1, v[1]), 3) for a, v in t.kernel_times().items() if v[1]}
 print(json.dumps({"size": n, "structure": structure, "eps": eps, "wmask": os.environ.get("OI_MG_WMASK", "default"), "scale": os.environ.get("OI_MG_SCALE", "default"),
                   "iterations": its, "relres": rel, "seconds": round(dt, 4), "ms_per_iteration": round(1e3 * dt / max(1, its), 2),
-                  "setup_s": round(t.stats().t_setup_s, 3), "kernels_ms": k}), flush=True)
+                  "setup_s": round(t.stats().t_setup_s, 3), "device_GB": round(t.stats().bytes_device / 1e9, 2), "tau": t.stats().tau, "kernels_ms": k}), flush=True)
 t.destroy()
