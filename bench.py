@@ -307,6 +307,7 @@ def main():
         mk = tm.kernel_times()
         solve_mg = {"eps": 1e-6, "preconditioner": "2x2x2 aggregation multigrid cycle per PCG iteration", "converged": bool(mdone),
                     "iterations": mits, "relres": mrel, "seconds": m1, "setup_seconds": tm.stats().t_setup_s,
+                    "device_GB": tm.stats().bytes_device / 1e9,
                     "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in mk.items()
                                               if k in ("mg_vcycle", "fused_a", "update_r", "apply", "update_p", "update_xr")}}
         tm.destroy()
