@@ -324,6 +324,40 @@ def test_512_bernoulli_properties():
     t.destroy(); t2.destroy(); buf.free()
 
 
+def test_1024_spheres_two_solver_paths_agree():
+    """BASELINE.json config 3 at full size (the bench workload): no oracle at 1.07e9 voxels, so two independent
+    solver paths check each other -- multigrid-PCG (dense and compacted vectors) against the single-kernel CG --
+    plus the reference's own acceptance tests (flux conservation 1e-6, matrix properties)."""
+    shape = (1024, 1024, 1024)
+    buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
+    res = {}
+    try:
+        for layout in (1, 5):
+            oia.set_cg1_layout(layout)
+            t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-9, precond=oia.PRECOND_MG)
+            tau = t.value()
+            st = t.stats()
+            assert t.status == oia.OI_OK and st.converged and st.iterations < 60
+            assert abs(abs(st.flux_in) - abs(st.flux_out)) / abs(st.flux_in) <= 1e-6
+            res[layout] = (tau, st.iterations, st.bytes_device, st.active_vf, st.flux_in)
+            t.destroy()
+    finally:
+        oia.set_cg1_layout(1)
+    assert res[1][:2] == res[5][:2]            # same iterates in either layout
+    assert res[5][2] < 0.75 * res[1][2]        # a third less memory
+    assert 0.35 < res[1][3] < 0.45 and res[1][0] > 1.0
+    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-7)  # default kernel, plain CG
+    assert t.checkMatrixProperties()
+    tau_cg = t.value()
+    st = t.stats()
+    assert st.converged and st.iterations > 1000 and t.status in (oia.OI_OK, oia.OI_FLUX_NOT_CONSERVED)
+    if t.status == oia.OI_OK:
+        assert tau_cg == pytest.approx(res[1][0], rel=1e-4)
+    # the inlet flux agrees whether or not value() accepted the conservation test
+    assert st.flux_in == pytest.approx(res[1][4], rel=1e-3)
+    t.destroy(); buf.free()
+
+
 @pytest.mark.parametrize("name,pid", [("SampleData_2Phase_squared.tif", 1), ("SampleData_2Phase_squared.tif", 0),
                                       ("spheres.tif", 1), ("spheres.tif", 0)])
 def test_other_bundled_tiffs_match_oracle(name, pid):
