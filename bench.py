@@ -239,18 +239,25 @@ def main():
                 traffic = ent["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
-    # The CG-form kernels never move a 128-byte line (16 doubles) of r/q/p/x that holds no free voxel, and move
+    # The CG-form kernels never move a line of r/q/p/x that holds no free voxel, and move
     # live lines whole.  ALGORITHMIC bytes of a launch = the code byte of every voxel + the kernel's vector
     # bytes (SURVEY 8(d) accounting, 60 of the 61 B) for every voxel of a LIVE line; `dense_equivalent` prices the
     # same launch as if every voxel streamed its 61 B (what earlier bench lines of this round reported, and
     # what the metric Mvoxel-iters/s counts) -- it may exceed the HBM peak and is not a bandwidth.
-    live16 = t.live_fraction(16)
+    # (the compacted vectors of the single-kernel iteration store lines of oia.line_voxels() = 8 voxels, one 64-byte
+    # HBM burst; the dense vectors of the other variants are predicated on whole 128-byte cache lines)
+    line_vox = oia.line_voxels() if main_k == "cg1" else 16
+    nfree_frac = t.live_fraction(1)
+    live16 = t.live_fraction(line_vox)
     dense_bytes = BYTES_PER_VOXEL[main_k] * n * n * nzl
     alg_bytes = (1.0 + (BYTES_PER_VOXEL[main_k] - 1.0) * live16) * n * n * nzl
     achieved = alg_bytes / ms_launch / 1e6
     roofline = {"bound": "hbm", "kernel": main_k, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "live_line_fraction": live16,
+                "algorithmic_bytes_per_launch": alg_bytes, "live_line_fraction": live16, "line_voxels": line_vox,
+                "free_voxel_minimum": {"what": "code byte of every voxel + the vector bytes of FREE voxels only (no layout can move less)",
+                                       "bytes_per_launch": (1.0 + (BYTES_PER_VOXEL[main_k] - 1.0) * nfree_frac) * n * n * nzl,
+                                       "GBps": (1.0 + (BYTES_PER_VOXEL[main_k] - 1.0) * nfree_frac) * n * n * nzl / ms_launch / 1e6},
                 "dense_equivalent": {"bytes_per_voxel_iter": alg_bytes_iter, "bytes_per_launch": dense_bytes,
                                      "GBps": dense_bytes / ms_launch / 1e6,
                                      "frac_of_peak": dense_bytes / ms_launch / 1e6 / HBM_PEAK_GBS,

@@ -196,18 +196,22 @@ void oi_tort_set_apply_tuning(int tile_rows);
 /* single-kernel CG iteration: rows per LDS tile (8, 16, 32; <= 0 automatic) and whether x is
  * updated every second iteration with both pending terms (1, default) or every iteration (0) */
 void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
-/* layout of r, q, p in the single-kernel iteration: 1 (default) = COMPACTED -- only the aligned 16-voxel lines
- * that hold a free voxel are stored (contiguous in HBM, ~40 % less memory at porosity 0.4), 0 = dense with
+/* layout of r, q, p in the single-kernel iteration: 1 (default) = COMPACTED -- only the aligned lines of
+ * oi_tort_line_voxels() voxels (8 = one 64-byte HBM burst) that hold a free voxel are stored (contiguous in
+ * HBM, half the memory at porosity 0.4), 0 = dense with
  * predicated accesses.  Affects handles created after the call.  Bit 1 (value 2) switches the kernel from
  * whole-line to pair-granular accesses inside live lines (an A/B switch: whole lines avoid partial-line
  * stores and measure 8-15 % faster).  The multigrid-preconditioned two-kernel iteration (r, q, z, p) takes the
  * same compacted layout when the dense vectors would not fit in device memory (a third less memory, ~5 %
  * slower per iteration); bit 2 (value 4) makes it take the compacted lines always. */
 void oi_tort_set_cg1_layout(int compact_lines);
+/* voxels per stored line of the compacted layout (a build constant) */
+int oi_tort_line_voxels(void);
 
 /* The solver kernels predicate their vector loads/stores on the code byte, so a cache line without a
  * free voxel is never moved.  Fraction of the aligned runs of `group_voxels` voxels along x (this slab)
- * that hold at least one free voxel -- 16 doubles = one 128-byte line; used by bench.py to state the
+ * that hold at least one free voxel -- 16 doubles = one 128-byte cache line (what dense, predicated vectors
+ * move), oi_tort_line_voxels() = what the compacted vectors store; used by bench.py to state the
  * bytes the kernel cannot avoid. */
 oi_status oi_tort_live_fraction(oi_tort* h, int group_voxels, double* fraction);
 

@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
-    "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_comm_unique_id oi_comm_create "
+    "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host"
@@ -144,6 +144,8 @@ def lib():
     L.oi_tort_set_cg1_tuning.restype = None
     L.oi_tort_set_cg1_layout.argtypes = [i]
     L.oi_tort_set_cg1_layout.restype = None
+    L.oi_tort_line_voxels.argtypes = []
+    L.oi_tort_line_voxels.restype = i
     L.oi_comm_unique_id.argtypes = [vp]
     L.oi_comm_create.argtypes = [pp, vp, i, i, i]
     L.oi_comm_create_local.argtypes = [pp, i, i]
@@ -330,6 +332,11 @@ def set_cg1_layout(compact_lines=1):
     lines (default), 0 = dense arrays with predicated accesses.  +2: pair-granular accesses (A/B switch);
     +4: the multigrid-preconditioned iteration takes the compacted lines even when dense vectors fit."""
     lib().oi_tort_set_cg1_layout(int(compact_lines))
+
+
+def line_voxels():
+    """Voxels per stored line of the compacted CG vectors (8 = one 64-byte HBM burst)."""
+    return int(lib().oi_tort_line_voxels())
 
 
 def _take_bytes(p, n):

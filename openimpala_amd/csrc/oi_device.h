@@ -44,6 +44,19 @@ enum KernelId {
 
 // maximum number of per-block partial sums any reducing kernel writes
 constexpr int kMaxPartials = 4096;
+// compacted line layout: voxels per stored line (aligned along x).  8 fp64 = one 64-byte HBM burst; stored lines are
+// contiguous, so finer lines do not mean partial cache-line accesses.  Measured on 1024^3 (profiles/r01/ab_linevox.txt):
+// 16 -> 8 voxels stores 15 % fewer lines (spheres; 32 % at porosity 0.2) and runs 3-7 % faster; 4 gains nothing more.
+// kLG = lanes of a wave (one voxel pair each) that share a stored line.  DENSE vectors are predicated on whole
+// 128-byte cache lines (kDenseLG lanes): a 64-byte predicate there means partial-line stores and measures 3 % slower.
+#ifndef OI_LINE_VOX
+#define OI_LINE_VOX 8
+#endif
+constexpr int kLV = OI_LINE_VOX;
+constexpr int kLVs = kLV == 16 ? 4 : kLV == 8 ? 3 : kLV == 4 ? 2 : 5;
+constexpr int kLG = kLV / 2;
+constexpr int kDenseLG = 8;
+static_assert((1 << kLVs) == kLV, "line length: 4, 8, 16 or 32 voxels");
 
 // ---- launchers (all asynchronous on `s`) ----
 void launch_pack_open(const uint8_t* phase /*nzl planes, no ghosts, row pitch nx*/, const Geom& g,
@@ -63,7 +76,7 @@ void launch_unpack_mask(const Geom& g, const uint64_t* active, uint8_t* mask_out
 // (lineoff != null: r goes to the compacted line layout, see launch_build_lines)
 int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double* r, double* p, int jacobi,
                      double* partials, const int* lineoff, hipStream_t s);
-// Compacted line layout of the single-kernel iteration: only the aligned 16-voxel lines (owned and ghost
+// Compacted line layout of the single-kernel iteration: only the aligned kLV-voxel lines (owned and ghost
 // planes) that hold a free voxel are stored, in (plane, row, line) order.  lineoff[(gz * ny + j) * LW + line],
 // LW = ceil(pitch / 16), is a line's slot or -1; plane_first_dev[gz] (gz = 0 .. nzl + 2) the first slot of a plane.
 hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, hipStream_t s);

@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __rest
   if (lineoff) {
     if (cc) {
       const long long gz = e / g.plane;
-      st2(r + 16LL * lineoff[(gz * g.ny + j) * LW + (i >> 4)] + (i & 15), r0, r1);
+      st2(r + (long long)kLV * lineoff[(gz * g.ny + j) * LW + (i >> kLVs)] + (i & (kLV - 1)), r0, r1);
     }
   } else {
     st2(r + e, r0, r1);
@@ -399,18 +399,18 @@ int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double
                      double* partials, const int* lineoff, hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.ny * (g.pitch / 2), 256, 2048);
   hipLaunchKernelGGL(k_residual0, dim3(blocks), dim3(256), 0, s, g, code, x, r, p, jacobi, partials, lineoff,
-                     (g.pitch + 15) / 16);
+                     (g.pitch + kLV - 1) / kLV);
   return blocks;
 }
 
-// ---- compacted line layout: which aligned 16-voxel lines (owned AND ghost planes) hold a free voxel ----
+// ---- compacted line layout: which aligned kLV-voxel lines (owned AND ghost planes) hold a free voxel ----
 __global__ void __launch_bounds__(256) k_line_flags(Geom g, const uint8_t* __restrict__ code, int LW, int* __restrict__ flags) {
   const long long n = (long long)(g.nzl + 2) * g.ny * LW;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     const int li = (int)(t % LW);
     const long long row = t / LW;  // gz * ny + j
-    const long long base = (row / g.ny) * g.plane + (row % g.ny) * g.pitch + 16LL * li;
-    const int len = min(16, g.pitch - 16 * li);
+    const long long base = (row / g.ny) * g.plane + (row % g.ny) * g.pitch + (long long)kLV * li;
+    const int len = min(kLV, g.pitch - kLV * li);
     int any = 0;
     for (int v = 0; v < len; ++v) any |= code[base + v] != 0;
     flags[t] = any;
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) k_line_finalize(long long n, long long pe
 }
 // lineoff: (nzl + 2) * ny * LW ints; plane_first_dev: nzl + 3 long longs.  Returns hipSuccess or the failing call's error.
 hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, hipStream_t s) {
-  const int LW = (g.pitch + 15) / 16;
+  const int LW = (g.pitch + kLV - 1) / kLV;
   const long long n = (long long)(g.nzl + 2) * g.ny * LW;
   if (n >= (1ll << 31)) return hipErrorInvalidValue;
   int* flags = nullptr;
@@ -488,7 +488,7 @@ __device__ __forceinline__ double safe_div(double a, double b) { return b != 0.0
 // predicating pair by pair.  Must be called by all lanes of the wave that are in the loop.
 __device__ __forceinline__ bool line_live(bool pair_live) {
   const unsigned long long m = __ballot(pair_live);
-  return ((m >> (threadIdx.x & 56)) & 0xffull) != 0;
+  return ((m >> (threadIdx.x & (64 - kDenseLG))) & ((1ull << kDenseLG) - 1)) != 0;
 }
 
 __global__ void __launch_bounds__(256) k_update_p(Geom g, const uint8_t* __restrict__ code,
@@ -633,9 +633,9 @@ __global__ void __launch_bounds__(256) k_update_r_lines(long long npairs, double
 int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double* q, int jacobi, const double* hist,
                     int k, double* partials, const Ctrl* ctrl, long long first_slot, long long nslots, hipStream_t s) {
   if (nslots >= 0) {
-    const long long npairs = nslots * 8;
+    const long long npairs = nslots * (kLV / 2);
     const int blocks = cap_blocks(npairs, 1024, 2048);
-    hipLaunchKernelGGL(k_update_r_lines, dim3(blocks), dim3(256), 0, s, npairs, r + 16 * first_slot, q + 16 * first_slot, hist, k,
+    hipLaunchKernelGGL(k_update_r_lines, dim3(blocks), dim3(256), 0, s, npairs, r + kLV * first_slot, q + kLV * first_slot, hist, k,
                        partials, ctrl);
     return blocks;
   }
@@ -675,9 +675,9 @@ __global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ 
     long long ev = e;
     if (lineoff) {  // p in the compacted line layout: lines that are not stored contribute nothing
       const int i = 2 * (int)(t % hp);
-      const int lo = lineoff[(t / hp + g.ny) * LW + (i >> 4)];
+      const int lo = lineoff[(t / hp + g.ny) * LW + (i >> kLVs)];
       if (lo < 0) continue;
-      ev = 16LL * lo + (i & 15);
+      ev = (long long)kLV * lo + (i & (kLV - 1));
     }
     const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + ev);
     st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
@@ -699,9 +699,9 @@ __global__ void __launch_bounds__(256) k_axpy_ptr(Geom g, double* __restrict__ x
     if (lineoff) {
       const int i = 2 * (int)(t % hp);
       const long long row = t / hp;  // (gz - 1) * ny + j
-      const int lo = lineoff[(row + g.ny) * LW + (i >> 4)];
+      const int lo = lineoff[(row + g.ny) * LW + (i >> kLVs)];
       if (lo < 0) continue;
-      ev = 16LL * lo + (i & 15);
+      ev = (long long)kLV * lo + (i & (kLV - 1));
     }
     const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + ev);
     st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(256) k_axpy_ptr(Geom g, double* __restrict__ x
 void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, const int* lineoff,
                      hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
-  const int LW = (g.pitch + 15) / 16;
+  const int LW = (g.pitch + kLV - 1) / kLV;
   if (p_f32) hipLaunchKernelGGL(k_axpy_ptr<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, alpha_ptr, lineoff, LW);
   else hipLaunchKernelGGL(k_axpy_ptr<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, alpha_ptr, lineoff, LW);
 }
@@ -719,7 +719,7 @@ void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const d
 void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k, const int* lineoff,
                       hipStream_t s) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
-  const int LW = (g.pitch + 15) / 16;
+  const int LW = (g.pitch + kLV - 1) / kLV;
   if (p_f32) hipLaunchKernelGGL(k_axpy_hist<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, hist, k, lineoff, LW);
   else hipLaunchKernelGGL(k_axpy_hist<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, hist, k, lineoff, LW);
 }
@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     if (PURE) return code[e] ? r[e] : 0.0;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    const long long ev = lineoff ? 16LL * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> 4)] + (ii & 15) : e;
+    const long long ev = lineoff ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
     double z = r[ev];
     if (jacobi) z = z / (double)c;
     return PIo<PT>::rnd(z + beta * (double)p_in[ev]);
@@ -814,10 +814,10 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       cn[rr_] = 0;
-      ln[rr_] = 0;
+      ln[rr_] = -1;
       if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
-        if (!PURE && lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+        if (!PURE && lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
       }
     }
   };
@@ -833,10 +833,13 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
         if (PURE && LEAN == 0) { pn[rr_] = ld2(r + e); continue; }
-        lv[rr_] = line_live(cc != 0);  // whole lines: every lane of a live line reads (and later writes)
+        // whole lines: every lane of a live line reads (and later writes).  Compacted vectors: the table says which
+        // lines exist (kLV voxels); dense vectors: a 128-byte cache line is live when any of its lanes holds a free voxel
+        const bool dense_live = line_live(cc != 0);
+        lv[rr_] = (!PURE && lineoff) ? ln[rr_] >= 0 : dense_live;
         if (!lv[rr_]) continue;
         if (PURE) { pn[rr_] = ld2(r + e); continue; }
-        const long long ev = lineoff ? 16LL * ln[rr_] + (i & 15) : e;
+        const long long ev = lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e;
         const double2 rv = ld2(r + ev);
         pin[rr_] = PIo<PT>::ld_pair(p_in + ev);
         double z0 = rv.x, z1 = rv.y;
@@ -878,7 +881,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       if (lv_nxt[rr_])
-        PIo<PT>::st_pair(p_out + (lineoff ? 16LL * lo_nxt[rr_] + (i & 15) : (long long)j * g.pitch + i), pn_prev[rr_].x, pn_prev[rr_].y);
+        PIo<PT>::st_pair(p_out + (lineoff ? (long long)kLV * lo_nxt[rr_] + (i & (kLV - 1)) : (long long)j * g.pitch + i), pn_prev[rr_].x, pn_prev[rr_].y);
     }
   }
   load_plane(gs, pn_cur, pin_cur, cc_cur, lo_cur, lv_cur);
@@ -904,7 +907,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const long long ev = (!PURE && lineoff) ? 16LL * lo_cur[rr_] + (i & 15) : e;  // q, p_out (x stays at e)
+        const long long ev = (!PURE && lineoff) ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e;  // q, p_out (x stays at e)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 pc = pn_cur[rr_];
         const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
         pq += pc.x * q0; pq += pc.y * q1;
       }
       if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && lv_nxt[rr_])  // hi ghost plane of p stays current
-        PIo<PT>::st_pair(p_out + (lineoff ? 16LL * lo_nxt[rr_] + (i & 15) : (long long)(gz + 1) * g.plane + (long long)j * g.pitch + i),
+        PIo<PT>::st_pair(p_out + (lineoff ? (long long)kLV * lo_nxt[rr_] + (i & (kLV - 1)) : (long long)(gz + 1) * g.plane + (long long)j * g.pitch + i),
                          pn_nxt[rr_].x, pn_nxt[rr_].y);
     }
 #pragma unroll
@@ -999,7 +1002,7 @@ static void launch_tiled_r(int blocks, const Geom& g, const uint8_t* code, doubl
                            int tiles_y, int nzc, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
   hipLaunchKernelGGL((k_fused_a<R, PURE, PT, LEAN>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
                      (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff,
-                     (g.pitch + 15) / 16);
+                     (g.pitch + kLV - 1) / kLV);
 }
 
 template <bool PURE, typename PT, int LEAN = 0>
@@ -1117,7 +1120,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    const long long ev = lineoff ? 16LL * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> 4)] + (ii & 15) : e;
+    const long long ev = lineoff ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
     double v = b[ev] * wtab[c];
     if (MODE == 2) v += corr_at(ii, jj, gz);
     return v;
@@ -1128,10 +1131,10 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       cn[rr_] = 0;
-      ln[rr_] = 0;
+      ln[rr_] = -1;
       if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
-        if (lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+        if (lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
       }
     }
   };
@@ -1144,8 +1147,9 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
-        if (line_live(cc != 0)) {  // b and the output vanish on non-free voxels: lines without one are not moved
-          const double2 bv = ld2(b + (lineoff ? 16LL * ln[rr_] + (i & 15) : e));
+        const bool dense_live = line_live(cc != 0);
+        if (lineoff ? ln[rr_] >= 0 : dense_live) {  // b and the output vanish on non-free voxels: lines without one are not moved
+          const double2 bv = ld2(b + (lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
           bn[rr_] = bv;
           double v0 = bv.x * wtab[cc & 0xffu], v1 = bv.y * wtab[cc >> 8];
           if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
@@ -1225,7 +1229,8 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cc_cur[rr_];
-        if (!line_live(cc != 0)) continue;  // (live lines are written whole)
+        const bool dense_live = line_live(cc != 0);
+        if (!(lineoff ? lo_cur[rr_] >= 0 : dense_live)) continue;  // (live lines are written whole)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 vc = v_cur[rr_], bc = b_cur[rr_];
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
@@ -1234,7 +1239,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
         if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + (bc.x - av) * wtab[c0]; }
         if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + (bc.y - av) * wtab[c1]; }
         if (MODE == 3) { xsum[rr_] = o0 + o1; continue; }
-        st2(out + (lineoff ? 16LL * lo_cur[rr_] + (i & 15) : e), o0, o1);
+        st2(out + (lineoff ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e), o0, o1);
         dot += o0 * bc.x; dot += o1 * bc.y;
       }
     }
@@ -1264,7 +1269,7 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
 // owns (needs an even g.z0: z pairs must not straddle the z chunks)
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
                    double* out, float* bcoarse, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
-  const int LW = (g.pitch + 15) / 16;
+  const int LW = (g.pitch + kLV - 1) / kLV;
   constexpr int R = 2;
   const int by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
@@ -1317,7 +1322,7 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
 // --------------------------------------------------------------------------------------
 enum { R1_RR = 0, R1_RZ, R1_PQ, R1_ZQ, R1_QDQ, R1_ALPHA, R1_BETA, R1_STRIDE = 8 };
 
-// COMPACT: r, q and p live in the COMPACTED layout -- only the aligned 16-voxel lines that hold a free
+// COMPACT: r, q and p live in the COMPACTED layout -- only the aligned kLV-voxel lines (8 voxels = 64 B) that hold a free
 // voxel are stored, in (plane, row, line) order; lineoff[(gz * ny + j) * LW + line] is a line's slot (-1:
 // not stored).  Same bytes as the predicated dense layout, but contiguous in HBM.  x stays dense.
 template <int R, int NW, typename PT, bool JACOBI, bool COMPACT>
@@ -1373,7 +1378,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
     const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    const long long ev = COMPACT ? 16LL * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> 4)] + (ii & 15) : e;
+    const long long ev = COMPACT ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
     double z = r_in[ev] - alpha_prev * q_in[ev];
     if (JACOBI) z = z / (double)c;
     return PIo<PT>::rnd(z + beta * (double)p_in[ev]);
@@ -1388,11 +1393,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
       ln[rr_] = -1;
       if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
-        if (COMPACT) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> 4)];
+        if (COMPACT) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
       }
       if (!COMPACT) {  // dense layout: a 16-voxel line is live when any of its 8 lanes holds a free voxel
         const unsigned long long m = __ballot(cn[rr_] != 0);
-        ln[rr_] = (in_x && j < g.ny && gz <= g.nzl + 1 && ((m >> (lane & ~7)) & 0xffull)) ? 0 : -1;
+        ln[rr_] = (in_x && j < g.ny && gz <= g.nzl + 1 && ((m >> (lane & ~(kDenseLG - 1))) & ((1ull << kDenseLG) - 1))) ? 0 : -1;
       }
     }
   };
@@ -1410,7 +1415,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
       // pair without a free voxel reads and writes zeros) -- no partial-line stores for HBM to merge
       if (fullline ? ln[rr_] >= 0 : cn[rr_] != 0) {  // (implies in_x && j < g.ny)
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;            // dense: x
-        const long long ev = COMPACT ? 16LL * ln[rr_] + (i & 15) : e;                         // r, q, p
+        const long long ev = COMPACT ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e;                         // r, q, p
         const double2 rv = ld2(r_in + ev), qv = ld2(q_in + ev);
         const double2 pin = PIo<PT>::ld_pair(p_in + ev);
         const double r0 = rv.x - alpha_prev * qv.x, r1 = rv.y - alpha_prev * qv.y;
@@ -1476,7 +1481,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
       const int j = j0 + w + rr_ * NW;
       const unsigned short cc = cc_cur[rr_];
       if (fullline && !cc && lo_cur[rr_] >= 0)  // whole lines
-        st2(q_out + (COMPACT ? 16LL * lo_cur[rr_] + (i & 15) : (long long)gz * g.plane + (long long)j * g.pitch + i), 0.0, 0.0);
+        st2(q_out + (COMPACT ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : (long long)gz * g.plane + (long long)j * g.pitch + i), 0.0, 0.0);
       if (cc) {  // q and every partial sum vanish where both voxels are non-free
         const int base = (w + rr_ * NW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
@@ -1490,7 +1495,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
         const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + pn_prev[rr_].y) + pn_nxt[rr_].y;
         const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
         const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
-        st2(q_out + (COMPACT ? 16LL * lo_cur[rr_] + (i & 15) : e), q0, q1);
+        st2(q_out + (COMPACT ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e), q0, q1);
         double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
         if (JACOBI) {
           if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
@@ -1547,7 +1552,7 @@ static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double*
                          const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
   hipLaunchKernelGGL((k_cg1<R, NW, PT, JAC, COMPACT>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
                      q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
-                     partial_base, partials, ctrl, lineoff, (g.pitch + 15) / 16, g_cg1_fullline);
+                     partial_base, partials, ctrl, lineoff, (g.pitch + kLV - 1) / kLV, g_cg1_fullline);
 }
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,

@@ -249,7 +249,7 @@ static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_
     return h->comm->exchange(b + pb, b, b + pb * (size_t)g.nzl, b + pb * (size_t)(g.nzl + 1), pb, s);
   }
   const std::vector<long long>& pf = h->plane_first;
-  const size_t le = 16 * elem;  // bytes per stored line
+  const size_t le = (size_t)oi::kLV * elem;  // bytes per stored line
   return h->comm->exchange_v(b + le * pf[1], le * (pf[2] - pf[1]), b + le * pf[0], le * (pf[1] - pf[0]),
                              b + le * pf[g.nzl], le * (pf[g.nzl + 1] - pf[g.nzl]), b + le * pf[g.nzl + 1],
                              le * (pf[g.nzl + 2] - pf[g.nzl + 1]), s);
@@ -259,6 +259,7 @@ static int g_cg1_compact = 1;  // single-kernel variant: store only the lines th
 // multigrid-preconditioned iteration: 1 = compacted lines always, 0 = only when the dense vectors would not fit
 // (the dense kernels are ~5% faster per iteration, the compacted vectors take a third less memory)
 static int g_mg_compact = 0;
+extern "C" int oi_tort_line_voxels(void) { return oi::kLV; }
 extern "C" void oi_tort_set_cg1_layout(int compact_lines) {
   // bit 0: compacted lines; bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch);
   // bit 2 set: the multigrid-preconditioned iteration takes the compacted lines even when dense vectors fit
@@ -382,8 +383,8 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   // kernels are the tiled ones with the restriction fused in (even first plane, see mg_vcycle)
   const bool mg_compact = want_mg && h->fused && h->mg_tiled && (g.z0 & 1) == 0;
   if ((h->cg1 || (want_mg && h->fused)) && g_cg1_compact) {
-    // r, q, p (and z): only the 16-voxel lines that hold a free voxel
-    const long long nlines = (long long)(g.nzl + 2) * g.ny * ((g.pitch + 15) / 16);
+    // r, q, p (and z): only the kLV-voxel lines that hold a free voxel
+    const long long nlines = (long long)(g.nzl + 2) * g.ny * ((g.pitch + oi::kLV - 1) / oi::kLV);
     // neighbours exchange ghost planes as line lists: every slab takes the same layout
     int dense = ((h->cg1 || mg_compact) && nlines < (1ll << 31)) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&dense, 1, s));
@@ -402,7 +403,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
       HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, s));
       h->plane_first.resize((size_t)g.nzl + 3);
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
-      h->nvec_cg = std::max<long long>(16, 16 * h->plane_first[g.nzl + 2]);
+      h->nvec_cg = std::max<long long>(16, (long long)oi::kLV * h->plane_first[g.nzl + 2]);
     }
   }
   OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));

@@ -26,7 +26,9 @@ def bench_name(kernel):
     if kernel.startswith("k_cg1"):
         return "cg1"
     if kernel.startswith("k_fused_a"):
-        return "apply" if ", true" in kernel else "fused_a"
+        if ", true" not in kernel:
+            return "fused_a"
+        return "apply" if kernel.rstrip().endswith(", 0>") else "apply_cgvec"  # LEAN = 3: the apply on a CG vector
     if kernel.startswith("k_update_xr"):
         return "update_r" if kernel.startswith("k_update_xr<false") else "update_xr"
     if kernel.startswith("k_apply"):
