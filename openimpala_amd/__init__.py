@@ -329,8 +329,8 @@ class Comm:
 
 def set_cg1_layout(compact_lines=1):
     """Layout of r, q, p in the single-kernel CG iteration for handles created afterwards: 1 = compacted
-    lines (default), 0 = dense arrays with predicated accesses.  +2: pair-granular accesses (A/B switch);
-    +4: the multigrid-preconditioned iteration takes the compacted lines even when dense vectors fit."""
+    lines (default; also r, q, z, p of the multigrid-preconditioned iteration), 0 = dense arrays with predicated
+    accesses.  +2: pair-granular accesses (A/B switch)."""
     lib().oi_tort_set_cg1_layout(int(compact_lines))
 
 

@@ -751,7 +751,7 @@ constexpr int kNW = 8;              // waves per block
 // LEAN = 2 recomputes q = A p on the fly and applies x += alpha p, r -= alpha q (`q` argument = r
 // vector), partials {r.r, r.z}.  Both take a CG vector and are predicated on the code byte.
 template <int R, bool PURE, typename PT, int LEAN = 0>
-__global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+__global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                        const double* __restrict__ r, const PT* __restrict__ p_in,
                                                        PT* __restrict__ p_out, double* __restrict__ q, int jacobi,
                                                        const double* __restrict__ hist, int k, int zchunk,
@@ -851,20 +851,74 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
       }
     }
   };
+  unsigned hcode = 0;  // halo lanes: code byte(s) and slot of their halo voxel (pair) in the plane staged next
+  int hslot = -1;
   // stage plane gz (own pair values) plus the halo ring into LDS buffer b
   auto stage = [&](int b, int gz, const double2 (&pn)[R]) {
     double* T = tile[b];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
       *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+    if (PURE && LEAN == 0) {  // any v: nothing decides the halo loads
+      if (w < 2) {
+        double2 h = make_double2(0.0, 0.0);
+        if (yhalo) { h.x = pnew_at(gz, hrow, i); h.y = pnew_at(gz, hrow, i + 1); }
+        *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+      } else if (w == 2 && lane < 2 * BY) {
+        double h = 0.0;
+        if (xhalo) h = pnew_at(gz, xh_row, xh_i);
+        T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+      }
+      return;
+    }
+    // halo code bytes and slots were fetched a plane ahead (load_halo_codes, see k_cg1): the halo's vector loads go
+    // out with no dependent look-up in front of them
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
-      if (yhalo) { h.x = pnew_at(gz, hrow, i); h.y = pnew_at(gz, hrow, i + 1); }
+      if (hcode) {
+        const long long e = (long long)gz * g.plane + (long long)hrow * g.pitch + i;
+        if (PURE) {
+          const double2 v = ld2(r + e);
+          if (hcode & 0xff) h.x = v.x;
+          if (hcode >> 8) h.y = v.y;
+        } else {
+          const long long ev = lineoff ? (long long)kLV * hslot + (i & (kLV - 1)) : e;
+          const double2 rv = ld2(r + ev);
+          const double2 pv = PIo<PT>::ld_pair(p_in + ev);
+          double z0 = rv.x, z1 = rv.y;
+          if (jacobi) {
+            if (hcode & 0xff) z0 = rv.x / (double)(hcode & 0xff);
+            if (hcode >> 8) z1 = rv.y / (double)(hcode >> 8);
+          }
+          h.x = PIo<PT>::rnd(z0 + beta * pv.x); h.y = PIo<PT>::rnd(z1 + beta * pv.y);
+        }
+      }
       *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
-      if (xhalo) h = pnew_at(gz, xh_row, xh_i);
+      if (hcode) {
+        const long long e = (long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i;
+        if (PURE) {
+          h = r[e];
+        } else {
+          const long long ev = lineoff ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : e;
+          double z = r[ev];
+          if (jacobi) z = z / (double)hcode;
+          h = PIo<PT>::rnd(z + beta * (double)p_in[ev]);
+        }
+      }
       T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    }
+  };
+  auto load_halo_codes = [&](int gz) {  // of plane gz, for the stage() call of the NEXT iteration
+    hcode = 0; hslot = -1;
+    if ((PURE && LEAN == 0) || gz > g.nzl + 1) return;
+    if (yhalo) {
+      hcode = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)hrow * g.pitch + i);
+      if (!PURE && lineoff) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
+    } else if (xhalo) {
+      hcode = code[(long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i];
+      if (!PURE && lineoff) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
     }
   };
 
@@ -872,6 +926,7 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
   int lo_cur[R], lo_nxt[R], lo_nn[R];
   bool lv_cur[R], lv_nxt[R];
+  load_halo_codes(gs);
   load_codes(gs - 1, cc_nxt, lo_nxt);
   load_codes(gs, cc_cur, lo_cur);
   load_codes(gs + 1, cc_nn, lo_nn);
@@ -888,13 +943,14 @@ __global__ void __launch_bounds__(64 * kNW) k_fused_a(Geom g, const uint8_t* __r
 #pragma unroll
   for (int rr_ = 0; rr_ < R; ++rr_) { cc_nxt[rr_] = cc_nn[rr_]; lo_nxt[rr_] = lo_nn[rr_]; }  // plane gs + 1
   stage(gs & 1, gs, pn_cur);
+  load_halo_codes(gs + 1);
   __syncthreads();
 
   double pq = 0.0, pz = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
     load_codes(gz + 2, cc_nn, lo_nn);
     load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt, lo_nxt, lv_nxt);
-    if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
+    if (gz + 1 < ge) { stage((gz + 1) & 1, gz + 1, pn_nxt); load_halo_codes(gz + 2); }
     const double* T = tile[gz & 1];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
@@ -1077,7 +1133,7 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 // fp32 coarse correction of the 2x2x2 aggregates.
 // --------------------------------------------------------------------------------------
 template <int R, int MODE>
-__global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
+__global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
                                                        const double* __restrict__ b, MgCoarse C, double omega, double scale,
                                                        double* __restrict__ out, float* __restrict__ bcoarse, int zchunk,
                                                        int tiles_x, int tiles_y, int nzc, double* __restrict__ partials,
@@ -1116,15 +1172,6 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
     if (C.xc2) cv += C.xc2[cm];
     return scale * (double)cv;
   };
-  auto v_at = [&](int ii, int jj, int gz) -> double {
-    const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
-    const unsigned c = code[e];
-    if (!c) return 0.0;
-    const long long ev = lineoff ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
-    double v = b[ev] * wtab[c];
-    if (MODE == 2) v += corr_at(ii, jj, gz);
-    return v;
-  };
   // code bytes one plane ahead of the vectors (see k_fused_a)
   auto load_codes = [&](int gz, unsigned short (&cn)[R], int (&ln)[R]) {
 #pragma unroll
@@ -1162,19 +1209,43 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
       }
     }
   };
+  unsigned hcode = 0;  // halo lanes: code byte(s) and slot of their halo voxel (pair) in the plane staged next
+  int hslot = -1;
   auto stage = [&](int bsel, int gz, const double2 (&vn)[R]) {
     double* T = tile[bsel];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
       *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = vn[rr_];
+    // halo code bytes and slots were fetched a plane ahead (load_halo_codes, see k_cg1)
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
-      if (yhalo) { h.x = v_at(i, hrow, gz); h.y = v_at(i + 1, hrow, gz); }
+      if (hcode) {
+        const long long ev = lineoff ? (long long)kLV * hslot + (i & (kLV - 1)) : (long long)gz * g.plane + (long long)hrow * g.pitch + i;
+        const double2 bv = ld2(b + ev);
+        const double cr = MODE == 2 ? corr_at(i, hrow, gz) : 0.0;  // voxels i and i + 1 share their aggregate
+        if (hcode & 0xff) h.x = bv.x * wtab[hcode & 0xff] + cr;
+        if (hcode >> 8) h.y = bv.y * wtab[hcode >> 8] + cr;
+      }
       *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
-      if (xhalo) h = v_at(xh_i, xh_row, gz);
+      if (hcode) {
+        const long long ev = lineoff ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : (long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i;
+        h = b[ev] * wtab[hcode];
+        if (MODE == 2) h += corr_at(xh_i, xh_row, gz);
+      }
       T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    }
+  };
+  auto load_halo_codes = [&](int gz) {  // of plane gz, for the stage() call of the NEXT iteration
+    hcode = 0; hslot = -1;
+    if (gz > g.nzl + 1) return;
+    if (yhalo) {
+      hcode = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)hrow * g.pitch + i);
+      if (lineoff) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
+    } else if (xhalo) {
+      hcode = code[(long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i];
+      if (lineoff) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
     }
   };
 
@@ -1202,18 +1273,20 @@ __global__ void __launch_bounds__(64 * kNW) k_mg_fine(Geom g, const uint8_t* __r
   double2 v_prev[R], v_cur[R], v_nxt[R], b_cur[R], b_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
   int lo_cur[R], lo_nxt[R], lo_nn[R];
+  load_halo_codes(gs);
   load_codes(gs - 1, cc_nn, lo_nn);
   load_codes(gs, cc_cur, lo_cur);
   load_codes(gs + 1, cc_nxt, lo_nxt);
   load_plane(gs - 1, cc_nn, lo_nn, v_prev, b_nxt);
   load_plane(gs, cc_cur, lo_cur, v_cur, b_cur);
   stage(gs & 1, gs, v_cur);
+  load_halo_codes(gs + 1);
   __syncthreads();
   double dot = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
     load_codes(gz + 2, cc_nn, lo_nn);
     load_plane(gz + 1, cc_nxt, lo_nxt, v_nxt, b_nxt);
-    if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, v_nxt);
+    if (gz + 1 < ge) { stage((gz + 1) & 1, gz + 1, v_nxt); load_halo_codes(gz + 2); }
     if (gz > gs) consume(gz - 1);
     const double* T = tile[gz & 1];
     double xsum[R];
@@ -1374,15 +1447,6 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   // r, q and p vanish on non-free voxels (code 0): their loads and stores are predicated on the code
   // byte, so a cache line without a free voxel is never fetched or written (spheres at porosity 0.4:
   // 41 % of the 128-byte lines)
-  auto pnew_at = [&](int gz, int jj, int ii) -> double {
-    const long long e = (long long)gz * g.plane + (long long)jj * g.pitch + ii;
-    const unsigned c = code[e];
-    if (!c) return 0.0;
-    const long long ev = COMPACT ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
-    double z = r_in[ev] - alpha_prev * q_in[ev];
-    if (JACOBI) z = z / (double)c;
-    return PIo<PT>::rnd(z + beta * (double)p_in[ev]);
-  };
   // code bytes (and, compacted layout, the line slot) of this thread's voxel pairs in plane gz, fetched
   // one plane ahead of the vectors
   auto load_codes = [&](int gz, unsigned short (&cn)[R], int (&ln)[R]) {
@@ -1443,38 +1507,72 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
       }
     }
   };
+  unsigned hcode = 0;  // halo lanes: code byte(s) and slot of their halo voxel (pair) in the plane staged next
+  int hslot = -1;
   auto stage = [&](int b, int gz, const double2 (&pn)[R]) {
     double* T = tile[b];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
       *reinterpret_cast<double2*>(&T[(w + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
-    if (w < 2) {
-      double2 h = make_double2(0.0, 0.0);
-      if (yhalo) { h.x = pnew_at(gz, hrow, i); h.y = pnew_at(gz, hrow, i + 1); }
-      *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
-    } else if (w == 2 && lane < 2 * BY) {
-      double h = 0.0;
-      if (xhalo) h = pnew_at(gz, xh_row, xh_i);
-      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    // halo code bytes and slots were fetched a plane ahead (load_halo_codes): the halo's vector loads go out with
+    // no dependent look-up in front of them (7.26 vs 7.59 ms at 1024^3; the halo waves are the block's critical path)
+    {
+      if (w < 2) {
+        double2 h = make_double2(0.0, 0.0);
+        if (hcode) {
+          const long long ev = COMPACT ? (long long)kLV * hslot + (i & (kLV - 1)) : (long long)gz * g.plane + (long long)hrow * g.pitch + i;
+          const double2 rv = ld2(r_in + ev), qv = ld2(q_in + ev);
+          const double2 pv = PIo<PT>::ld_pair(p_in + ev);
+          double z0 = rv.x - alpha_prev * qv.x, z1 = rv.y - alpha_prev * qv.y;
+          if (JACOBI) {
+            if (hcode & 0xff) z0 = z0 / (double)(hcode & 0xff);
+            if (hcode >> 8) z1 = z1 / (double)(hcode >> 8);
+          }
+          h.x = PIo<PT>::rnd(z0 + beta * pv.x); h.y = PIo<PT>::rnd(z1 + beta * pv.y);
+        }
+        *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+      } else if (w == 2 && lane < 2 * BY) {
+        double h = 0.0;
+        if (hcode) {
+          const long long ev = COMPACT ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : (long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i;
+          double z = r_in[ev] - alpha_prev * q_in[ev];
+          if (JACOBI) z = z / (double)hcode;
+          h = PIo<PT>::rnd(z + beta * (double)p_in[ev]);
+        }
+        T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+      }
+    }
+  };
+  auto load_halo_codes = [&](int gz) {  // of plane gz, for the stage() call of the NEXT iteration
+    hcode = 0; hslot = -1;
+    if (gz > g.nzl + 1) return;
+    if (yhalo) {
+      hcode = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)hrow * g.pitch + i);
+      if (COMPACT) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
+    } else if (xhalo) {
+      hcode = code[(long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i];
+      if (COMPACT) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
     }
   };
 
   double2 pn_prev[R], pn_cur[R], pn_nxt[R], rn_cur[R], rn_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
   int lo_cur[R], lo_nxt[R], lo_nn[R];
+  load_halo_codes(gs);
   load_codes(gs - 1, cc_nn, lo_nn);
   load_codes(gs, cc_cur, lo_cur);
   load_codes(gs + 1, cc_nxt, lo_nxt);
   load_plane(gs - 1, cc_nn, lo_nn, pn_prev, rn_nxt, gs == 1 ? 2 : 0);
   load_plane(gs, cc_cur, lo_cur, pn_cur, rn_cur, 1);
   stage(gs & 1, gs, pn_cur);
+  load_halo_codes(gs + 1);
   __syncthreads();
 
   double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
     load_codes(gz + 2, cc_nn, lo_nn);
     load_plane(gz + 1, cc_nxt, lo_nxt, pn_nxt, rn_nxt, gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0));
-    if (gz + 1 < ge) stage((gz + 1) & 1, gz + 1, pn_nxt);
+    if (gz + 1 < ge) { stage((gz + 1) & 1, gz + 1, pn_nxt); load_halo_codes(gz + 2); }
     const double* T = tile[gz & 1];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {

@@ -256,15 +256,11 @@ static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_
 }
 
 static int g_cg1_compact = 1;  // single-kernel variant: store only the lines that hold a free voxel
-// multigrid-preconditioned iteration: 1 = compacted lines always, 0 = only when the dense vectors would not fit
-// (the dense kernels are ~5% faster per iteration, the compacted vectors take a third less memory)
-static int g_mg_compact = 0;
 extern "C" int oi_tort_line_voxels(void) { return oi::kLV; }
 extern "C" void oi_tort_set_cg1_layout(int compact_lines) {
-  // bit 0: compacted lines; bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch);
-  // bit 2 set: the multigrid-preconditioned iteration takes the compacted lines even when dense vectors fit
+  // bit 0: compacted lines (single-kernel iteration and the multigrid-preconditioned two-kernel iteration);
+  // bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch)
   g_cg1_compact = (compact_lines & 1) ? 1 : 0;
-  g_mg_compact = (compact_lines & 4) ? 1 : 0;
   oi::set_cg1_fullline((compact_lines & 2) ? 0 : 1);
 }
 
@@ -388,15 +384,6 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     // neighbours exchange ghost planes as line lists: every slab takes the same layout
     int dense = ((h->cg1 || mg_compact) && nlines < (1ll << 31)) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&dense, 1, s));
-    if (!dense && !h->cg1 && !g_mg_compact) {
-      // r, q, z, two p and ~4 bytes per voxel of hierarchy still to come: stay dense when that fits with room to spare
-      size_t free_b = 0, total_b = 0;
-      HIPC(hipMemGetInfo(&free_b, &total_b));
-      const double need = (double)g.nvec * (3.0 * sizeof(double) + 2.0 * h->p_elem + 4.0);
-      int tight = need > 0.85 * (double)free_b ? 1 : 0;
-      if (h->comm) OIC(h->comm->allreduce_max_i32_host(&tight, 1, s));
-      dense = tight ? 0 : 1;
-    }
     if (!dense) {
       OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
       OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));

@@ -332,7 +332,7 @@ def test_1024_spheres_two_solver_paths_agree():
     buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
     res = {}
     try:
-        for layout in (1, 5):
+        for layout in (0, 1):
             oia.set_cg1_layout(layout)
             t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-9, precond=oia.PRECOND_MG)
             tau = t.value()
@@ -343,8 +343,8 @@ def test_1024_spheres_two_solver_paths_agree():
             t.destroy()
     finally:
         oia.set_cg1_layout(1)
-    assert res[1][:2] == res[5][:2]            # same iterates in either layout
-    assert res[5][2] < 0.75 * res[1][2]        # a third less memory
+    assert res[1][:2] == res[0][:2]            # same iterates in either layout
+    assert res[1][2] < 0.75 * res[0][2]        # a third less memory
     assert 0.35 < res[1][3] < 0.45 and res[1][0] > 1.0
     t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-7)  # default kernel, plain CG
     assert t.checkMatrixProperties()
@@ -449,12 +449,12 @@ def test_single_kernel_layouts_compacted_and_dense(sample, goldens):
 
 @pytest.mark.parametrize("p_storage", [oia.STORE_F64, oia.STORE_F32])
 def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_storage):
-    """r, q, z, p of the multigrid-preconditioned two-kernel iteration as compacted lines (taken when the dense
-    vectors would not fit; forced here with layout bit 2) or dense: identical iterates, less memory."""
+    """r, q, z, p of the multigrid-preconditioned two-kernel iteration as compacted lines (default) or dense:
+    identical iterates, less memory."""
     g = goldens["phases"]["1"]
     out = {}
     try:
-        for layout in (5, 1):
+        for layout in (1, 0):
             oia.set_cg1_layout(layout)
             t = oia.TortuosityMI355(sample, 1, 2, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG, p_storage=p_storage)
             tau = t.value()
@@ -462,10 +462,10 @@ def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_stor
             t.destroy()
     finally:
         oia.set_cg1_layout(1)
-    assert out[5][0] == out[1][0] and out[5][1] == out[1][1] and out[5][2] == out[1][2]
-    assert np.array_equal(out[5][4], out[1][4])
-    assert out[5][0] == pytest.approx(g["tau"][2], rel=1e-7)
-    assert out[5][3] < out[1][3]
+    assert out[1][0] == out[0][0] and out[1][1] == out[0][1] and out[1][2] == out[0][2]
+    assert np.array_equal(out[1][4], out[0][4])
+    assert out[1][0] == pytest.approx(g["tau"][2], rel=1e-7)
+    assert out[1][3] < out[0][3]
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 8), (9, 7, 12), (4, 4, 4), (5, 6, 4), (6, 4, 17), (12, 5, 5), (7, 33, 9)])

@@ -162,15 +162,11 @@ def test_slabs_multigrid_compacted_lines(sample_phase, goldens, nranks):
     line lists.  Two slabs of 50 planes start on even planes and compact; with three one slab starts on plane 67,
     which the fused fine-level kernels do not take, and ALL slabs then agree on dense vectors."""
     g = goldens["phases"]["1"]
-    try:
-        oia.set_cg1_layout(5)
-        single = oia.TortuosityMI355(sample_phase, 1, 2, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG)
-        tau1, it1, mem1 = single.value(), single.getSolverIterations(), single.stats().bytes_device
-        single.destroy()
-        outs = run_slabs(np.ascontiguousarray(sample_phase), 1, 2, nranks, g["vlo"], g["vhi"], eps=1e-10,
-                         precond=oia.PRECOND_MG)
-    finally:
-        oia.set_cg1_layout(1)
+    single = oia.TortuosityMI355(sample_phase, 1, 2, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG)
+    tau1, it1 = single.value(), single.getSolverIterations()
+    single.destroy()
+    outs = run_slabs(np.ascontiguousarray(sample_phase), 1, 2, nranks, g["vlo"], g["vhi"], eps=1e-10,
+                     precond=oia.PRECOND_MG)
     for r in outs:
         assert r["status"] == oia.OI_OK and r["st"]["converged"]
         assert r["tau"] == outs[0]["tau"]
