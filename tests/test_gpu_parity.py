@@ -468,6 +468,30 @@ def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_stor
     assert out[1][3] < out[0][3]
 
 
+def test_multigrid_four_cells_per_thread_kernels_are_bit_identical(monkeypatch):
+    """Coarse levels whose rows split into groups of four cells run k_mg_pre4 / k_mg_post4 (16-byte row loads, x
+    neighbours in registers): same arithmetic in the same order as the one-cell kernels, so the whole solve is
+    bit-identical -- flow-through (open faces) and homogenization (periodic wrap of the group's edge cells and rows)."""
+    ph = o.gen_spheres((40, 72, 136), 3, 7, 0.45)   # first coarse level 20 x 36 x 68: rows of 17 groups
+
+    def both():
+        t = oia.TortuosityMI355(ph, 1, 0, eps=1e-10, precond=oia.PRECOND_MG)
+        tau, it, rel = t.value(), t.getSolverIterations(), t.stats().final_relres
+        t.destroy()
+        h = oia.EffectiveDiffusivityMI355(ph, 1, eps=1e-10, precond=oia.PRECOND_MG)
+        res = [h.solve(k) for k in range(3)]
+        return tau, it, rel, res, h.tensor().copy()
+
+    fast = both()
+    monkeypatch.setenv("OI_MG_NOVEC4", "1")
+    ref = both()
+    assert fast[:3] == ref[:3] and fast[0] > 1.0
+    assert fast[3] == ref[3] and all(r[0] for r in ref[3])
+    assert np.array_equal(fast[4], ref[4])
+    want, _ = o.effective_diffusivity(ph, 1, eps=1e-10)
+    np.testing.assert_allclose(fast[4], want, rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 8), (9, 7, 12), (4, 4, 4), (5, 6, 4), (6, 4, 17), (12, 5, 5), (7, 33, 9)])
 def test_multigrid_on_tiny_and_odd_volumes(shape):
     """Hierarchies that end after one or two levels, single-child aggregates, levels one block wide (REV samples
