@@ -1187,28 +1187,45 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
       }
     }
   };
-  auto load_plane = [&](int gz, const unsigned short (&cn)[R], const int (&ln)[R], double2 (&vn)[R], double2 (&bn)[R]) {
+  // The plane's loads are issued ONE ITERATION before they are used (issue_plane -> braw / craw, finish_plane a
+  // barrier later): the kernel moves few bytes per plane and is latency-bound, two blocks per CU do not hide a load.
+  double2 braw[R];
+  float craw[R];
+  auto issue_plane = [&](int gz, const unsigned short (&cn)[R], const int (&ln)[R]) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
-      vn[rr_] = make_double2(0.0, 0.0);
-      bn[rr_] = make_double2(0.0, 0.0);
+      braw[rr_] = make_double2(0.0, 0.0);
+      craw[rr_] = 0.f;
       if (in_x && j < g.ny) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
         const bool dense_live = line_live(cc != 0);
         if (lineoff ? ln[rr_] >= 0 : dense_live) {  // b and the output vanish on non-free voxels: lines without one are not moved
-          const double2 bv = ld2(b + (lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
-          bn[rr_] = bv;
-          double v0 = bv.x * wtab[cc & 0xffu], v1 = bv.y * wtab[cc >> 8];
+          braw[rr_] = ld2(b + (lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
           if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
-            const double cr = corr_at(i, j, gz);
-            if (cc & 0xffu) v0 += cr;
-            if (cc >> 8) v1 += cr;
+            const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+            float cv = C.xc[cm];
+            if (C.xc2) cv += C.xc2[cm];
+            craw[rr_] = cv;
           }
-          vn[rr_] = make_double2(v0, v1);
         }
       }
+    }
+  };
+  auto finish_plane = [&](const unsigned short (&cn)[R], double2 (&vn)[R], double2 (&bn)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const unsigned short cc = cn[rr_];
+      const double2 bv = braw[rr_];
+      bn[rr_] = bv;
+      double v0 = bv.x * wtab[cc & 0xffu], v1 = bv.y * wtab[cc >> 8];
+      if (MODE == 2 && cc) {
+        const double cr = scale * (double)craw[rr_];
+        if (cc & 0xffu) v0 += cr;
+        if (cc >> 8) v1 += cr;
+      }
+      vn[rr_] = make_double2(v0, v1);
     }
   };
   unsigned hcode = 0;  // halo lanes: code byte(s) and slot of their halo voxel (pair) in the plane staged next
@@ -1273,21 +1290,26 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
   };
 
   double2 v_prev[R], v_cur[R], v_nxt[R], b_cur[R], b_nxt[R];
-  unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
-  int lo_cur[R], lo_nxt[R], lo_nn[R];
+  unsigned short cc_cur[R], cc_nxt[R], cc_nn[R], cc_n3[R];
+  int lo_cur[R], lo_nxt[R], lo_nn[R], lo_n3[R];
   load_halo_codes(gs);
-  load_codes(gs - 1, cc_nn, lo_nn);
+  load_codes(gs - 1, cc_n3, lo_n3);
   load_codes(gs, cc_cur, lo_cur);
   load_codes(gs + 1, cc_nxt, lo_nxt);
-  load_plane(gs - 1, cc_nn, lo_nn, v_prev, b_nxt);
-  load_plane(gs, cc_cur, lo_cur, v_cur, b_cur);
+  load_codes(gs + 2, cc_nn, lo_nn);
+  issue_plane(gs - 1, cc_n3, lo_n3);
+  finish_plane(cc_n3, v_prev, b_nxt);
+  issue_plane(gs, cc_cur, lo_cur);
+  finish_plane(cc_cur, v_cur, b_cur);
   stage(gs & 1, gs, v_cur);
   load_halo_codes(gs + 1);
+  issue_plane(gs + 1, cc_nxt, lo_nxt);  // used by the first iteration
   __syncthreads();
   double dot = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
-    load_codes(gz + 2, cc_nn, lo_nn);
-    load_plane(gz + 1, cc_nxt, lo_nxt, v_nxt, b_nxt);
+    load_codes(gz + 3, cc_n3, lo_n3);
+    finish_plane(cc_nxt, v_nxt, b_nxt);       // plane gz + 1, requested one iteration ago
+    issue_plane(gz + 2, cc_nn, lo_nn);        // plane gz + 2, for the next iteration
     if (gz + 1 < ge) { stage((gz + 1) & 1, gz + 1, v_nxt); load_halo_codes(gz + 2); }
     if (gz > gs) consume(gz - 1);
     const double* T = tile[gz & 1];
@@ -1329,8 +1351,8 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       v_prev[rr_] = v_cur[rr_]; v_cur[rr_] = v_nxt[rr_]; b_cur[rr_] = b_nxt[rr_];
-      cc_cur[rr_] = cc_nxt[rr_]; cc_nxt[rr_] = cc_nn[rr_];
-      lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
+      cc_cur[rr_] = cc_nxt[rr_]; cc_nxt[rr_] = cc_nn[rr_]; cc_nn[rr_] = cc_n3[rr_];
+      lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_]; lo_nn[rr_] = lo_n3[rr_];
     }
     __syncthreads();
   }
