@@ -47,10 +47,14 @@ const char* last_error() { return g_err; }
 // exchange go into ONE group so the two xGMI links are driven concurrently.
 // --------------------------------------------------------------------------------------
 struct RcclComm : oi_comm {
-  ncclComm_t nccl = nullptr;
+  ncclComm_t nccl = nullptr;      // collectives (all-reduce), on the solver's stream
+  ncclComm_t nccl_p2p = nullptr;  // ghost-plane send/recv: a communicator of its own (ncclCommSplit), because the
+                                  // single-kernel iteration runs the exchange on a second stream while the scalar
+                                  // all-reduce is in flight, and operations of ONE communicator must not overlap
   void* scratch = nullptr;  // 64 bytes of device memory for the host-value collectives
   ~RcclComm() override {
     if (scratch) (void)hipFree(scratch);
+    if (nccl_p2p && nccl_p2p != nccl) ncclCommDestroy(nccl_p2p);
     if (nccl) ncclCommDestroy(nccl);
   }
   oi_status exchange(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes,
@@ -58,12 +62,12 @@ struct RcclComm : oi_comm {
     if (size == 1) return OI_OK;  // no neighbours
     NCCLC(ncclGroupStart());
     if (rank > 0) {
-      NCCLC(ncclSend(send_lo, bytes, ncclInt8, rank - 1, nccl, s));
-      NCCLC(ncclRecv(recv_lo, bytes, ncclInt8, rank - 1, nccl, s));
+      NCCLC(ncclSend(send_lo, bytes, ncclInt8, rank - 1, nccl_p2p, s));
+      NCCLC(ncclRecv(recv_lo, bytes, ncclInt8, rank - 1, nccl_p2p, s));
     }
     if (rank < size - 1) {
-      NCCLC(ncclSend(send_hi, bytes, ncclInt8, rank + 1, nccl, s));
-      NCCLC(ncclRecv(recv_hi, bytes, ncclInt8, rank + 1, nccl, s));
+      NCCLC(ncclSend(send_hi, bytes, ncclInt8, rank + 1, nccl_p2p, s));
+      NCCLC(ncclRecv(recv_hi, bytes, ncclInt8, rank + 1, nccl_p2p, s));
     }
     NCCLC(ncclGroupEnd());
     return OI_OK;
@@ -73,12 +77,12 @@ struct RcclComm : oi_comm {
     if (size == 1) return OI_OK;
     NCCLC(ncclGroupStart());
     if (rank > 0) {
-      if (n_send_lo) NCCLC(ncclSend(send_lo, n_send_lo, ncclInt8, rank - 1, nccl, s));
-      if (n_recv_lo) NCCLC(ncclRecv(recv_lo, n_recv_lo, ncclInt8, rank - 1, nccl, s));
+      if (n_send_lo) NCCLC(ncclSend(send_lo, n_send_lo, ncclInt8, rank - 1, nccl_p2p, s));
+      if (n_recv_lo) NCCLC(ncclRecv(recv_lo, n_recv_lo, ncclInt8, rank - 1, nccl_p2p, s));
     }
     if (rank < size - 1) {
-      if (n_send_hi) NCCLC(ncclSend(send_hi, n_send_hi, ncclInt8, rank + 1, nccl, s));
-      if (n_recv_hi) NCCLC(ncclRecv(recv_hi, n_recv_hi, ncclInt8, rank + 1, nccl, s));
+      if (n_send_hi) NCCLC(ncclSend(send_hi, n_send_hi, ncclInt8, rank + 1, nccl_p2p, s));
+      if (n_recv_hi) NCCLC(ncclRecv(recv_hi, n_recv_hi, ncclInt8, rank + 1, nccl_p2p, s));
     }
     NCCLC(ncclGroupEnd());
     return OI_OK;
@@ -94,10 +98,10 @@ struct RcclComm : oi_comm {
     // with two ranks both neighbours are the same peer: messages between a pair match in posting
     // order, so sends go (lo, hi) and receives (hi, lo) -- the peer's first plane is my upper ghost
     NCCLC(ncclGroupStart());
-    NCCLC(ncclSend(send_lo, bytes, ncclInt8, prev, nccl, s));
-    NCCLC(ncclSend(send_hi, bytes, ncclInt8, next, nccl, s));
-    NCCLC(ncclRecv(recv_hi, bytes, ncclInt8, next, nccl, s));
-    NCCLC(ncclRecv(recv_lo, bytes, ncclInt8, prev, nccl, s));
+    NCCLC(ncclSend(send_lo, bytes, ncclInt8, prev, nccl_p2p, s));
+    NCCLC(ncclSend(send_hi, bytes, ncclInt8, next, nccl_p2p, s));
+    NCCLC(ncclRecv(recv_hi, bytes, ncclInt8, next, nccl_p2p, s));
+    NCCLC(ncclRecv(recv_lo, bytes, ncclInt8, prev, nccl_p2p, s));
     NCCLC(ncclGroupEnd());
     return OI_OK;
   }
@@ -345,6 +349,12 @@ oi_status oi_comm_create(oi_comm** out, const void* id, int nranks, int rank, in
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   NCCLC(ncclCommInitRank(&c->nccl, nranks, uid, rank));
+  // second communicator over the same ranks for the plane exchanges (also with one rank: the rehearsal on a
+  // single GPU then covers the call)
+  if (ncclCommSplit(c->nccl, 0, rank, &c->nccl_p2p, nullptr) != ncclSuccess || !c->nccl_p2p) {
+    c->nccl_p2p = c->nccl;        // one communicator: the solver then keeps exchange and all-reduce on one stream
+    c->exchange_overlaps = false;
+  }
   HIPC(hipMalloc(&c->scratch, 128));
   *out = c.release();
   return OI_OK;

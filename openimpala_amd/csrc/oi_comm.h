@@ -14,6 +14,9 @@
 
 struct oi_comm {
   int rank = 0, size = 1, device = 0;
+  // true when the plane exchanges may run on a second stream WHILE a collective of this communicator is in flight
+  // on another (RCCL: they use a communicator of their own; two operations of one RCCL communicator must not overlap)
+  bool exchange_overlaps = true;
   virtual ~oi_comm() {}
   // Sends `send_lo` to rank-1 (lands in its recv_hi) and `send_hi` to rank+1 (lands in its
   // recv_lo); chain ends skip the missing neighbour.  Asynchronous on `s`.

@@ -639,9 +639,11 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
                           h->partials, h->ctrl, 1, 1, 0, h->lineoff, s);
       }
       HIPC(hipEventRecord(h->ev_boundary, s));
-      HIPC(hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
-      OIC(exchange_cg_vec(h, qb[out], sizeof(double), h->comm_stream));  // the ONE plane exchange per iteration
-      HIPC(hipEventRecord(h->ev_exchanged, h->comm_stream));
+      // (a transport whose exchange may not overlap its own collectives keeps everything on the solver stream)
+      hipStream_t xs = h->comm->exchange_overlaps ? h->comm_stream : s;
+      HIPC(hipStreamWaitEvent(xs, h->ev_boundary, 0));
+      OIC(exchange_cg_vec(h, qb[out], sizeof(double), xs));  // the ONE plane exchange per iteration
+      HIPC(hipEventRecord(h->ev_exchanged, xs));
       {
         PROF(K_CG1);
         nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
