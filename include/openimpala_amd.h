@@ -253,6 +253,8 @@ uint64_t oi_blobs_level(uint64_t seed, int spacing, double porosity);
 
 /* ---- device memory helpers for hosts without a GPU array library ---- */
 oi_status oi_dev_malloc(void** ptr, size_t bytes);
+/* free / total memory of the current device (a volume needs 25-60 bytes per voxel) */
+oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 oi_status oi_dev_free(void* ptr);
 oi_status oi_dev_upload(void* dst_dev, const void* src_host, size_t bytes);
 oi_status oi_dev_download(void* dst_host, const void* src_dev, size_t bytes);

@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
-    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
+    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host"
 ).split()
 
@@ -159,6 +159,7 @@ def lib():
     L.oi_blobs_level.argtypes = [u64, i, d]
     L.oi_blobs_level.restype = u64
     L.oi_dev_malloc.argtypes = [pp, C.c_size_t]
+    L.oi_dev_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.oi_dev_free.argtypes = [vp]
     L.oi_dev_upload.argtypes = [vp, vp, C.c_size_t]
     L.oi_dev_download.argtypes = [vp, vp, C.c_size_t]
@@ -332,6 +333,13 @@ def set_cg1_layout(compact_lines=1):
     lines (default; also r, q, z, p of the multigrid-preconditioned iteration), 0 = dense arrays with predicated
     accesses.  +2: pair-granular accesses (A/B switch)."""
     lib().oi_tort_set_cg1_layout(int(compact_lines))
+
+
+def device_memory():
+    """(free, total) bytes of the current device."""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(lib().oi_dev_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def line_voxels():

@@ -1289,6 +1289,13 @@ extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
   return OI_OK;
 }
 extern "C" oi_status oi_dev_free(void* ptr) { HIPC(hipFree(ptr)); return OI_OK; }
+extern "C" oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return OI_BAD_ARG;
+  int device = 0;
+  OIC(ensure_device(-1, &device));
+  HIPC(hipMemGetInfo(free_bytes, total_bytes));
+  return OI_OK;
+}
 extern "C" oi_status oi_dev_upload(void* dst, const void* src, size_t bytes) {
   HIPC(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return OI_OK;

@@ -398,6 +398,28 @@ def test_capacity_mode_footprint_and_refusals(sample, goldens):
     lean.destroy(); full.destroy()
 
 
+def test_handles_release_their_device_memory(sample):
+    """A REV study creates and destroys hundreds of handles: every variant gives its device memory back."""
+    sub = np.ascontiguousarray(sample[:48, :52, :60])
+
+    def cycle():
+        for kw in (dict(), dict(precond=oia.PRECOND_MG), dict(kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_JACOBI),
+                   dict(kernel=oia.KERNEL_FUSED), dict(kernel=oia.KERNEL_UNFUSED, precond=oia.PRECOND_MG)):
+            t = oia.TortuosityMI355(sub, 1, 0, eps=1e-8, **kw)
+            assert t.value() > 1.0
+            t.destroy()
+        h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-8, precond=oia.PRECOND_MG)
+        assert h.solve(0)[0]
+        h.destroy()
+
+    cycle()  # first use: streams, library workspaces
+    free0, _ = oia.device_memory()
+    for _ in range(8):
+        cycle()
+    free1, _ = oia.device_memory()
+    assert free0 - free1 < (8 << 20), (free0, free1)
+
+
 def test_remspot_on_the_device_equals_the_sequential_pass():
     """tortuosity_remspot is defined by its x-fastest in-place order (a flip is seen by the voxels after it);
     the device relaxation must land on exactly that result: iid noise (many isolated voxels), a 3-D
