@@ -26,6 +26,7 @@ struct Geom {
   long long nvec;      // (nzl+2) * plane elements per vector incl. ghost planes
   long long nwords;    // (nzl+2) * wplane
   double vlo, vhi;
+  int periodic;        // 1: x and y wrap by index in the tiled kernels (homogenization cell problem; z wraps through the ghost planes)
 };
 
 // slots of the device-resident CG history: hist[3*k + {0,1,2}] = {p.q, r.r, r.z} of iteration k

@@ -786,10 +786,16 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
   const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);  // output planes [gs, ge)
 
   // halo duty: wave 0 -> row j0-1, wave 1 -> row j0+BY (pairs); wave 2, lanes < 2*BY -> x halos
-  const int hrow = (w == 0) ? j0 - 1 : j0 + BY;
+  // periodic x / y (g.periodic, even nx): the halo of the domain's first row / column is its last one and vice versa;
+  // where the domain ends INSIDE a tile the wrapped row / column is staged right behind the last one
+  const bool per = g.periodic != 0;
+  const bool ywrap_hi = per && j0 + BY >= g.ny, xwrap_hi = per && tx * kBX + kBX >= g.nx;
+  const int hrow = (w == 0) ? ((per && j0 == 0) ? g.ny - 1 : j0 - 1) : (ywrap_hi ? 0 : j0 + BY);
+  const int hlds = (w == 0) ? 0 : (ywrap_hi ? g.ny - j0 + 1 : BY + 1);  // LDS row of this wave's halo row
   const bool yhalo = (w < 2) && in_x && hrow >= 0 && hrow < g.ny;
   const int xh_row = j0 + (lane >> 1);
-  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const int xh_i = (lane & 1) ? (xwrap_hi ? 0 : tx * kBX + kBX) : ((per && tx == 0) ? g.nx - 1 : tx * kBX - 1);
+  const int xlds = (lane & 1) ? (xwrap_hi ? 2 + g.nx - tx * kBX : 2 + kBX) : 1;  // LDS column of this lane's halo value
   const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
 
   // CG vectors (z, p, q) vanish on non-free voxels: in the CG form their loads and stores are predicated
@@ -858,16 +864,17 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
     double* T = tile[b];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
-      *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+      if (!(per && (i == g.nx || j0 + w + rr_ * kNW == g.ny)))  // (that slot holds the wrapped column / row)
+        *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
     if (PURE && LEAN == 0) {  // any v: nothing decides the halo loads
       if (w < 2) {
         double2 h = make_double2(0.0, 0.0);
         if (yhalo) { h.x = pnew_at(gz, hrow, i); h.y = pnew_at(gz, hrow, i + 1); }
-        *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+        *reinterpret_cast<double2*>(&T[hlds * kLP + 2 + 2 * lane]) = h;
       } else if (w == 2 && lane < 2 * BY) {
         double h = 0.0;
         if (xhalo) h = pnew_at(gz, xh_row, xh_i);
-        T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+        T[((lane >> 1) + 1) * kLP + xlds] = h;
       }
       return;
     }
@@ -893,7 +900,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
           h.x = PIo<PT>::rnd(z0 + beta * pv.x); h.y = PIo<PT>::rnd(z1 + beta * pv.y);
         }
       }
-      *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+      *reinterpret_cast<double2*>(&T[hlds * kLP + 2 + 2 * lane]) = h;
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
@@ -907,7 +914,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
           h = PIo<PT>::rnd(z + beta * (double)p_in[ev]);
         }
       }
-      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+      T[((lane >> 1) + 1) * kLP + xlds] = h;
     }
   };
   auto load_halo_codes = [&](int gz) {  // of plane gz, for the stage() call of the NEXT iteration
@@ -1159,10 +1166,16 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
   const int i = tx * kBX + 2 * lane, j0 = ty * BY;
   const bool in_x = i < g.pitch;
   const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);
-  const int hrow = (w == 0) ? j0 - 1 : j0 + BY;
+  // periodic x / y (g.periodic, even nx): the halo of the domain's first row / column is its last one and vice versa;
+  // where the domain ends INSIDE a tile the wrapped row / column is staged right behind the last one
+  const bool per = g.periodic != 0;
+  const bool ywrap_hi = per && j0 + BY >= g.ny, xwrap_hi = per && tx * kBX + kBX >= g.nx;
+  const int hrow = (w == 0) ? ((per && j0 == 0) ? g.ny - 1 : j0 - 1) : (ywrap_hi ? 0 : j0 + BY);
+  const int hlds = (w == 0) ? 0 : (ywrap_hi ? g.ny - j0 + 1 : BY + 1);  // LDS row of this wave's halo row
   const bool yhalo = (w < 2) && in_x && hrow >= 0 && hrow < g.ny;
   const int xh_row = j0 + (lane >> 1);
-  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const int xh_i = (lane & 1) ? (xwrap_hi ? 0 : tx * kBX + kBX) : ((per && tx == 0) ? g.nx - 1 : tx * kBX - 1);
+  const int xlds = (lane & 1) ? (xwrap_hi ? 2 + g.nx - tx * kBX : 2 + kBX) : 1;  // LDS column of this lane's halo value
   const bool xhalo = (w == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
 
   // v at one voxel (the pad column and the ghost planes beyond the domain hold code 0, so the coarse
@@ -1234,7 +1247,8 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
     double* T = tile[bsel];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
-      *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = vn[rr_];
+      if (!(per && (i == g.nx || j0 + w + rr_ * kNW == g.ny)))  // (that slot holds the wrapped column / row)
+        *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = vn[rr_];
     // halo code bytes and slots were fetched a plane ahead (load_halo_codes, see k_cg1)
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
@@ -1245,7 +1259,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         if (hcode & 0xff) h.x = bv.x * wtab[hcode & 0xff] + cr;
         if (hcode >> 8) h.y = bv.y * wtab[hcode >> 8] + cr;
       }
-      *reinterpret_cast<double2*>(&T[((w == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+      *reinterpret_cast<double2*>(&T[hlds * kLP + 2 + 2 * lane]) = h;
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
@@ -1253,7 +1267,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         h = b[ev] * wtab[hcode];
         if (MODE == 2) h += corr_at(xh_i, xh_row, gz);
       }
-      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+      T[((lane >> 1) + 1) * kLP + xlds] = h;
     }
   };
   auto load_halo_codes = [&](int gz) {  // of plane gz, for the stage() call of the NEXT iteration

@@ -812,7 +812,9 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   MgLevelHost& C = Ls[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   const bool transition = mg->comm && C.replicated;  // owned contributions are summed across ranks afterwards
-  if (mg->periodic) tiled = 0;  // the LDS-tiled fine kernels have no x/y wrap: the periodic problem uses the plain ones
+  // periodic problem: the LDS-tiled fine kernels wrap x / y by index when every extent is even (pairs and 2x2x2
+  // aggregates then never straddle the seam); other shapes take the plain kernels
+  if (mg->periodic && !(g.periodic && ((g.nx | g.ny | g.nz) & 1) == 0)) tiled = 0;
   if (tiled && (g.z0 & 1) == 0) {
     // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
     if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);

@@ -122,10 +122,13 @@ def test_gpu_homogenization_on_a_ring_of_slabs(sample_phase, nranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,pid", [((40, 36, 44), 1), ((25, 31, 33), 0), ((16, 18, 130), 1), ((64, 64, 64), 1)])
+@pytest.mark.parametrize("shape,pid", [((40, 36, 44), 1), ((25, 31, 33), 0), ((16, 18, 130), 1), ((64, 64, 64), 1), ((12, 40, 300), 1)])
 def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
     """OI_PRECOND_MG on the periodic cell problems: the aggregation hierarchy wraps in x, y (by index) and z (ghost
-    planes), odd sizes leave single-child aggregates next to the wrap.  Same chi and tensor, far fewer iterations."""
+    planes), odd sizes leave single-child aggregates next to the wrap.  Same chi and tensor, far fewer iterations.
+    Even extents run the flow-through path's LDS-tiled kernels and fused two-kernel iteration with x / y wrapped by
+    index (domain ends inside a tile: 18 and 40 rows over 16-row tiles, 130 and 300 columns over 128-column tiles);
+    odd extents the plain kernels."""
     import openimpala_amd as oia
     nz, ny, nx = shape
     sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
@@ -177,3 +180,26 @@ def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, monkeypatch, nrank
     assert all(conv for conv, _, _ in out[0]["res"])
     assert all(abs(it - i1) <= 2 for (_, it, _), i1 in zip(out[0]["res"], its1)), ([r[1] for r in out[0]["res"]], its1)
     np.testing.assert_allclose(out[0]["D"], want, rtol=0, atol=2e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, monkeypatch):
+    """The two kernel families behind OI_PRECOND_MG on the cell problems (OI_MG_PLAIN selects the plain one): same
+    iteration counts, chi fields equal to solver tolerance."""
+    import openimpala_amd as oia
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:36, :52, :172])
+
+    def run():
+        h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-11, precond=oia.PRECOND_MG)
+        res = [h.solve(k) for k in range(3)]
+        out = res, [h.getChiSolution(k) for k in range(3)], h.tensor().copy()
+        h.destroy()
+        return out
+
+    tiled = run()
+    monkeypatch.setenv("OI_MG_PLAIN", "1")
+    plain = run()
+    for k in range(3):
+        assert tiled[0][k][0] and plain[0][k][0] and abs(tiled[0][k][1] - plain[0][k][1]) <= 1
+        np.testing.assert_allclose(tiled[1][k], plain[1][k], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(tiled[2], plain[2], rtol=0, atol=1e-10)
