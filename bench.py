@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -61,6 +62,9 @@ def parse():
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
+    ap.add_argument("--extras-budget-s", type=float, default=480.0,
+                    help="wall-clock cap on everything after the timed region (solves to 1e-6, variants, homogenization, CPU "
+                         "baseline): past it the JSON line is printed without the unfinished parts and the process exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=384)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -266,6 +270,49 @@ def main():
                 "bytes_per_voxel_iter_in_live_lines": alg_bytes_iter}
     t.cg_finish()
 
+    # Everything below is reported beside the metric, never part of it.  A watchdog prints the line without the
+    # unfinished parts if they overrun (a collective that never returns on some node must not cost the measurement).
+    extras = {"solve": None, "solve_mg": None, "variants": None, "homog": None, "cpu": None, "note": None}
+    emitted = threading.Lock()
+
+    def emit():
+        if not emitted.acquire(blocking=False):
+            return
+        if rank != 0:
+            return
+        out = {
+            "metric": "Mvoxel-iters/sec", "value": value, "unit": "Mvoxel-iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n}x{n}x{nz} two-phase {desc}; phase 1, {args.direction} direction; matrix-free CG "
+                                   f"({args.kernel}, precond {args.precond}); z-slabs over {world} GPU(s)",
+                       "voxels": nvox, "active_vf": st.active_vf, "volume_fraction": st.vf,
+                       "unknowns": st.n_free, "parallelism": f"z-slab x{world}"},
+            "roofline": roofline, "cpu_baseline": extras["cpu"],
+            "apply_roofline": apply_info,
+            "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in ktimes.items()},
+            "steps_effective": steps_done, "relres_after_timed_region": relres,
+            "time_to_1e-6": extras["solve"], "time_to_1e-6_multigrid_pcg": extras["solve_mg"],
+            "variants": extras["variants"], "homogenization": extras["homog"],
+            "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
+                        "flood_sweeps": st.flood_sweeps},
+            "device_bytes": st.bytes_device,
+        }
+        if extras["note"]:
+            out["note"] = extras["note"]
+        print(json.dumps(out), flush=True)
+
+    def overrun():
+        extras["note"] = f"extras stopped by the watchdog after {args.extras_budget_s:.0f} s; null entries did not finish"
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_budget_s, overrun)
+    watchdog.daemon = True
+    watchdog.start()
+
     # ---- wall time to relative residual 1e-6 (second half of the BASELINE metric) ----
     solve = None
     if not args.no_solve:
@@ -289,6 +336,7 @@ def main():
         s1 = time.perf_counter() - s0
         solve = {"eps": 1e-6, "converged": bool(done), "iterations": its, "relres": rel, "seconds": s1,
                  "mvoxel_iters_per_s": nvox * its / s1 / 1e6 if s1 > 0 else None}
+        extras["solve"] = solve
 
     # ---- same solve with the multigrid cycle as preconditioner (the role of SMG in the reference) ----
     solve_mg = None
@@ -319,6 +367,7 @@ def main():
                                               if k in ("mg_vcycle", "fused_a", "update_r", "apply", "update_p", "update_xr")}}
         tm.destroy()
         t = None
+        extras["solve_mg"] = solve_mg
 
     # ---- variant: search direction p STORED as fp32 (x, r, q and all arithmetic fp64) ----
     variants = None
@@ -377,30 +426,12 @@ def main():
                  "seconds_incl_upload": h1, "iterations": [r[1] for r in res], "converged": [bool(r[0]) for r in res],
                  "D_diag": [float(D[i, i]) for i in range(3)]}
 
-    cpu = None
+    extras["variants"] = variants
+    extras["homog"] = homog
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(oia, args)
-
-    if rank == 0:
-        out = {
-            "metric": "Mvoxel-iters/sec", "value": value, "unit": "Mvoxel-iters/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{n}x{n}x{nz} two-phase {desc}; phase 1, {args.direction} direction; matrix-free CG "
-                                   f"({args.kernel}, precond {args.precond}); z-slabs over {world} GPU(s)",
-                       "voxels": nvox, "active_vf": st.active_vf, "volume_fraction": st.vf,
-                       "unknowns": st.n_free, "parallelism": f"z-slab x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "apply_roofline": apply_info,
-            "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in ktimes.items()},
-            "steps_effective": steps_done, "relres_after_timed_region": relres,
-            "time_to_1e-6": solve, "time_to_1e-6_multigrid_pcg": solve_mg, "variants": variants, "homogenization": homog,
-            "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
-                        "flood_sweeps": st.flood_sweeps},
-            "device_bytes": st.bytes_device,
-        }
-        print(json.dumps(out), flush=True)
+        extras["cpu"] = cpu_baseline(oia, args)
+    watchdog.cancel()
+    emit()
     if t is not None:
         t.destroy()
     if comm is not None:
