@@ -1,0 +1,61 @@
+"""bench.py's output contract and the smoke entry point, on a small volume (GPU box only)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--size", "128", "--steps", "6", "--warmup", "2", "--cpu-size", "64", "--cpu-seconds", "1"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def one_line(cmd, env=None):
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines   # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def check(d, n_gpus):
+    assert KEYS <= set(d)
+    assert d["metric"] == "Mvoxel-iters/sec" and d["unit"] == "Mvoxel-iters/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == n_gpus and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["scaling"] == "strong" and "workload" in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
+
+
+def test_bench_line_single_gpu():
+    d = one_line([sys.executable, "bench.py"] + SMALL)
+    check(d, 1)
+    c = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
+    assert d["time_to_1e-6"]["converged"] and d["time_to_1e-6_multigrid_pcg"]["converged"]
+    assert all(d["homogenization"]["converged"])
+
+
+def test_bench_line_through_the_rccl_path():
+    """The launch line of the multi-GPU runs with ONE rank: process group, unique-id broadcast, the library's two RCCL
+    communicators, split launches and the scalar all-reduce all run (there is no neighbour to exchange planes with)."""
+    d = one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                  "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "1", "--force-dist", "--no-cpu-baseline"] + SMALL[:6])
+    check(d, 1)
+    assert d["time_to_1e-6_multigrid_pcg"]["converged"]
+
+
+def test_watchdog_prints_the_line_without_the_unfinished_extras():
+    d = one_line([sys.executable, "bench.py", "--size", "256", "--steps", "6", "--warmup", "2", "--extras-budget-s", "0.05"])
+    assert d["value"] > 0 and "note" in d and d["homogenization"] is None
+
+
+def test_smoke_entry_point():
+    p = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "smoke ok" in p.stdout, p.stderr[-2000:]
