@@ -35,6 +35,7 @@ using namespace oi;
     hipError_t e_ = (call);                                                              \
     if (e_ != hipSuccess) {                                                              \
       oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (void)hipGetLastError(); /* reported: do not leave it for the next launch check to find */ \
       return OI_HIP_ERROR;                                                               \
     }                                                                                    \
   } while (0)

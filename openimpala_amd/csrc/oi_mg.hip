@@ -648,6 +648,7 @@ static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool paren
     hipError_t e_ = (call);                                                  \
     if (e_ != hipSuccess) {                                                  \
       oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (void)hipGetLastError(); /* reported: do not leave it for the next launch check to find */ \
       mg_destroy(mg);                                                        \
       return nullptr;                                                        \
     }                                                                        \
