@@ -398,6 +398,47 @@ def test_capacity_mode_footprint_and_refusals(sample, goldens):
     lean.destroy(); full.destroy()
 
 
+@pytest.mark.parametrize("shape", [(1, 40, 50), (2, 9, 9), (50, 1, 40), (40, 50, 1), (1, 1, 30), (3, 2, 1)])
+def test_degenerate_thin_volumes(shape):
+    """Single planes, rows and columns (a 2-D image is a one-plane stack): every direction and both solvers give the
+    oracle's tau -- including +Inf where both Dirichlet faces are the same cells and NaN where nothing percolates."""
+    ph = o.gen_bernoulli(shape, 5, 0.8)
+    for d in range(3):
+        ref = o.tortuosity(ph, 1, d, 0.0, 1.0, eps=1e-11)
+        for pre in (oia.PRECOND_NONE, oia.PRECOND_MG):
+            t = oia.TortuosityMI355(ph, 1, d, 0.0, 1.0, eps=1e-11, precond=pre)
+            tau = t.value()
+            assert t.status == ref["status"], (d, pre)
+            if math.isfinite(ref["tau"]):
+                assert tau == pytest.approx(ref["tau"], rel=1e-8), (d, pre)
+            else:
+                assert (math.isnan(tau) and math.isnan(ref["tau"])) or tau == ref["tau"], (d, pre)
+            t.destroy()
+
+
+def test_independent_handles_in_concurrent_host_threads(sample, goldens):
+    """Distinct handles may be driven from distinct host threads at once (the reference runs one solver object per
+    MPI rank; the app's gpu.ngpus mode and a parallel REV study do this): three directions, two preconditioners."""
+    import threading
+    g = goldens["phases"]["1"]
+    out, err = {}, []
+
+    def work(d, precond):
+        try:
+            t = oia.TortuosityMI355(sample, 1, d, g["vlo"], g["vhi"], eps=1e-10, precond=precond)
+            out[(d, precond)] = (t.value(), t.stats().flux_in)
+            t.destroy()
+        except Exception as e:  # surface it in the main thread
+            err.append((d, precond, repr(e)))
+
+    th = [threading.Thread(target=work, args=(d, p)) for d in range(3) for p in (oia.PRECOND_MG, oia.PRECOND_JACOBI)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th) and not err, err
+    for (d, _), (tau, flux) in out.items():
+        assert tau == pytest.approx(g["tau"][d], rel=1e-7) and flux == pytest.approx(g["flux"][d], rel=1e-7)
+
+
 def test_out_of_memory_is_an_error_not_a_crash():
     """A volume that cannot fit (34e9 voxels: x alone would take 275 GB next to 70 GB of phase and code bytes) fails
     with OI_HIP_ERROR, gives back what it had allocated, and the library keeps working."""
