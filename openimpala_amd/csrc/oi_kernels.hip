@@ -827,12 +827,13 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
       }
     }
   };
-  auto load_plane = [&](int gz, double2 (&pn)[R], double2 (&pin)[R], const unsigned short (&cn)[R], const int (&ln)[R],
-                        bool (&lv)[R]) {
+  // mode 0: a halo plane owned by another block (nothing stored); 1: an output plane of this block (p_k stored, x
+  // updated at once: keeps p_{k-1} out of the register budget); 2: a ghost plane of the slab, kept current by the
+  // block that marches over it (p_k stored)
+  auto load_plane = [&](int gz, double2 (&pn)[R], const unsigned short (&cn)[R], const int (&ln)[R], bool (&lv)[R], int mode) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
-      pin[rr_] = make_double2(0.0, 0.0);
       pn[rr_] = make_double2(0.0, 0.0);
       lv[rr_] = false;
       if (in_x && j < g.ny) {
@@ -847,13 +848,20 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
         if (PURE) { pn[rr_] = ld2(r + e); continue; }
         const long long ev = lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e;
         const double2 rv = ld2(r + ev);
-        pin[rr_] = PIo<PT>::ld_pair(p_in + ev);
+        const double2 pin = PIo<PT>::ld_pair(p_in + ev);
         double z0 = rv.x, z1 = rv.y;
         if (jacobi) {
           if (cc & 0xff) z0 = rv.x / (double)(cc & 0xff);
           if (cc >> 8) z1 = rv.y / (double)(cc >> 8);
         }
-        pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin[rr_].x), PIo<PT>::rnd(z1 + beta * pin[rr_].y));
+        pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
+        if (mode != 0) {
+          PIo<PT>::st_pair(p_out + ev, pn[rr_].x, pn[rr_].y);
+          if (mode == 1 && k > 0) {
+            const double2 xv = ld2(x + e);
+            st2(x + e, xv.x + alpha_prev * pin.x, xv.y + alpha_prev * pin.y);
+          }
+        }
       }
     }
   };
@@ -929,7 +937,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
     }
   };
 
-  double2 pn_prev[R], pn_cur[R], pn_nxt[R], pin_cur[R], pin_nxt[R];
+  double2 pn_prev[R], pn_cur[R], pn_nxt[R];
   unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
   int lo_cur[R], lo_nxt[R], lo_nn[R];
   bool lv_cur[R], lv_nxt[R];
@@ -937,16 +945,8 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
   load_codes(gs - 1, cc_nxt, lo_nxt);
   load_codes(gs, cc_cur, lo_cur);
   load_codes(gs + 1, cc_nn, lo_nn);
-  load_plane(gs - 1, pn_prev, pin_nxt, cc_nxt, lo_nxt, lv_nxt);
-  if (!PURE && gs == 1) {  // lo ghost plane of p stays current
-#pragma unroll
-    for (int rr_ = 0; rr_ < R; ++rr_) {
-      const int j = j0 + w + rr_ * kNW;
-      if (lv_nxt[rr_])
-        PIo<PT>::st_pair(p_out + (lineoff ? (long long)kLV * lo_nxt[rr_] + (i & (kLV - 1)) : (long long)j * g.pitch + i), pn_prev[rr_].x, pn_prev[rr_].y);
-    }
-  }
-  load_plane(gs, pn_cur, pin_cur, cc_cur, lo_cur, lv_cur);
+  load_plane(gs - 1, pn_prev, cc_nxt, lo_nxt, lv_nxt, gs == 1 ? 2 : 0);  // (lo ghost plane of p stays current)
+  load_plane(gs, pn_cur, cc_cur, lo_cur, lv_cur, 1);
 #pragma unroll
   for (int rr_ = 0; rr_ < R; ++rr_) { cc_nxt[rr_] = cc_nn[rr_]; lo_nxt[rr_] = lo_nn[rr_]; }  // plane gs + 1
   stage(gs & 1, gs, pn_cur);
@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
   double pq = 0.0, pz = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
     load_codes(gz + 2, cc_nn, lo_nn);
-    load_plane(gz + 1, pn_nxt, pin_nxt, cc_nxt, lo_nxt, lv_nxt);
+    load_plane(gz + 1, pn_nxt, cc_nxt, lo_nxt, lv_nxt, gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0));
     if (gz + 1 < ge) { stage((gz + 1) & 1, gz + 1, pn_nxt); load_halo_codes(gz + 2); }
     const double* T = tile[gz & 1];
 #pragma unroll
@@ -992,22 +992,12 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
           continue;
         }
         if (LEAN == 0 || LEAN == 3) st2(q + ev, q0, q1);
-        if (!PURE) {
-          PIo<PT>::st_pair(p_out + ev, pc.x, pc.y);
-          if (k > 0) {
-            const double2 xv = ld2(x + e);
-            st2(x + e, xv.x + alpha_prev * pin_cur[rr_].x, xv.y + alpha_prev * pin_cur[rr_].y);
-          }
-        }
         pq += pc.x * q0; pq += pc.y * q1;
       }
-      if (!PURE && gz + 1 == ge && ge == g.nzl + 1 && lv_nxt[rr_])  // hi ghost plane of p stays current
-        PIo<PT>::st_pair(p_out + (lineoff ? (long long)kLV * lo_nxt[rr_] + (i & (kLV - 1)) : (long long)(gz + 1) * g.plane + (long long)j * g.pitch + i),
-                         pn_nxt[rr_].x, pn_nxt[rr_].y);
     }
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
-      pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; pin_cur[rr_] = pin_nxt[rr_]; cc_cur[rr_] = cc_nxt[rr_];
+      pn_prev[rr_] = pn_cur[rr_]; pn_cur[rr_] = pn_nxt[rr_]; cc_cur[rr_] = cc_nxt[rr_];
       cc_nxt[rr_] = cc_nn[rr_];
       lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
       lv_cur[rr_] = lv_nxt[rr_];
