@@ -1,0 +1,67 @@
+"""Corrupted and truncated input files: the readers report OI_IO_ERROR (or read what is still consistent), they never
+crash.  Each batch runs in a child process so that a fault would fail the test instead of killing the session."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+
+import h5write
+from conftest import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import openimpala_amd as oia
+kind, dataset = sys.argv[2], sys.argv[3]
+for path in sys.argv[4:]:
+    try:
+        r = (oia.TiffReader(path) if kind == "tiff" else oia.HDF5Reader(path, dataset)).threshold(0.5)
+        print("ok", r.shape)
+    except oia.OpenImpalaError as e:
+        assert e.status in (oia.OI_IO_ERROR, oia.OI_BAD_ARG), e.status
+        print("err")
+print("batch done")
+'''
+
+
+def corrupt(src, t, rng):
+    b = bytearray(src)
+    mode = t % 3
+    if mode == 0:
+        return b[:rng.randrange(8, len(b))]
+    if mode == 1:
+        for _ in range(rng.randrange(1, 16)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        return b
+    for _ in range(10):  # header / directory regions
+        pos = rng.randrange(0, min(len(b), 4096)) if rng.random() < 0.5 else rng.randrange(max(0, len(b) - 8192), len(b))
+        b[pos] = rng.randrange(256)
+    return b
+
+
+def run_batch(tmp_path, kind, dataset, sources, n):
+    rng = random.Random(20251031)
+    paths = []
+    for t in range(n):
+        p = tmp_path / f"{kind}{t}"
+        p.write_bytes(bytes(corrupt(sources[t % len(sources)], t, rng)))
+        paths.append(str(p))
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, kind, dataset] + paths, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("batch done"), (r.returncode, r.stderr[-500:])
+    assert len(r.stdout.split()) > n  # one verdict per file
+
+
+def test_corrupted_tiffs_are_errors(tmp_path):
+    src = open(os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif"), "rb").read()
+    run_batch(tmp_path, "tiff", "-", [src], 45)
+
+
+def test_corrupted_hdf5_files_are_errors(tmp_path):
+    arr = (np.random.default_rng(1).random((12, 20, 28)) * 255).astype(np.uint8)
+    a, b = tmp_path / "a.h5", tmp_path / "b.h5"
+    h5write.write_h5(str(a), arr)
+    h5write.write_h5(str(b), arr, chunks=(4, 10, 14), gzip=True, shuffle=True)
+    run_batch(tmp_path, "hdf5", "image", [a.read_bytes(), b.read_bytes()], 45)
