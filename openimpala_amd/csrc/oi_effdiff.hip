@@ -238,9 +238,9 @@ static oi_status reduce_to(oi_effdiff* h, int nblocks, int ncomp, double* dst, b
 
 static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const uint8_t* phase, bool on_device, int nx,
                                        int ny, int nz, int z0, int nzl, int phase_id, const oi_tort_opts* opts) {
-  if (!out) return OI_BAD_ARG;
+  if (!out) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *out = nullptr;
-  if (!phase || nx < 1 || ny < 1 || nz < 1 || nzl < 1 || z0 < 0 || z0 + nzl > nz) return OI_BAD_ARG;
+  if (!phase || nx < 1 || ny < 1 || nz < 1 || nzl < 1 || z0 < 0 || z0 + nzl > nz) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   oi_tort_opts o;
   oi_tort_default_opts(&o);
   if (opts) o = *opts;
@@ -336,7 +336,7 @@ extern "C" oi_status oi_effdiff_create_slab(oi_effdiff** out, oi_comm* comm, con
 // EffectiveDiffusivityHypre::solve (EffectiveDiffusivityHypre.cpp:543-687) for direction k.
 // *converged = 0 leaves chi_k = 0 as the reference does (:641-645).
 extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, int* iterations, double* relres) {
-  if (!h || dir_k < 0 || dir_k > 2) return OI_BAD_ARG;
+  if (!h || dir_k < 0 || dir_k > 2) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   hipStream_t s = h->stream;
@@ -436,7 +436,7 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
 
 // getChiSolution (EffectiveDiffusivityHypre.cpp:689-): nx*ny*nz doubles, x fastest
 extern "C" oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi_out) {
-  if (!h || dir_k < 0 || dir_k > 2 || !chi_out) return OI_BAD_ARG;
+  if (!h || dir_k < 0 || dir_k > 2 || !chi_out) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
@@ -452,7 +452,7 @@ extern "C" oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi_ou
 
 // calculate_Deff_tensor_homogenization (Diffusion.cpp:60-167): row-major 3x3, D_eff / D_material
 extern "C" oi_status oi_effdiff_tensor(oi_effdiff* h, double* deff9) {
-  if (!h || !deff9) return OI_BAD_ARG;
+  if (!h || !deff9) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!(h->solved[0] && h->solved[1] && h->solved[2])) {
     oi::set_error("solve chi_x, chi_y and chi_z first");
     return OI_BAD_ARG;
@@ -474,7 +474,7 @@ extern "C" oi_status oi_effdiff_tensor(oi_effdiff* h, double* deff9) {
 }
 
 extern "C" oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int* iterations3, double* relres3) {
-  if (!h) return OI_BAD_ARG;
+  if (!h) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (n_active) *n_active = h->n_active;
   for (int k = 0; k < 3; ++k) {
     if (iterations3) iterations3[k] = h->iters[k];

@@ -425,7 +425,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
 static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phase, bool on_device, int nx,
                                int ny, int nz, int z0, int nzl, int phase_id, int dir, double vlo, double vhi,
                                const oi_tort_opts* opts) {
-  if (!out) return OI_BAD_ARG;
+  if (!out) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *out = nullptr;
   if (!phase || nx < 1 || ny < 1 || nz < 1 || nzl < 1 || z0 < 0 || z0 + nzl > nz || dir < 0 || dir > 2) {
     oi::set_error("bad geometry/direction");
@@ -576,7 +576,7 @@ static oi_status reduce_to(oi_tort* h, int nblocks, int ncomp, double* dst, bool
 }
 
 extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
-  if (!h) return OI_BAD_ARG;
+  if (!h) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!h->percolates || !h->vectors_ready) return OI_NO_PERCOLATION;
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
@@ -733,8 +733,8 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
 }
 
 extern "C" oi_status oi_tort_cg_iterate(oi_tort* h, int n) {
-  if (!h || n < 0) return OI_BAD_ARG;
-  if (!h->cg_active) return OI_BAD_ARG;
+  if (!h || n < 0) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  if (!h->cg_active) { oi::set_error("%s: no CG run is open (oi_tort_cg_begin first)", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const int limit = h->maxiter + (h->cg1 ? 1 : 0);  // kernel k of the single-kernel variant completes iteration k
   for (int i = 0; i < n; ++i) {
@@ -753,7 +753,7 @@ static oi_status poll_ctrl(oi_tort* h) {
 }
 
 extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
-  if (!h || !h->cg_active) return OI_BAD_ARG;
+  if (!h || !h->cg_active) { oi::set_error("%s: no CG run is open (oi_tort_cg_begin first)", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
@@ -786,14 +786,14 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
 }
 
 extern "C" oi_status oi_tort_set_eps(oi_tort* h, double eps) {
-  if (!h || !(eps > 0.0)) return OI_BAD_ARG;
-  if (h->cg_active) return OI_BAD_ARG;
+  if (!h || !(eps > 0.0)) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  if (h->cg_active) { oi::set_error("%s: a CG run is open (oi_tort_cg_finish first)", __func__); return OI_BAD_ARG; }
   h->opts.eps = eps;
   return OI_OK;
 }
 
 extern "C" oi_status oi_tort_sync(oi_tort* h) {
-  if (!h) return OI_BAD_ARG;
+  if (!h) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   HIPC(hipStreamSynchronize(h->stream));
   if (h->opts.profile) prof_harvest(h);
@@ -801,7 +801,7 @@ extern "C" oi_status oi_tort_sync(oi_tort* h) {
 }
 
 extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int* converged) {
-  if (!h || !h->vectors_ready) return OI_BAD_ARG;
+  if (!h || !h->vectors_ready) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
@@ -873,7 +873,7 @@ static oi_status fluxes(oi_tort* h) {
 
 // TortuosityHypre::value (TortuosityHypre.cpp:761-891)
 extern "C" oi_status oi_tort_value(oi_tort* h, int refresh, double* tau) {
-  if (!h || !tau) return OI_BAD_ARG;
+  if (!h || !tau) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   const double nan = std::numeric_limits<double>::quiet_NaN();
   const double inf = std::numeric_limits<double>::infinity();
   *tau = nan;
@@ -928,14 +928,14 @@ extern "C" oi_status oi_tort_value(oi_tort* h, int refresh, double* tau) {
 }
 
 extern "C" oi_status oi_tort_get_stats(const oi_tort* h, oi_tort_stats* st) {
-  if (!h || !st) return OI_BAD_ARG;
+  if (!h || !st) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *st = h->st;
   st->bytes_device = (double)h->bytes_device;
   return OI_OK;
 }
 
 extern "C" oi_status oi_tort_get_solution(oi_tort* h, double* phi) {
-  if (!h || !phi) return OI_BAD_ARG;
+  if (!h || !phi) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
@@ -951,7 +951,7 @@ extern "C" oi_status oi_tort_get_solution(oi_tort* h, double* phi) {
 }
 
 extern "C" oi_status oi_tort_get_mask(oi_tort* h, uint8_t* mask) {
-  if (!h || !mask) return OI_BAD_ARG;
+  if (!h || !mask) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
@@ -966,7 +966,7 @@ extern "C" oi_status oi_tort_get_mask(oi_tort* h, uint8_t* mask) {
 }
 
 extern "C" oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes) {
-  if (!h || !codes) return OI_BAD_ARG;
+  if (!h || !codes) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
@@ -983,9 +983,9 @@ extern "C" oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes) {
 
 // q = A v with either stencil kernel; uses r / q as scratch, so only outside a solve
 extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q, int variant) {
-  if (!h || !v || !q) return OI_BAD_ARG;
+  if (!h || !v || !q) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
-  if (h->cg_active) return OI_BAD_ARG;
+  if (h->cg_active) { oi::set_error("%s: a CG run is open (oi_tort_cg_finish first)", __func__); return OI_BAD_ARG; }
   if (!h->q) { oi::set_error("the capacity mode keeps no A p vector: use another kernel variant for the stand-alone apply"); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
@@ -1021,9 +1021,9 @@ extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q,
 }
 
 extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_launch) {
-  if (!h || reps < 1 || !ms_per_launch) return OI_BAD_ARG;
+  if (!h || reps < 1 || !ms_per_launch) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
-  if (h->cg_active) return OI_BAD_ARG;
+  if (h->cg_active) { oi::set_error("%s: a CG run is open (oi_tort_cg_finish first)", __func__); return OI_BAD_ARG; }
   if (!h->q) { oi::set_error("the capacity mode keeps no A p vector: use another kernel variant for the stand-alone apply"); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
@@ -1073,10 +1073,10 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
 //   neighbours > 0 and off-diagonals -1 on exactly those neighbours (row sum 0).
 // Implemented by regenerating the codes from the mask into scratch and comparing.
 extern "C" oi_status oi_tort_check_matrix_properties(oi_tort* h, int64_t* n_violations) {
-  if (!h || !n_violations) return OI_BAD_ARG;
+  if (!h || !n_violations) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *n_violations = 0;
   if (!h->vectors_ready) return OI_NO_PERCOLATION;
-  if (h->cg_active) return OI_BAD_ARG;
+  if (h->cg_active) { oi::set_error("%s: a CG run is open (oi_tort_cg_finish first)", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
@@ -1125,7 +1125,7 @@ extern "C" oi_status oi_tort_check_matrix_properties(oi_tort* h, int64_t* n_viol
 
 // fraction of the aligned `group_voxels`-long x-runs (this slab) that contain a free voxel
 extern "C" oi_status oi_tort_live_fraction(oi_tort* h, int group_voxels, double* fraction) {
-  if (!h || !fraction || group_voxels < 1) return OI_BAD_ARG;
+  if (!h || !fraction || group_voxels < 1) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *fraction = 0.0;
   if (!h->percolates || !h->code) return OI_NO_PERCOLATION;
   HIPC(hipSetDevice(h->device));
@@ -1162,7 +1162,7 @@ extern "C" void oi_tort_reset_kernel_times(oi_tort* h) {
 // ---- stand-alone helpers ---------------------------------------------------------------
 extern "C" oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phase_id, int64_t* phase_count,
                                         int64_t* total_count) {
-  if (!phase || !phase_count || !total_count) return OI_BAD_ARG;
+  if (!phase || !phase_count || !total_count) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;
   OIC(ensure_device(-1, &device));
   *total_count = (int64_t)n;
@@ -1195,7 +1195,7 @@ extern "C" oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phas
 // tortuosity_remspot (Tortuosity_filcc.F90:88-177) on a host array: in place, x-fastest order, one box.
 // Runs on the device like everything else (no CPU path).
 extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes) {
-  if (!q || nx < 1 || ny < 1 || nz < 1 || passes < 0) return OI_BAD_ARG;
+  if (!q || nx < 1 || ny < 1 || nz < 1 || passes < 0) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (passes == 0) return OI_OK;
   uint8_t* dev = nullptr;
   OIC(remspot_private_copy(q, false, nx, ny, nz, passes, -1, &dev));
@@ -1207,7 +1207,7 @@ extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes) 
 
 extern "C" oi_status oi_gen_bernoulli_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
                                              int nz_local, uint64_t seed, uint64_t thr53) {
-  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1) return OI_BAD_ARG;
+  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   launch_gen_bernoulli(phase_dev, nx, ny, nz_global, z0, nz_local, seed, thr53, nullptr);
   HIPC(hipGetLastError());
   HIPC(hipDeviceSynchronize());
@@ -1223,7 +1223,7 @@ static inline uint64_t mix64_host(uint64_t z) {
 
 extern "C" oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0,
                                            int nz_local, uint64_t seed, int nspheres, int r2h) {
-  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1 || nspheres < 0 || r2h < 1) return OI_BAD_ARG;
+  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1 || nspheres < 0 || r2h < 1) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   // centres in half-voxel units (same draw as the oracle), binned into cubic cells >= radius
   const int cell = std::max(r2h, 8);
   const int ncx = (2 * nx) / cell + 1, ncy = (2 * ny) / cell + 1, ncz = (2 * nz_global) / cell + 1;
@@ -1257,7 +1257,7 @@ extern "C" oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, i
 
 extern "C" oi_status oi_gen_blobs_device(uint8_t* phase_dev, int nx, int ny, int nz_global, int z0, int nz_local,
                                          uint64_t seed, int spacing, uint64_t level) {
-  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1 || spacing < 2 || spacing > 512 || level > 65535) return OI_BAD_ARG;
+  if (!phase_dev || nx < 1 || ny < 1 || nz_local < 1 || spacing < 2 || spacing > 512 || level > 65535) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   (void)nz_global;
   launch_gen_blobs(phase_dev, nx, ny, z0, nz_local, seed, spacing, level, nullptr);
   HIPC(hipGetLastError());
@@ -1283,7 +1283,7 @@ extern "C" uint64_t oi_blobs_level(uint64_t seed, int spacing, double porosity) 
 }
 
 extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
-  if (!ptr) return OI_BAD_ARG;
+  if (!ptr) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;
   OIC(ensure_device(-1, &device));
   HIPC(hipMalloc(ptr, bytes));
@@ -1291,7 +1291,7 @@ extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
 }
 extern "C" oi_status oi_dev_free(void* ptr) { HIPC(hipFree(ptr)); return OI_OK; }
 extern "C" oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
-  if (!free_bytes || !total_bytes) return OI_BAD_ARG;
+  if (!free_bytes || !total_bytes) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;
   OIC(ensure_device(-1, &device));
   HIPC(hipMemGetInfo(free_bytes, total_bytes));

@@ -416,6 +416,42 @@ def test_degenerate_thin_volumes(shape):
             t.destroy()
 
 
+def test_api_misuse_is_reported_not_fatal(sample):
+    """Calls out of order, bad arguments, use after destroy: OI_BAD_ARG with a message that names the call."""
+    sub = np.ascontiguousarray(sample[:24, :28, :32])
+    t = oia.TortuosityMI355(sub, 1, 0)
+    for call in (lambda: t.cg_iterate(3), t.cg_finish, lambda: t.set_eps(0.0), lambda: t.set_eps(float("nan"))):
+        with pytest.raises(oia.OpenImpalaError) as e:
+            call()
+        assert e.value.status == oia.OI_BAD_ARG and "oi_tort_" in str(e.value)
+    assert t.cg_state() == (0, 0.0, False) and t.solution().shape == sub.shape
+    tau = t.value()
+    assert tau > 1.0 and t.value() == tau and t.value(refresh=True) == pytest.approx(tau, rel=1e-12)
+    t.cg_begin()
+    with pytest.raises(oia.OpenImpalaError):   # the stand-alone apply is refused while a CG run is open
+        t.apply(np.zeros(sub.shape))
+    with pytest.raises(oia.OpenImpalaError):
+        t.cg_iterate(-5)
+    t.cg_iterate(0); t.cg_finish()
+    t.destroy(); t.destroy()
+    with pytest.raises(oia.OpenImpalaError):
+        t.value()
+    for kw in (dict(kernel=99), dict(eps=-1.0)):
+        with pytest.raises(oia.OpenImpalaError):
+            oia.TortuosityMI355(sub, 1, 0, **kw)
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TortuosityMI355(np.zeros((0, 4, 4), np.uint8), 1, 0)
+    assert math.isnan(oia.TortuosityMI355(sub, 5, 0).value())            # phase id absent: no percolation
+    assert math.isnan(oia.TortuosityMI355(sub, 1, 0, maxiter=1).value())  # not converged
+    h = oia.EffectiveDiffusivityMI355(sub, 1)
+    with pytest.raises(oia.OpenImpalaError):
+        h.tensor()
+    with pytest.raises(oia.OpenImpalaError) as e:
+        h.solve(5)
+    assert "oi_effdiff_solve" in str(e.value)
+    h.destroy(); h.destroy()
+
+
 def test_independent_handles_in_concurrent_host_threads(sample, goldens):
     """Distinct handles may be driven from distinct host threads at once (the reference runs one solver object per
     MPI rank; the app's gpu.ngpus mode and a parallel REV study do this): three directions, two preconditioners."""
