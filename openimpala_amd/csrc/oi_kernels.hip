@@ -750,7 +750,7 @@ constexpr int kNW = 8;              // waves per block
 // capacity mode that stores x, r, p only (25 B/voxel): LEAN = 1 reduces p.Ap without storing q;
 // LEAN = 2 recomputes q = A p on the fly and applies x += alpha p, r -= alpha q (`q` argument = r
 // vector), partials {r.r, r.z}.  Both take a CG vector and are predicated on the code byte.
-template <int R, bool PURE, typename PT, int LEAN = 0>
+template <int R, bool PURE, typename PT, int LEAN, bool COMPACT>
 __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                        const double* __restrict__ r, const PT* __restrict__ p_in,
                                                        PT* __restrict__ p_out, double* __restrict__ q, int jacobi,
@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
     if (PURE) return code[e] ? r[e] : 0.0;
     const unsigned c = code[e];
     if (!c) return 0.0;
-    const long long ev = lineoff ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
+    const long long ev = COMPACT ? (long long)kLV * lineoff[((long long)gz * g.ny + jj) * LW + (ii >> kLVs)] + (ii & (kLV - 1)) : e;
     double z = r[ev];
     if (jacobi) z = z / (double)c;
     return PIo<PT>::rnd(z + beta * (double)p_in[ev]);
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
       ln[rr_] = -1;
       if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
-        if (!PURE && lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
+        if (!PURE && COMPACT) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
       }
     }
   };
@@ -843,10 +843,10 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
         // whole lines: every lane of a live line reads (and later writes).  Compacted vectors: the table says which
         // lines exist (kLV voxels); dense vectors: a 128-byte cache line is live when any of its lanes holds a free voxel
         const bool dense_live = line_live(cc != 0);
-        lv[rr_] = (!PURE && lineoff) ? ln[rr_] >= 0 : dense_live;
+        lv[rr_] = (!PURE && COMPACT) ? ln[rr_] >= 0 : dense_live;
         if (!lv[rr_]) continue;
         if (PURE) { pn[rr_] = ld2(r + e); continue; }
-        const long long ev = lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e;
+        const long long ev = COMPACT ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e;
         const double2 rv = ld2(r + ev);
         const double2 pin = PIo<PT>::ld_pair(p_in + ev);
         double z0 = rv.x, z1 = rv.y;
@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
           if (hcode & 0xff) h.x = v.x;
           if (hcode >> 8) h.y = v.y;
         } else {
-          const long long ev = lineoff ? (long long)kLV * hslot + (i & (kLV - 1)) : e;
+          const long long ev = COMPACT ? (long long)kLV * hslot + (i & (kLV - 1)) : e;
           const double2 rv = ld2(r + ev);
           const double2 pv = PIo<PT>::ld_pair(p_in + ev);
           double z0 = rv.x, z1 = rv.y;
@@ -916,7 +916,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
         if (PURE) {
           h = r[e];
         } else {
-          const long long ev = lineoff ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : e;
+          const long long ev = COMPACT ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : e;
           double z = r[ev];
           if (jacobi) z = z / (double)hcode;
           h = PIo<PT>::rnd(z + beta * (double)p_in[ev]);
@@ -930,10 +930,10 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
     if ((PURE && LEAN == 0) || gz > g.nzl + 1) return;
     if (yhalo) {
       hcode = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)hrow * g.pitch + i);
-      if (!PURE && lineoff) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
+      if (!PURE && COMPACT) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
     } else if (xhalo) {
       hcode = code[(long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i];
-      if (!PURE && lineoff) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
+      if (!PURE && COMPACT) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
     }
   };
 
@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const long long ev = (!PURE && lineoff) ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e;  // q, p_out (x stays at e)
+        const long long ev = (!PURE && COMPACT) ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e;  // q, p_out (x stays at e)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 pc = pn_cur[rr_];
         const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
@@ -1053,9 +1053,14 @@ template <int R, bool PURE, typename PT, int LEAN>
 static void launch_tiled_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
                            void* p_out, double* q, int jacobi, const double* hist, int k, int zchunk, int tiles_x,
                            int tiles_y, int nzc, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
-  hipLaunchKernelGGL((k_fused_a<R, PURE, PT, LEAN>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
-                     (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff,
-                     (g.pitch + kLV - 1) / kLV);
+  if (lineoff && !PURE)
+    hipLaunchKernelGGL((k_fused_a<R, PURE, PT, LEAN, !PURE>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
+                       (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff,
+                       (g.pitch + kLV - 1) / kLV);
+  else
+    hipLaunchKernelGGL((k_fused_a<R, PURE, PT, LEAN, false>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (const PT*)p_in,
+                       (PT*)p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, nullptr,
+                       (g.pitch + kLV - 1) / kLV);
 }
 
 template <bool PURE, typename PT, int LEAN = 0>
@@ -1131,7 +1136,9 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 // b vanishes on non-free cells and its ghost planes hold the neighbour slabs' values; xc is the
 // fp32 coarse correction of the 2x2x2 aggregates.
 // --------------------------------------------------------------------------------------
-template <int R, int MODE>
+// COMPACT: b and out live in the compacted line layout (lineoff != null); a compile-time switch, so that neither address
+// form is computed just to be discarded by a select
+template <int R, int MODE, bool COMPACT>
 __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, const uint8_t* __restrict__ code,
                                                        const double* __restrict__ b, MgCoarse C, double omega, double scale,
                                                        double* __restrict__ out, float* __restrict__ bcoarse, int zchunk,
@@ -1186,7 +1193,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
       ln[rr_] = -1;
       if (in_x && j < g.ny && gz <= g.nzl + 1) {
         cn[rr_] = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)j * g.pitch + i);
-        if (lineoff) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
+        if (COMPACT) ln[rr_] = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
       }
     }
   };
@@ -1204,8 +1211,8 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
         const bool dense_live = line_live(cc != 0);
-        if (lineoff ? ln[rr_] >= 0 : dense_live) {  // b and the output vanish on non-free voxels: lines without one are not moved
-          braw[rr_] = ld2(b + (lineoff ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
+        if (COMPACT ? ln[rr_] >= 0 : dense_live) {  // b and the output vanish on non-free voxels: lines without one are not moved
+          braw[rr_] = ld2(b + (COMPACT ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
           if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
             const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
             float cv = C.xc[cm];
@@ -1243,7 +1250,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (hcode) {
-        const long long ev = lineoff ? (long long)kLV * hslot + (i & (kLV - 1)) : (long long)gz * g.plane + (long long)hrow * g.pitch + i;
+        const long long ev = COMPACT ? (long long)kLV * hslot + (i & (kLV - 1)) : (long long)gz * g.plane + (long long)hrow * g.pitch + i;
         const double2 bv = ld2(b + ev);
         const double cr = MODE == 2 ? corr_at(i, hrow, gz) : 0.0;  // voxels i and i + 1 share their aggregate
         if (hcode & 0xff) h.x = bv.x * wtab[hcode & 0xff] + cr;
@@ -1253,7 +1260,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
     } else if (w == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
-        const long long ev = lineoff ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : (long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i;
+        const long long ev = COMPACT ? (long long)kLV * hslot + (xh_i & (kLV - 1)) : (long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i;
         h = b[ev] * wtab[hcode];
         if (MODE == 2) h += corr_at(xh_i, xh_row, gz);
       }
@@ -1265,10 +1272,10 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
     if (gz > g.nzl + 1) return;
     if (yhalo) {
       hcode = *reinterpret_cast<const unsigned short*>(code + (long long)gz * g.plane + (long long)hrow * g.pitch + i);
-      if (lineoff) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
+      if (COMPACT) hslot = lineoff[((long long)gz * g.ny + hrow) * LW + (i >> kLVs)];
     } else if (xhalo) {
       hcode = code[(long long)gz * g.plane + (long long)xh_row * g.pitch + xh_i];
-      if (lineoff) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
+      if (COMPACT) hslot = lineoff[((long long)gz * g.ny + xh_row) * LW + (xh_i >> kLVs)];
     }
   };
 
@@ -1331,7 +1338,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cc_cur[rr_];
         const bool dense_live = line_live(cc != 0);
-        if (!(lineoff ? lo_cur[rr_] >= 0 : dense_live)) continue;  // (live lines are written whole)
+        if (!(COMPACT ? lo_cur[rr_] >= 0 : dense_live)) continue;  // (live lines are written whole)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 vc = v_cur[rr_], bc = b_cur[rr_];
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
@@ -1340,7 +1347,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + (bc.x - av) * wtab[c0]; }
         if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + (bc.y - av) * wtab[c1]; }
         if (MODE == 3) { xsum[rr_] = o0 + o1; continue; }
-        st2(out + (lineoff ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e), o0, o1);
+        st2(out + (COMPACT ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e), o0, o1);
         dot += o0 * bc.x; dot += o1 * bc.y;
       }
     }
@@ -1388,15 +1395,13 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
     nzc = (g.nzl + zchunk - 1) / zchunk;
   }
   const int blocks = (int)(cols * nzc);
-  if (mode == 1)
-    hipLaunchKernelGGL((k_mg_fine<R, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW);
-  else if (mode == 3)
-    hipLaunchKernelGGL((k_mg_fine<R, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW);
-  else
-    hipLaunchKernelGGL((k_mg_fine<R, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse,
-                       zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW);
+#define OI_MGF(M, C)                                                                                                     \
+  hipLaunchKernelGGL((k_mg_fine<R, M, C>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse, \
+                     zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, LW)
+  if (mode == 1) { if (lineoff) OI_MGF(1, true); else OI_MGF(1, false); }
+  else if (mode == 3) { if (lineoff) OI_MGF(3, true); else OI_MGF(3, false); }
+  else { if (lineoff) OI_MGF(2, true); else OI_MGF(2, false); }
+#undef OI_MGF
   return blocks;
 }
 

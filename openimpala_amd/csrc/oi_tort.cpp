@@ -107,6 +107,7 @@ struct oi_tort {
   bool percolates = false;
   bool vectors_ready = false;
   bool cg_active = false;
+  bool cg_ever = false;    // a CG run has been begun at least once (the device-side history is initialised)
   bool solved = false;
   int maxiter = 0;
   int iters_issued = 0;
@@ -610,6 +611,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   h->iters_issued = 0;
   h->iters_done = 0;
   h->cg_active = true;
+  h->cg_ever = true;
   return OI_OK;
 }
 
@@ -802,6 +804,12 @@ extern "C" oi_status oi_tort_sync(oi_tort* h) {
 
 extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int* converged) {
   if (!h || !h->vectors_ready) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  if (!h->cg_ever) {  // no run yet: the history and the flag on the device are not initialised
+    if (iterations_done) *iterations_done = 0;
+    if (relres) *relres = 0.0;
+    if (converged) *converged = 0;
+    return OI_OK;
+  }
   HIPC(hipSetDevice(h->device));
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
