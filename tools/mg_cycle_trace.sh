@@ -12,7 +12,7 @@ import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].replace("void oi::", "") for r in rows]
 # cycles start at k_mg_fine<2, 3>
-starts = [i for i, n in enumerate(names) if n.startswith("k_mg_fine<2, 3>")]
+starts = [i for i, n in enumerate(names) if n.startswith("k_mg_fine<2, 3")]
 a, b = starts[11], starts[12]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
