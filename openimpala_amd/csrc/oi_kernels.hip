@@ -836,13 +836,14 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
       const int j = j0 + w + rr_ * kNW;
       pn[rr_] = make_double2(0.0, 0.0);
       lv[rr_] = false;
-      if (in_x && j < g.ny) {
+      // (compacted layout: rows / pairs outside the domain have no slot, so the slot test is the only one needed)
+      if ((!PURE && COMPACT) || (in_x && j < g.ny)) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
         if (PURE && LEAN == 0) { pn[rr_] = ld2(r + e); continue; }
         // whole lines: every lane of a live line reads (and later writes).  Compacted vectors: the table says which
         // lines exist (kLV voxels); dense vectors: a 128-byte cache line is live when any of its lanes holds a free voxel
-        const bool dense_live = line_live(cc != 0);
+        const bool dense_live = (!PURE && COMPACT) ? false : line_live(cc != 0);
         lv[rr_] = (!PURE && COMPACT) ? ln[rr_] >= 0 : dense_live;
         if (!lv[rr_]) continue;
         if (PURE) { pn[rr_] = ld2(r + e); continue; }
@@ -1207,10 +1208,11 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
       const int j = j0 + w + rr_ * kNW;
       braw[rr_] = make_double2(0.0, 0.0);
       craw[rr_] = 0.f;
-      if (in_x && j < g.ny) {
+      // (compacted layout: rows / pairs outside the domain have no slot, so the slot test is the only one needed)
+      if (COMPACT || (in_x && j < g.ny)) {
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned short cc = cn[rr_];
-        const bool dense_live = line_live(cc != 0);
+        const bool dense_live = COMPACT ? false : line_live(cc != 0);
         if (COMPACT ? ln[rr_] >= 0 : dense_live) {  // b and the output vanish on non-free voxels: lines without one are not moved
           braw[rr_] = ld2(b + (COMPACT ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
           if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
@@ -1329,16 +1331,16 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const int j = j0 + w + rr_ * kNW;
       xsum[rr_] = 0.0;
-      if (in_x && j < g.ny) {
+      if (COMPACT || (in_x && j < g.ny)) {
+        const unsigned short cc = cc_cur[rr_];
+        const bool dense_live = COMPACT ? false : line_live(cc != 0);
+        if (!(COMPACT ? lo_cur[rr_] >= 0 : dense_live)) continue;  // (live lines are written whole; dead ones read no LDS)
         const int base = (w + rr_ * kNW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
         const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
-        const unsigned short cc = cc_cur[rr_];
-        const bool dense_live = line_live(cc != 0);
-        if (!(COMPACT ? lo_cur[rr_] >= 0 : dense_live)) continue;  // (live lines are written whole)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 vc = v_cur[rr_], bc = b_cur[rr_];
         const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
