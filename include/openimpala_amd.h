@@ -47,7 +47,10 @@ typedef struct oi_comm oi_comm; /* replaces MPI_COMM_WORLD / amrex::ParallelDesc
 
 /* MG: one 2x2x2 aggregation-multigrid cycle per PCG iteration (what SMG is to the reference's
  * FlexGMRES): tens of iterations instead of O(10 N); works on z-slabs too */
-enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1, OI_PRECOND_MG = 2 };
+/* NONE / JACOBI: (Jacobi-preconditioned) CG; MG: one aggregation-multigrid cycle per PCG iteration, the role of SMG in
+ * the reference's FlexGMRES (TortuosityHypre.cpp:664-693).  DEFAULT (what oi_tort_default_opts selects): MG where the
+ * kernel variant runs it (auto / fused / unfused), plain CG for the explicitly chosen fused1 / lean variants. */
+enum { OI_PRECOND_NONE = 0, OI_PRECOND_JACOBI = 1, OI_PRECOND_MG = 2, OI_PRECOND_DEFAULT = 3 };
 /* UNFUSED: apply / p-update / x,r-update kernels (89 B/voxel-iter); FUSED: two kernels (73 B);
  * FUSED1: ONE kernel per iteration with a single reduction (61 B), see DESIGN.md section 4;
  * LEAN: capacity mode -- only x, r, p are stored (25 B/voxel of HBM instead of 57): A p is never

@@ -30,7 +30,7 @@ ABI_VERSION = 1
 
 OI_OK, OI_BAD_ARG, OI_NO_PERCOLATION, OI_NOT_CONVERGED, OI_FLUX_NOT_CONSERVED = 0, 1, 2, 3, 4
 OI_HIP_ERROR, OI_RCCL_ERROR, OI_NO_DEVICE, OI_IO_ERROR = 5, 6, 7, 8
-PRECOND_NONE, PRECOND_JACOBI, PRECOND_MG = 0, 1, 2
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_MG, PRECOND_DEFAULT = 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_UNFUSED, KERNEL_FUSED, KERNEL_FUSED1, KERNEL_LEAN = 0, 1, 2, 3, 4
 STORE_F64, STORE_F32 = 0, 1
 COMM_ID_BYTES = 128

@@ -303,7 +303,7 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   h->n_active = (long long)cnt;
   // one multigrid cycle per PCG iteration (what PFMG is to the reference's FlexGMRES, EffectiveDiffusivityHypre.cpp:
   // 578-600); tiny or empty volumes keep plain CG
-  if (o.precond == OI_PRECOND_MG && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4) {
+  if ((o.precond == OI_PRECOND_MG || o.precond == OI_PRECOND_DEFAULT) && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4) {
     HIPC(hipMalloc((void**)&h->z, sizeof(double) * g.nvec));
     HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
     size_t mg_bytes = 0;

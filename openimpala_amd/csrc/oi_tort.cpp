@@ -222,7 +222,7 @@ extern "C" void oi_tort_default_opts(oi_tort_opts* o) {
   if (!o) return;
   o->eps = 1e-9;  // reference default, TortuosityHypre.cpp:142
   o->maxiter = 0;
-  o->precond = OI_PRECOND_NONE;
+  o->precond = OI_PRECOND_DEFAULT;  // the reference's solve is multigrid-preconditioned too
   o->remspot_passes = 0;
   o->verbose = 0;
   o->check_every = 0;
@@ -437,6 +437,12 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   if (opts) o = *opts;
   if (!(o.eps > 0.0)) {  // AMREX_ALWAYS_ASSERT(m_eps > 0), TortuosityHypre.cpp:159
     oi::set_error("eps must be positive");
+    return OI_BAD_ARG;
+  }
+  if (o.precond == OI_PRECOND_DEFAULT)
+    o.precond = (o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_LEAN) ? OI_PRECOND_NONE : OI_PRECOND_MG;
+  if (o.precond < OI_PRECOND_NONE || o.precond > OI_PRECOND_MG) {
+    oi::set_error("unknown preconditioner %d", o.precond);
     return OI_BAD_ARG;
   }
   int device = 0;

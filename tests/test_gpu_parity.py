@@ -162,7 +162,7 @@ def test_iterate_after_m_steps_matches_oracle(sample, variant, m):
     for xs in ((0, 1) if variant == oia.KERNEL_FUSED1 else (1,)):
         try:
             oia.set_tuning(16, 0, 32, 0, xs)
-            t = oia.TortuosityMI355(sub, 1, 0, -1.0, 1.0, eps=1e-30, maxiter=m, kernel=variant)
+            t = oia.TortuosityMI355(sub, 1, 0, -1.0, 1.0, eps=1e-30, maxiter=m, kernel=variant, precond=oia.PRECOND_NONE)
             assert math.isnan(t.value()) and t.status == oia.OI_NOT_CONVERGED
             st = t.stats()
             assert st.iterations == m and st.final_relres == pytest.approx(rel, rel=1e-9)
@@ -346,7 +346,7 @@ def test_1024_spheres_two_solver_paths_agree():
     assert res[1][:2] == res[0][:2]            # same iterates in either layout
     assert res[1][2] < 0.75 * res[0][2]        # a third less memory
     assert 0.35 < res[1][3] < 0.45 and res[1][0] > 1.0
-    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-7)  # default kernel, plain CG
+    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-7, precond=oia.PRECOND_NONE)  # single-kernel plain CG
     assert t.checkMatrixProperties()
     tau_cg = t.value()
     st = t.stats()
