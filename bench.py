@@ -112,7 +112,17 @@ def cpu_baseline(oia, args):
     t0 = time.time()
     o.cg_fixed(code, x0, iters)
     dt = time.time() - t0
-    return {"value": n ** 3 * iters / dt / 1e6, "unit": "Mvoxel-iters/s", "cores": threads, "kind": "port",
+    # the same kernel on ONE core for reference (the reference's README advises OMP_NUM_THREADS=1 under MPI): a few iterations
+    one_core = None
+    try:
+        o.lib().oi_oracle_set_threads(1)
+        n1 = max(2, min(20, int(3.0 / max(per_iter * threads, 1e-6))))
+        t0 = time.time()
+        o.cg_fixed(code, x0, n1)
+        one_core = n ** 3 * n1 / (time.time() - t0) / 1e6
+    finally:
+        o.lib().oi_oracle_set_threads(threads)
+    return {"value": n ** 3 * iters / dt / 1e6, "unit": "Mvoxel-iters/s", "cores": threads, "kind": "port", "one_core_value": one_core,
             "sample": f"{n}^3 {desc}, X direction, {iters} CG iterations in {dt:.1f} s, "
                       "CPU restatement (matrix-free CG, OpenMP), not Hypre FlexGMRES+SMG"}
 
