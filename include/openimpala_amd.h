@@ -191,8 +191,10 @@ oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
  * uses it (a vector that vanishes off the free set, live-line predication) */
 oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, double* ms_per_launch);
 
-/* process-wide tuning of the fused CG kernel: rows per LDS tile (4 or 8) and planes per
- * block (0 = automatic).  Affects launches made after the call. */
+/* Launch shapes and layouts.  The oi_tort_set_* calls below change the process DEFAULTS (under a mutex); a handle
+ * copies the defaults when it is created and is never touched by a later call -- no tuning state is shared between
+ * live handles (oi_tort_retune re-reads the defaults for ONE handle, from the thread that drives it).
+ * Fused CG kernel: rows per LDS tile (8, 16 or 32) and planes per block of every z-marching kernel (0 = automatic). */
 void oi_tort_set_tuning(int fused_tile_rows, int fused_planes_per_block);
 /* rows per LDS tile (8, 16 or 32) of the stand-alone stencil apply */
 void oi_tort_set_apply_tuning(int tile_rows);
@@ -210,6 +212,19 @@ void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second);
 void oi_tort_set_cg1_layout(int compact_lines);
 /* voxels per stored line of the compacted layout (a build constant) */
 int oi_tort_line_voxels(void);
+/* named switches of the process defaults (experiments and cross-checks; none is needed in normal use):
+ *   "tile_map"      0 / 1 / 2   block -> tile order of the z-marching kernels (2 = z sweep, default)
+ *   "zchunk"        planes per block (0 = automatic)      "apply_kernel"  0 = wave-autonomous apply, 1 = LDS-tiled
+ *   "mg_plain" "mg_novec4" "mg_debug"   multigrid cross-check kernels / per-level norms
+ *   "mg_replicate_cells" "mg_wmask" "mg_scale"   multigrid level distribution and cycle shape
+ *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
+ * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
+ * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM seed the same defaults, read ONCE per process.
+ * OI_BAD_ARG for an unknown key. */
+oi_status oi_tort_set_option(const char* key, double value);
+/* copy the current process defaults of the launch shapes into a live handle (layout, multigrid hierarchy and the
+ * capacity of its partial-sum array stay as built) */
+oi_status oi_tort_retune(oi_tort* h);
 
 /* The solver kernels predicate their vector loads/stores on the code byte, so a cache line without a
  * free voxel is never moved.  Fraction of the aligned runs of `group_voxels` voxels along x (this slab)

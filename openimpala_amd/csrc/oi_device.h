@@ -15,6 +15,31 @@
 
 namespace oi {
 
+// Launch shapes of the z-marching kernels.  A handle takes a snapshot of the process defaults when it is created
+// (default_tune(), changed through the oi_tort_set_* entry points under a mutex) and every launcher reads the
+// handle's own copy (Geom::tune): no tuning state is shared between live handles.
+struct Tune {
+  int tile_map = 2;      // block -> tile: 0 every XCD one contiguous range of ALL tiles; 1 identity; 2 every XCD a
+                         // contiguous y band of EVERY z chunk, z chunks in launch order (the chip sweeps the volume in z)
+  int zchunk = 0;        // planes per block of the z-marching kernels, 0 = automatic
+  int fused_rows = 2;    // rows per thread of k_fused_a (tile height 8 x rows)
+  int pure_rows = 4;     // the same for the LDS-tiled stand-alone apply
+  int cg1_rows = 2, cg1_waves = 8, cg1_auto = 1;  // k_cg1 tile: rows per thread, waves per block; auto = by plane size
+  int cg1_xskip = 1;     // k_cg1: x touched every second iteration
+  int cg1_fullline = 1;  // compacted layout: stored lines read and written whole
+  int cg1_compact = 1;   // single-kernel variant: r, q, p stored as compacted live lines
+  int apply_kernel = 0;  // stand-alone apply: 0 = wave-autonomous k_apply7, 1 = LDS-tiled k_fused_a<PURE>
+  int mg_plain = 0, mg_novec4 = 0, mg_debug = 0;  // multigrid cross-check switches (env OI_MG_PLAIN / _NOVEC4 / _DEBUG)
+  long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
+  int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
+  float mg_scale = 0.f;  // > 0: scale of the coarse correction
+  int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
+  int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
+};
+Tune default_tune();                 // snapshot of the process defaults (+ the OI_* environment overrides)
+void set_default_tune(const Tune&);  // new handles only
+void tune_set_cg1_tile(Tune& t, int tile_rows);  // 8 / 16 / 32 rows (33: the 8-wave x 4-row form), <= 0 automatic
+
 struct Geom {
   int nx, ny, nz;      // global voxel counts
   int z0, nzl;         // this slab: global planes [z0, z0+nzl)
@@ -27,6 +52,7 @@ struct Geom {
   long long nwords;    // (nzl+2) * wplane
   double vlo, vhi;
   int periodic;        // 1: x and y wrap by index in the tiled kernels (homogenization cell problem; z wraps through the ghost planes)
+  Tune tune;
 };
 
 // slots of the device-resident CG history: hist[3*k + {0,1,2}] = {p.q, r.r, r.z} of iteration k
@@ -43,8 +69,18 @@ enum KernelId {
   K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_CG1, K_MG, K_COUNT
 };
 
-// maximum number of per-block partial sums any reducing kernel writes
+// grid cap of the flat (non-tiled) reducing kernels; the z-marching kernels are bounded by Tune::max_blocks
 constexpr int kMaxPartials = 4096;
+// shortest z chunk the automatic choice makes, and the grid bound that follows for a slab: 128 x 8 voxel tile
+// columns x chunks of kMinZChunk planes.  A handle sizes its partial-sum array for it (8 doubles per block;
+// 1024^3: 131072 blocks = 8 MB), so no launch shape can write past the array.
+constexpr int kMinZChunk = 8;
+inline int partial_blocks_bound(int pitch, int ny, int nzl) {
+  long long b = (long long)((pitch + 127) / 128) * ((ny + 7) / 8) * ((nzl + kMinZChunk - 1) / kMinZChunk);
+  if (b < kMaxPartials) b = kMaxPartials;
+  if (b > (1ll << 22)) b = 1ll << 22;
+  return (int)b;
+}
 // compacted line layout: voxels per stored line (aligned along x).  8 fp64 = one 64-byte HBM burst; stored lines are
 // contiguous, so finer lines do not mean partial cache-line accesses.  Measured on 1024^3 (profiles/r01/ab_linevox.txt):
 // 16 -> 8 voxels stores 15 % fewer lines (spheres; 32 % at porosity 0.2) and runs 3-7 % faster; 4 gains nothing more.
@@ -123,8 +159,6 @@ struct MgCoarse {
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
                    double* out, float* bcoarse, double* partials, const Ctrl* ctrl, const int* lineoff /* b, out compacted */,
                    hipStream_t s);
-void set_fused_tuning(int tile_rows, int zchunk);
-void set_apply_tuning(int tile_rows);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
@@ -133,10 +167,6 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);
-void set_cg1_tuning(int tile_rows);  // <= 0: automatic
-void set_cg1_xskip(int on);
-void set_cg1_fullline(int on);  // compacted layout: whole-line reads and writes (default on)
-int cg1_xskip();
 void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, const int* lineoff,
                      hipStream_t s);
 constexpr int kRec1Alpha = 5;

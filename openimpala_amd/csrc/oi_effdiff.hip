@@ -267,6 +267,8 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   g.nwords = 0;
   g.vlo = 0; g.vhi = 0;
   g.periodic = 1;  // the tiled kernels wrap x and y by index
+  g.tune = oi::default_tune();  // this handle's launch shapes: a snapshot of the process defaults
+  g.tune.max_blocks = oi::partial_blocks_bound(g.pitch, ny, nzl);
   // the reference's default budget is 1000 multigrid-preconditioned iterations (:120); CG on this
   // well-conditioned system needs ~100, so the same default is generous
   h->maxiter = o.maxiter > 0 ? o.maxiter : 1000 + 4 * (nx + ny + nz);
@@ -277,7 +279,7 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   HIPC(hipMalloc((void**)&h->r, sizeof(double) * g.nvec));
   HIPC(hipMalloc((void**)&h->p, sizeof(double) * g.nvec));
   HIPC(hipMalloc((void**)&h->q, sizeof(double) * g.nvec));
-  HIPC(hipMalloc((void**)&h->partials, sizeof(double) * 9 * kMaxPartials));
+  HIPC(hipMalloc((void**)&h->partials, sizeof(double) * 9 * g.tune.max_blocks));
   HIPC(hipMalloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
   HIPC(hipMalloc((void**)&h->scal, sizeof(double) * 16));
   HIPC(hipMalloc((void**)&h->ctrl, sizeof(Ctrl)));
@@ -311,7 +313,7 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
     if (!h->mg) return OI_HIP_ERROR;
     // even extents: pairs and aggregates never straddle the periodic seam, the LDS-tiled kernels of the flow-through
     // path wrap x / y by index -> their fused two-kernel iteration (needs a second p buffer)
-    h->fused = ((nx | ny | nz) & 1) == 0 && !getenv("OI_MG_PLAIN");
+    h->fused = ((nx | ny | nz) & 1) == 0 && !g.tune.mg_plain;
     if (h->fused) {
       HIPC(hipMalloc((void**)&h->p2, sizeof(double) * g.nvec));
       HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * g.nvec, s));
@@ -398,7 +400,7 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
         }
         if (h->mg) {  // z = M^-1 r, r.z into hist[k], p = z + beta p
           OIC(wrap_z(h, h->r, sizeof(double) * g.plane));
-          const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, getenv("OI_MG_PLAIN") ? 0 : 1, nullptr, s);
+          const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, g.tune.mg_plain ? 0 : 1, nullptr, s);
           if (nbz < 0) return OI_RCCL_ERROR;
           OIC(reduce_to(h, nbz, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
           if (k > 0) launch_update_p(g, h->code, h->z, h->p, 0, h->hist, k, h->ctrl, s);

@@ -13,6 +13,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
+#include <mutex>
 
 namespace oi {
 
@@ -47,6 +49,49 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 
 __device__ __forceinline__ bool bit_at(const uint64_t* bits, const Geom& g, int gz, int j, int i) {
   return (bits[(long long)gz * g.wplane + (long long)j * g.W + (i >> 6)] >> (i & 63)) & 1ULL;
+}
+
+// Block -> logical tile (x fastest, then y, then z chunk) of the z-marching kernels.  HIP deals blocks b, b + 8, ... to
+// one XCD (one L2).  map 2 (default): inside EVERY z chunk each XCD owns a contiguous band of tile rows, and chunks
+// follow launch order, so the whole chip sweeps the volume in z like one linear stream -- the planes in flight are a
+// few hundred MB that stay within DRAM-page / TLB reach and the chunk-boundary planes are re-read while still cached
+// (1024^3 stand-alone apply: 3.00 ms against 3.40 ms with map 0, profiles/r02/apply_proto_*.txt).  map 0: every XCD
+// one contiguous range of ALL tiles (eight distant regions at once); map 1: identity.
+__device__ __forceinline__ int tile_of_block(int b, int tiles_xy, int nzc, int map) {
+  if (map == 2 && (tiles_xy & 7) == 0) {
+    const int per = tiles_xy >> 3, idx = b >> 3;
+    return (idx / per) * tiles_xy + (b & 7) * per + idx % per;
+  }
+  const int ntiles = tiles_xy * nzc;
+  if (map == 0 && (ntiles & 7) == 0) return (b & 7) * (ntiles >> 3) + (b >> 3);
+  return b;
+}
+
+// process defaults of the launch shapes; handles copy them at creation (see oi_device.h)
+static std::mutex g_tune_mutex;
+static Tune g_tune_defaults;
+static bool g_tune_env_read = false;
+Tune default_tune() {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  if (!g_tune_env_read) {  // environment overrides, read ONCE per process (experiments and cross-checks)
+    g_tune_env_read = true;
+    if (const char* e = getenv("OI_TILE_MAP")) g_tune_defaults.tile_map = atoi(e);
+    if (const char* e = getenv("OI_ZCHUNK")) g_tune_defaults.zchunk = atoi(e);
+    if (const char* e = getenv("OI_APPLY_KERNEL")) g_tune_defaults.apply_kernel = atoi(e);
+    if (getenv("OI_MG_PLAIN")) g_tune_defaults.mg_plain = 1;
+    if (getenv("OI_MG_NOVEC4")) g_tune_defaults.mg_novec4 = 1;
+    if (getenv("OI_MG_DEBUG")) g_tune_defaults.mg_debug = 1;
+    if (const char* e = getenv("OI_MG_REPLICATE_CELLS")) g_tune_defaults.mg_replicate_cells = atoll(e);
+    if (const char* e = getenv("OI_MG_WMASK")) g_tune_defaults.mg_wmask = atoi(e);
+    if (const char* e = getenv("OI_MG_SCALE")) g_tune_defaults.mg_scale = (float)atof(e);
+    if (getenv("OI_FORCE_COMM")) g_tune_defaults.force_comm = 1;
+  }
+  return g_tune_defaults;
+}
+void set_default_tune(const Tune& t) {
+  (void)default_tune();  // (environment first, so that an explicit call wins)
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  g_tune_defaults = t;
 }
 
 static inline int cap_blocks(long long work_items, int per_block, int cap) {
@@ -765,11 +810,8 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
   __shared__ double red[kNW];
   // lineoff != null (CG form only): r (z), p_in, p_out and q live in the compacted line layout of k_cg1; x is dense
 
-  // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2), so
-  // give every XCD one contiguous range of logical tiles (x fastest, then y, then z chunk).
-  const int ntiles = tiles_x * tiles_y * nzc;
-  int L = blockIdx.x;
-  if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  // XCD-aware block -> tile map: see tile_of_block
+  const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nzc, g.tune.tile_map);
   const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
 
   static_assert(LEAN == 0 || PURE, "the lean passes are forms of the stand-alone apply");
@@ -1016,23 +1058,13 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
 
 // Defaults from the 1024^3 sweep in profiles/r01/tile_sweep.txt: 16-row tiles for the CG
 // kernel (32 rows need 190 VGPRs -> one block per CU), 32-row tiles for the stand-alone apply.
-static int g_fused_rows = 2;     // R: rows per thread (tile height 8 R)
-static int g_pure_rows = 4;
-static int g_fused_zchunk = 0;   // planes per block, 0 = auto
-
-void set_fused_tuning(int tile_rows, int zchunk) {
-  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_fused_rows = tile_rows / 8;
-  g_fused_zchunk = zchunk > 0 ? zchunk : 0;
-}
-void set_apply_tuning(int tile_rows) {
-  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) g_pure_rows = tile_rows / 8;
-}
+// (tile shapes and chunk lengths are per-handle state: Geom::tune)
 
 // Planes per block of the z-marching kernels.  Large volumes: >= ~4096 blocks, but chunks of >= 64 planes so the
 // two redundant halo planes per chunk stay near 3 %.  Small volumes (the reference's 100^3 sample gives 7 tile
 // columns) would leave most of the 256 CUs idle behind a few long marches: there the chunks shrink, down to 8
 // planes, until ~1024 blocks exist -- the march is latency-bound, so halo planes are cheap next to idle CUs.
-static int pick_zchunk(const Geom& g, long long cols) {
+static int auto_zchunk(const Geom& g, long long cols) {
   long long want = (4096 + cols - 1) / cols;
   if (want < 1) want = 1;
   long long zc = (g.nzl + want - 1) / want;
@@ -1048,6 +1080,32 @@ static int pick_zchunk(const Geom& g, long long cols) {
     }
   }
   return (int)zc;
+}
+
+// planes per block and number of z chunks of a z-marching launch over `cols` tile columns: the handle's fixed choice
+// (Tune::zchunk) or the automatic one, kept within the handle's partial-sum capacity (Tune::max_blocks)
+static void pick_chunks(const Geom& g, long long cols, bool even, int* zchunk_out, int* nzc_out) {
+  int zchunk = g.tune.zchunk > 0 ? g.tune.zchunk : auto_zchunk(g, cols);
+  if (zchunk > g.nzl) zchunk = g.nzl;
+  if (zchunk < 1) zchunk = 1;
+  long long nzc = (g.nzl + zchunk - 1) / zchunk;
+  const long long cap = g.tune.max_blocks > 0 ? g.tune.max_blocks : kMaxPartials;
+  if (cols * nzc > cap) {  // the partial-sum array bounds the grid
+    const long long maxc = cap / cols > 0 ? cap / cols : 1;
+    zchunk = (int)((g.nzl + maxc - 1) / maxc);
+    nzc = (g.nzl + zchunk - 1) / zchunk;
+  }
+  if (even && (zchunk & 1) && zchunk < g.nzl) {  // chunks must hold whole z pairs
+    ++zchunk;
+    nzc = (g.nzl + zchunk - 1) / zchunk;
+  }
+  *zchunk_out = zchunk;
+  *nzc_out = (int)nzc;
+}
+// a launch whose tile columns alone exceed the partial-sum capacity cannot run (create sizes the array by
+// partial_blocks_bound, so this only guards against a handle driven with a foreign geometry)
+static bool grid_fits(const Geom& g, long long cols, int nzc) {
+  return cols * nzc <= (g.tune.max_blocks > 0 ? g.tune.max_blocks : kMaxPartials);
 }
 
 template <int R, bool PURE, typename PT, int LEAN>
@@ -1070,20 +1128,12 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
                         hipStream_t s, const int* lineoff = nullptr) {
   // the predicated PURE forms (capacity-mode passes, apply on a CG vector) run best on 16-row tiles (R = 2: 99 VGPRs,
   // 4 waves/SIMD; 10.1 vs 13.5 ms per lean iteration at 1024^3), the unpredicated stand-alone apply on 32-row tiles
-  const int R = PURE ? (LEAN != 0 && g_pure_rows > 2 ? 2 : g_pure_rows) : g_fused_rows, by = kNW * R;
+  const int R = PURE ? (LEAN != 0 && g.tune.pure_rows > 2 ? 2 : g.tune.pure_rows) : g.tune.fused_rows, by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
-  int zchunk = g_fused_zchunk;
-  if (zchunk <= 0) {
-    zchunk = pick_zchunk(g, cols);
-  }
-  if (zchunk > g.nzl) zchunk = g.nzl;
-  int nzc = (g.nzl + zchunk - 1) / zchunk;
-  if (cols * nzc > kMaxPartials) {  // the partial-sum array bounds the grid
-    const int maxc = (int)(kMaxPartials / cols) > 0 ? (int)(kMaxPartials / cols) : 1;
-    zchunk = (g.nzl + maxc - 1) / maxc;
-    nzc = (g.nzl + zchunk - 1) / zchunk;
-  }
+  int zchunk, nzc;
+  pick_chunks(g, cols, false, &zchunk, &nzc);
+  if (!grid_fits(g, cols, nzc)) return -1;
   const int blocks = (int)(cols * nzc);
   if (R == 4)
     launch_tiled_r<4, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
@@ -1094,6 +1144,167 @@ static int launch_tiled(const Geom& g, const uint8_t* code, double* x, const dou
   else
     launch_tiled_r<1, PURE, PT, LEAN>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y,
                                       nzc, partials, ctrl, lineoff, s);
+  return blocks;
+}
+
+// --------------------------------------------------------------------------------------
+// Stand-alone masked 7-point apply q = A v, partial v.q -- the kernel the "fraction of the HBM roofline" target of the
+// north star names (17 B/voxel: v 8 + code 1 + q 8).  Barrier-free and LDS-free: one WAVE owns 128 (x) x RY (y)
+// voxels and marches over a short z chunk.
+//   * x neighbours: DPP wave shifts (wave_shr:1 / wave_shl:1) of the lane's own voxel pair; the two values a row needs
+//     from the neighbouring tiles are fetched by 2 RY lanes with ONE 8-byte load instruction per plane and handed to
+//     lanes 0 / 63 as the shift's fill value (v_readlane);
+//   * y neighbours: the wave's own rows plus one halo row above and below (served by L2: the neighbouring wave reads
+//     them as its centre rows at about the same time);
+//   * z neighbours: a register ring of D + 2 planes, D planes loaded ahead of the one computed;
+//   * addresses: one 32-bit lane offset against wave-uniform (scalar) row bases (global_load ... v_off, s[base:base+1]),
+//     so a plane costs a handful of scalar adds and no 64-bit vector arithmetic;
+//   * q leaves with nontemporal stores (read once by the next kernel; keeps v's halo rows in L2).
+// Launch order is the point (tile_of_block, map 2; z chunks of 8 planes): the whole chip sweeps through z like a linear
+// stream.  1024^3 on one MI355X: 3.00 ms = 6.1 TB/s = 0.76 of the 8 TB/s peak, at the best linear float4 copy of the
+// same box (3.02 ms for 16 B/voxel); the LDS-tiled k_fused_a<PURE> with 64-plane chunks and map 0: 3.6-3.7 ms
+// (profiles/r02/apply_proto_*.txt).  Summation order is the oracle's, results are bit-identical to k_apply / k_fused_a.
+// --------------------------------------------------------------------------------------
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// shr1: lane l gets the value of lane l - 1, lane 0 gets `fill`;  shl1: lane l gets lane l + 1, lane 63 gets `fill`
+__device__ __forceinline__ double dpp_shr1(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_shl1(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int RY>
+struct ApplyPlane {
+  v2d_t c[RY + 2];        // rows j0 - 1 .. j0 + RY of this lane's voxel pair
+  double xh;              // lanes < 2 RY: x halo of row (lane >> 1), side (lane & 1)
+  unsigned short cc[RY];  // code bytes of the centre rows
+};
+
+template <int RY, int NW, int D>
+__global__ void __launch_bounds__(64 * NW) k_apply7(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ v,
+                                                    double* __restrict__ q, double* __restrict__ partials,
+                                                    const Ctrl* __restrict__ ctrl, int zchunk, int tiles_x, int tiles_y,
+                                                    int nzc) {
+  constexpr int RING = D + 2;
+  if (ctrl && ctrl->done) return;
+  __shared__ double red[NW];
+  const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nzc, g.tune.tile_map);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i0 = tx * kBX, j0 = (ty * NW + w) * RY;
+  const bool in_x = i0 + 2 * lane < g.pitch;
+  const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);  // output planes [gs, ge)
+
+  const int hrow = j0 + (lane >> 1);
+  const int hi_ = (lane & 1) ? i0 + kBX : i0 - 1;
+  const bool hvalid = lane < 2 * RY && hrow < g.ny && hi_ >= 0 && hi_ < g.pitch;  // (columns >= nx hold zeros)
+
+  const unsigned lane_b16 = 16u * lane, lane_b2 = 2u * lane;
+  const long long urow = (long long)j0 * g.pitch + i0;  // wave-uniform: first voxel of the wave's row j0
+  const unsigned hoff_b = hvalid ? (unsigned)(((lane >> 1) * g.pitch + (hi_ - i0 + 1)) * 8) : 0u;  // from (row j0, i0 - 1)
+
+  ApplyPlane<RY> P[RING];
+  // with_halo = false: a plane that only serves as z neighbour (centre rows, no halo, no codes)
+  auto load_plane = [&](ApplyPlane<RY>& p, int gz, bool with_halo) {
+    const char* vp = reinterpret_cast<const char*>(v + (long long)gz * g.plane + urow);
+#pragma unroll
+    for (int r = 0; r < RY + 2; ++r) {
+      const int j = j0 + r - 1;
+      const bool edge = (r == 0 || r == RY + 1);
+      v2d_t val = {0.0, 0.0};
+      if ((!edge || with_halo) && j >= 0 && j < g.ny && in_x)
+        val = *reinterpret_cast<const v2d_t*>(vp + (long long)(r - 1) * g.pitch * 8 + lane_b16);
+      p.c[r] = val;
+    }
+    double h = 0.0;
+    if (with_halo && hvalid) h = *reinterpret_cast<const double*>(vp - 8 + hoff_b);
+    p.xh = h;
+    if (with_halo) {
+      const char* cp = reinterpret_cast<const char*>(code + (long long)gz * g.plane + urow);
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        unsigned short c = 0;
+        if (j0 + r < g.ny && in_x) c = *reinterpret_cast<const unsigned short*>(cp + (long long)r * g.pitch + lane_b2);
+        p.cc[r] = c;
+      }
+    }
+  };
+
+  double pq = 0.0;
+  auto compute = [&](int gz, const ApplyPlane<RY>& pv, const ApplyPlane<RY>& cu, const ApplyPlane<RY>& nx) {
+    char* qp = reinterpret_cast<char*>(q + (long long)gz * g.plane + urow);
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const v2d_t pc = cu.c[r + 1], ym = cu.c[r], yp = cu.c[r + 2];
+      const double lf = dpp_shr1(pc.y, lane_bcast(cu.xh, 2 * r)), rt = dpp_shl1(pc.x, lane_bcast(cu.xh, 2 * r + 1));
+      const unsigned c0 = cu.cc[r] & 0xffu, c1 = cu.cc[r] >> 8;
+      const double s0 = ((((lf + pc.y) + ym.x) + yp.x) + pv.c[r + 1].x) + nx.c[r + 1].x;
+      const double s1 = ((((pc.x + rt) + ym.y) + yp.y) + pv.c[r + 1].y) + nx.c[r + 1].y;
+      const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
+      const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
+      if (j0 + r < g.ny && in_x) {
+        const v2d_t o = {q0, q1};
+        __builtin_nontemporal_store(o, reinterpret_cast<v2d_t*>(qp + (long long)r * g.pitch * 8 + lane_b16));
+      }
+      pq += pc.x * q0;
+      pq += pc.y * q1;
+    }
+  };
+
+  load_plane(P[0], gs - 1, false);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (gs + d <= ge) load_plane(P[1 + d], gs + d, gs + d < ge);
+  for (int gz0 = gs; gz0 < ge; gz0 += RING) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      const int gz = gz0 + u;
+      if (gz < ge) {
+        const int ahead = gz + D;
+        if (ahead <= ge) load_plane(P[(u + 1 + D) % RING], ahead, ahead < ge);
+        compute(gz, P[u % RING], P[(u + 1) % RING], P[(u + 2) % RING]);
+      }
+    }
+  }
+  pq = wave_sum(pq);
+  if (lane == 0) red[w] = pq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < NW; ++k) t += red[k];
+    partials[blockIdx.x] = t;
+  }
+}
+
+static int launch_apply7(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials, const Ctrl* ctrl,
+                         hipStream_t s) {
+  constexpr int RY = 4;
+  const bool tall = g.ny > 16 * 8;  // 8-wave blocks (32 rows) on tall planes, 4-wave blocks otherwise
+  const int by = RY * (tall ? 8 : 4);
+  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)tiles_x * tiles_y;
+  Geom gt = g;
+  if (gt.tune.zchunk <= 0) gt.tune.zchunk = kMinZChunk;  // short chunks: the launch order makes the march a z sweep
+  int zchunk, nzc;
+  pick_chunks(gt, cols, false, &zchunk, &nzc);
+  if (!grid_fits(g, cols, nzc)) return -1;
+  const int blocks = (int)(cols * nzc);
+  if (tall)
+    hipLaunchKernelGGL((k_apply7<RY, 8, 2>), dim3(blocks), dim3(512), 0, s, g, code, v, q, partials, ctrl, zchunk, tiles_x, tiles_y, nzc);
+  else
+    hipLaunchKernelGGL((k_apply7<RY, 4, 2>), dim3(blocks), dim3(256), 0, s, g, code, v, q, partials, ctrl, zchunk, tiles_x, tiles_y, nzc);
   return blocks;
 }
 
@@ -1121,6 +1332,7 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
 
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s) {
+  if (g.tune.apply_kernel == 0 && !g.periodic) return launch_apply7(g, code, v, q, partials, ctrl, s);
   return launch_tiled<true, double>(g, code, nullptr, v, nullptr, nullptr, q, 0, nullptr, 0, partials, ctrl, s);
 }
 
@@ -1156,9 +1368,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
   __shared__ double wtab[8];  // omega / c for the neighbour counts c = 1..6 (0 for c = 0): one LDS read replaces a division
   if (threadIdx.x < 8) wtab[threadIdx.x] = threadIdx.x ? omega / (double)threadIdx.x : 0.0;
   __syncthreads();
-  const int ntiles = tiles_x * tiles_y * nzc;
-  int L = blockIdx.x;
-  if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nzc, g.tune.tile_map);
   const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = tx * kBX + 2 * lane, j0 = ty * BY;
@@ -1384,18 +1594,9 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
   const int by = kNW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
-  int zchunk = pick_zchunk(g, cols);
-  if (zchunk > g.nzl) zchunk = g.nzl;
-  int nzc = (g.nzl + zchunk - 1) / zchunk;
-  if (cols * nzc > kMaxPartials) {
-    const int maxc = (int)(kMaxPartials / cols) > 0 ? (int)(kMaxPartials / cols) : 1;
-    zchunk = (g.nzl + maxc - 1) / maxc;
-    nzc = (g.nzl + zchunk - 1) / zchunk;
-  }
-  if (mode == 3 && (zchunk & 1) && zchunk < g.nzl) {  // chunks must hold whole z pairs
-    ++zchunk;
-    nzc = (g.nzl + zchunk - 1) / zchunk;
-  }
+  int zchunk, nzc;
+  pick_chunks(g, cols, mode == 3, &zchunk, &nzc);
+  if (!grid_fits(g, cols, nzc)) return -1;
   const int blocks = (int)(cols * nzc);
 #define OI_MGF(M, C)                                                                                                     \
   hipLaunchKernelGGL((k_mg_fine<R, M, C>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, b, c, omega, scale, out, bcoarse, \
@@ -1451,9 +1652,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   // part 0: every z chunk; 1: only the first and last chunk of the slab (they produce the
   // planes the neighbours wait for); 2: the interior chunks (run while the planes travel)
   const int nsel = part == 0 ? nzc : (part == 1 ? min(2, nzc) : nzc - 2);
-  const int ntiles = tiles_x * tiles_y * nsel;
-  int L = blockIdx.x;
-  if ((ntiles & 7) == 0) L = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nsel, g.tune.tile_map);
   const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zsel = L / (tiles_x * tiles_y);
   const int zc = part == 0 ? zsel : (part == 1 ? (zsel == 0 ? 0 : nzc - 1) : zsel + 1);
 
@@ -1660,22 +1859,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   }
 }
 
-static int g_cg1_rows = 2;   // rows per thread
-static int g_cg1_waves = 8;  // waves per block: tile height = waves * rows
-static bool g_cg1_auto = true;
-static int g_cg1_xskip = 1;
-static int g_cg1_fullline = 1;  // compacted layout: read and write stored lines whole
-void set_cg1_fullline(int on) { g_cg1_fullline = on ? 1 : 0; }
-int cg1_xskip() { return g_cg1_xskip; }
-void set_cg1_xskip(int on) { g_cg1_xskip = on ? 1 : 0; }
-void set_cg1_tuning(int tile_rows) {
-  g_cg1_auto = tile_rows <= 0;
-  // 8, 16: 8-wave blocks with 1 or 2 rows per thread; 32: 16-wave blocks x 2 rows (the
-  // 8-wave x 4-row form needs 194 VGPRs and fits only one block per CU); 33 selects it
-  if (tile_rows == 8) { g_cg1_rows = 1; g_cg1_waves = 8; }
-  else if (tile_rows == 16) { g_cg1_rows = 2; g_cg1_waves = 8; }
-  else if (tile_rows == 32) { g_cg1_rows = 2; g_cg1_waves = 16; }
-  else if (tile_rows == 33) { g_cg1_rows = 4; g_cg1_waves = 8; }
+// k_cg1 tile shapes (Tune::cg1_rows x cg1_waves): 8 rows = 8 waves x 1 row per thread, 16 = 8 x 2, 32 = 16 waves x 2
+// rows (the 8-wave x 4-row form needs 194 VGPRs and fits only one block per CU; tile_rows 33 selects it)
+void tune_set_cg1_tile(Tune& t, int tile_rows) {
+  t.cg1_auto = tile_rows <= 0;
+  if (tile_rows == 8) { t.cg1_rows = 1; t.cg1_waves = 8; }
+  else if (tile_rows == 16) { t.cg1_rows = 2; t.cg1_waves = 8; }
+  else if (tile_rows == 32) { t.cg1_rows = 2; t.cg1_waves = 16; }
+  else if (tile_rows == 33) { t.cg1_rows = 4; t.cg1_waves = 8; }
 }
 
 template <int R, int NW, typename PT, bool JAC, bool COMPACT>
@@ -1684,8 +1875,8 @@ static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double*
                          int zchunk, int tiles_x, int tiles_y, int nzc, int part, int partial_base, double* partials,
                          const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
   hipLaunchKernelGGL((k_cg1<R, NW, PT, JAC, COMPACT>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
-                     q_out, (const PT*)p_in, (PT*)p_out, rec, k, g_cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
-                     partial_base, partials, ctrl, lineoff, (g.pitch + kLV - 1) / kLV, g_cg1_fullline);
+                     q_out, (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
+                     partial_base, partials, ctrl, lineoff, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
 }
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
@@ -1710,29 +1901,22 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
                hipStream_t s) {
   // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
   // off on large planes; locals only, handles may be driven from several host threads
-  const int R = g_cg1_auto ? 2 : g_cg1_rows;
-  const int NW = g_cg1_auto ? ((g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g_cg1_waves;
+  const int R = g.tune.cg1_auto ? 2 : g.tune.cg1_rows;
+  const int NW = g.tune.cg1_auto ? ((g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g.tune.cg1_waves;
   const int by = NW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
-  const int max_blocks = kMaxPartials;  // five partial sums per block, partials holds 8 per block
-  int zchunk;
-  if (g_fused_zchunk > 0) {
-    zchunk = g_fused_zchunk;
-  } else if (split) {
-    zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
-    if (zchunk > 64) zchunk = 64;
-    if (zchunk < 16) zchunk = 16;
+  int zchunk, nzc;
+  if (split && g.tune.zchunk <= 0) {
+    Geom gs_ = g;
+    gs_.tune.zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
+    if (gs_.tune.zchunk > 64) gs_.tune.zchunk = 64;
+    if (gs_.tune.zchunk < 16) gs_.tune.zchunk = 16;
+    pick_chunks(gs_, cols, false, &zchunk, &nzc);
   } else {
-    zchunk = pick_zchunk(g, cols);
+    pick_chunks(g, cols, false, &zchunk, &nzc);
   }
-  if (zchunk > g.nzl) zchunk = g.nzl;
-  int nzc = (g.nzl + zchunk - 1) / zchunk;
-  if (cols * nzc > max_blocks) {
-    const int maxc = (int)(max_blocks / cols) > 0 ? (int)(max_blocks / cols) : 1;
-    zchunk = (g.nzl + maxc - 1) / maxc;
-    nzc = (g.nzl + zchunk - 1) / zchunk;
-  }
+  if (!grid_fits(g, cols, nzc)) return -1;
   const int nsel = part == 0 ? nzc : (part == 1 ? (nzc < 2 ? nzc : 2) : nzc - 2);
   if (nsel <= 0) return 0;
   const int blocks = (int)(cols * nsel);

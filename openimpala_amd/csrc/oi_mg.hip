@@ -565,20 +565,12 @@ struct MgHierarchy {
   size_t bytes = 0;
   unsigned wmask = kWCycleMask;
   float scale = kScale;
-  // the cycle is a fixed sequence of ~250 mostly tiny launches: with OI_MG_GRAPH=1 (one GPU only) it is captured
-  // once into a hipGraph and replayed every iteration.  OFF by default: measured no gain on ROCm 7.2 (100^3:
-  // 35.5 vs 34.7 ms per solve, 1024^3: 16.4 vs 16.3 ms per cycle) and rocprofv3 --kernel-trace crashes on the replay.
-  bool use_graph = false;
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_nb = 0;
-  const void* graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int graph_tiled = -1;
+  bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
   bool failed = false;
 };
 
 void mg_destroy(MgHierarchy* mg) {
   if (!mg) return;
-  if (mg->graph_exec) (void)hipGraphExecDestroy(mg->graph_exec);
   for (auto& L : mg->levels) {
     void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.b2, L.r, L.x2, L.xs};
     for (void* q : p)
@@ -661,10 +653,10 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   int pnx = g.nx, pny = g.ny, pnz = g.nz, pz0 = g.z0, pnzl = g.nzl;
   bool prep = false;  // parent replicated?
   long long replicate_cells = kReplicateCells;
-  if (const char* e = getenv("OI_MG_REPLICATE_CELLS")) replicate_cells = atoll(e);  // tests: distribute small levels too
-  if (const char* e = getenv("OI_MG_WMASK")) mg->wmask = (unsigned)atoi(e);            // experiments with the cycle shape
-  if (const char* e = getenv("OI_MG_SCALE")) mg->scale = (float)atof(e);
-  if (const char* e = getenv("OI_MG_GRAPH")) mg->use_graph = atoi(e) != 0;
+  if (g.tune.mg_replicate_cells > 0) replicate_cells = g.tune.mg_replicate_cells;  // tests: distribute small levels too
+  if (g.tune.mg_wmask >= 0) mg->wmask = (unsigned)g.tune.mg_wmask;                   // experiments with the cycle shape
+  if (g.tune.mg_scale > 0.f) mg->scale = g.tune.mg_scale;
+  mg->novec4 = g.tune.mg_novec4 != 0;
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
     L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
@@ -780,7 +772,7 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   }
   MgLevelHost& C = Ls[l + 1];
   // byte / 16-bit levels whose rows split into groups of four cells take the four-cells-per-thread kernels
-  const bool vec4 = L.compact && (L.d.nx & 3) == 0 && L.d.nx >= 64 && !getenv("OI_MG_NOVEC4");
+  const bool vec4 = L.compact && (L.d.nx & 3) == 0 && L.d.nx >= 64 && !mg->novec4;
   const int blocks4 = (int)((((long long)(L.d.nx >> 2) * L.d.ny * L.d.nzl) + 255) / 256);
   if (vec4 && blocks4 > 0)
     hipLaunchKernelGGL((k_mg_pre4<uint8_t, uint16_t>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), kfirst, L.d.nzl, rhs, L.r);
@@ -840,42 +832,11 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   return launch_dot(g, r, z, partials, s);
 }
 
+// (A hipGraph replay of the cycle's ~250 launches was measured in round 1: no gain on ROCm 7.2 -- back-to-back dependent
+// launches already run at the dispatch latency -- and it did not survive rocprofv3 --kernel-trace; removed.)
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
               double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s) {
-  if (mg->comm || !mg->use_graph || lineoff) return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, lineoff, s);
-  const void* key[6] = {code, r, scratch, z, partials, ctrl};
-  bool same = mg->graph_exec != nullptr && mg->graph_tiled == tiled;
-  for (int i = 0; same && i < 6; ++i) same = key[i] == mg->graph_key[i];
-  if (!same) {
-    if (mg->graph_exec) { (void)hipGraphExecDestroy(mg->graph_exec); mg->graph_exec = nullptr; }
-    hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      mg->use_graph = false;
-      (void)hipGetLastError();
-      return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
-    }
-    const int nb = mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
-    hipError_t e = hipStreamEndCapture(s, &graph);
-    if (e == hipSuccess && nb >= 0) e = hipGraphInstantiate(&mg->graph_exec, graph, nullptr, nullptr, 0);
-    if (graph) (void)hipGraphDestroy(graph);
-    if (e != hipSuccess || nb < 0 || !mg->graph_exec) {  // no graph on this runtime: plain launches from now on
-      if (getenv("OI_MG_DEBUG")) fprintf(stderr, "[openimpala_amd] hipGraph capture of the cycle failed (%s): plain launches\n", hipGetErrorString(e));
-      mg->graph_exec = nullptr;
-      mg->use_graph = false;
-      (void)hipGetLastError();
-      return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
-    }
-    if (getenv("OI_MG_DEBUG")) fprintf(stderr, "[openimpala_amd] multigrid cycle captured into a hipGraph (%d partials)\n", nb);
-    mg->graph_nb = nb;
-    mg->graph_tiled = tiled;
-    for (int i = 0; i < 6; ++i) mg->graph_key[i] = key[i];
-  }
-  if (hipGraphLaunch(mg->graph_exec, s) != hipSuccess) {
-    (void)hipGetLastError();
-    mg->use_graph = false;
-    return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, nullptr, s);
-  }
-  return mg->graph_nb;
+  return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, lineoff, s);
 }
 
 int mg_levels(const MgHierarchy* mg) { return mg ? (int)mg->levels.size() + 1 : 0; }

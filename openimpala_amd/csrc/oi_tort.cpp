@@ -257,13 +257,16 @@ static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_
                              le * (pf[g.nzl + 2] - pf[g.nzl + 1]), s);
 }
 
-static int g_cg1_compact = 1;  // single-kernel variant: store only the lines that hold a free voxel
 extern "C" int oi_tort_line_voxels(void) { return oi::kLV; }
+// Process DEFAULTS of the launch shapes and layouts: a handle copies them when it is created (oi::Tune in its
+// Geom) and is not touched by later calls; oi_tort_retune re-reads them for one handle.
 extern "C" void oi_tort_set_cg1_layout(int compact_lines) {
   // bit 0: compacted lines (single-kernel iteration and the multigrid-preconditioned two-kernel iteration);
   // bit 1 set: pair-granular (partial-line) accesses inside stored lines (A/B switch)
-  g_cg1_compact = (compact_lines & 1) ? 1 : 0;
-  oi::set_cg1_fullline((compact_lines & 2) ? 0 : 1);
+  oi::Tune t = oi::default_tune();
+  t.cg1_compact = (compact_lines & 1) ? 1 : 0;
+  t.cg1_fullline = (compact_lines & 2) ? 0 : 1;
+  oi::set_default_tune(t);
 }
 
 // ---- construction ----------------------------------------------------------------------
@@ -284,7 +287,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->counters, 8));
   OIC(dmalloc(h, &h->changed, 1));
   OIC(dmalloc(h, &h->scal, 8));
-  OIC(dmalloc(h, &h->partials, (size_t)8 * kMaxPartials));
+  OIC(dmalloc(h, &h->partials, (size_t)8 * g.tune.max_blocks));
   OIC(dmalloc(h, &h->ctrl, 1));
   HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
   HIPC(hipHostMalloc((void**)&h->h_counters, 8 * sizeof(unsigned long long)));
@@ -376,11 +379,11 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->x, (size_t)g.nvec));
   h->nvec_cg = g.nvec;
   const bool want_mg = h->opts.precond == OI_PRECOND_MG;
-  h->mg_tiled = getenv("OI_MG_PLAIN") ? 0 : 1;
+  h->mg_tiled = g.tune.mg_plain ? 0 : 1;
   // the multigrid-preconditioned two-kernel iteration takes the compacted layout when its fine-level
   // kernels are the tiled ones with the restriction fused in (even first plane, see mg_vcycle)
   const bool mg_compact = want_mg && h->fused && h->mg_tiled && (g.z0 & 1) == 0;
-  if ((h->cg1 || (want_mg && h->fused)) && g_cg1_compact) {
+  if ((h->cg1 || (want_mg && h->fused)) && g.tune.cg1_compact) {
     // r, q, p (and z): only the kLV-voxel lines that hold a free voxel
     const long long nlines = (long long)(g.nzl + 2) * g.ny * ((g.pitch + oi::kLV - 1) / oi::kLV);
     // neighbours exchange ghost planes as line lists: every slab takes the same layout
@@ -451,7 +454,8 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->opts = o;
   // a one-rank communicator is dropped unless OI_FORCE_COMM is set (single-GPU rehearsal of
   // the collective code path)
-  h->comm = (comm && (comm->size > 1 || getenv("OI_FORCE_COMM"))) ? comm : nullptr;
+  const oi::Tune tune0 = oi::default_tune();
+  h->comm = (comm && (comm->size > 1 || tune0.force_comm)) ? comm : nullptr;
   h->device = device;
   h->phase_id = phase_id;
   h->jacobi = o.precond == OI_PRECOND_JACOBI;
@@ -490,6 +494,8 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   g.nvec = (long long)(nzl + 2) * g.plane;
   g.nwords = (long long)(nzl + 2) * g.wplane;
   g.vlo = vlo; g.vhi = vhi;
+  g.tune = tune0;  // this handle's launch shapes: a snapshot of the process defaults
+  g.tune.max_blocks = oi::partial_blocks_bound(g.pitch, ny, nzl);
   const oi_status st = build(h.get(), phase, on_device);
   if (st != OI_OK) return st;
   *out = h.release();
@@ -570,6 +576,7 @@ extern "C" oi_status oi_tort_create_slab(oi_tort** out, oi_comm* comm, const uin
 
 // ---- CG --------------------------------------------------------------------------------
 static oi_status reduce_to(oi_tort* h, int nblocks, int ncomp, double* dst, bool check, int iter_done) {
+  if (nblocks < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", h->g.tune.max_blocks); return OI_BAD_ARG; }
   const bool multi = h->comm != nullptr;
   {
     PROF(K_FINALIZE);
@@ -600,7 +607,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * h->nvec_cg, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
   int nb;
-  h->xskip = h->cg1 ? cg1_xskip() : 0;
+  h->xskip = h->cg1 ? g.tune.cg1_xskip : 0;
   if (h->cg1) {
     // kernel 0 reads buffer 1: r_{-1} := r_0 with alpha_{-1} = 0, q_{-1} = p_{-1} = 0
     HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * h->nvec_cg, s));
@@ -637,6 +644,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
         nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
                         h->partials, h->ctrl, 0, 0, 0, h->lineoff, s);
       }
+      if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 1, s); }
     } else {
       // slab with neighbours: the two boundary chunks first, their q planes travel on the comm
@@ -658,6 +666,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
         nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
                           h->partials, h->ctrl, 1, 2, nb_b, h->lineoff, s);
       }
+      if (nb_b < 0 || nb_i < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s); }
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
       launch_scalars1(rk, h->ctrl, k, s);
@@ -1341,10 +1350,54 @@ extern "C" const char* oi_status_string(oi_status s) {
 }
 extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
 extern "C" void oi_tort_set_tuning(int fused_tile_rows, int fused_zchunk) {
-  oi::set_fused_tuning(fused_tile_rows, fused_zchunk);
+  oi::Tune t = oi::default_tune();
+  if (fused_tile_rows == 8 || fused_tile_rows == 16 || fused_tile_rows == 32) t.fused_rows = fused_tile_rows / 8;
+  t.zchunk = fused_zchunk > 0 ? fused_zchunk : 0;
+  oi::set_default_tune(t);
 }
-extern "C" void oi_tort_set_apply_tuning(int tile_rows) { oi::set_apply_tuning(tile_rows); }
+extern "C" void oi_tort_set_apply_tuning(int tile_rows) {
+  oi::Tune t = oi::default_tune();
+  if (tile_rows == 8 || tile_rows == 16 || tile_rows == 32) t.pure_rows = tile_rows / 8;
+  oi::set_default_tune(t);
+}
 extern "C" void oi_tort_set_cg1_tuning(int tile_rows, int x_every_second) {
-  oi::set_cg1_tuning(tile_rows);
-  oi::set_cg1_xskip(x_every_second);
+  oi::Tune t = oi::default_tune();
+  oi::tune_set_cg1_tile(t, tile_rows);
+  t.cg1_xskip = x_every_second ? 1 : 0;
+  oi::set_default_tune(t);
+}
+// named switches of the process defaults (experiments, cross-checks; the keys are listed in include/openimpala_amd.h)
+extern "C" oi_status oi_tort_set_option(const char* key, double value) {
+  if (!key) { oi::set_error("%s: null key", __func__); return OI_BAD_ARG; }
+  oi::Tune t = oi::default_tune();
+  const std::string k(key);
+  const int iv = (int)value;
+  if (k == "tile_map") t.tile_map = iv;
+  else if (k == "zchunk") t.zchunk = iv > 0 ? iv : 0;
+  else if (k == "apply_kernel") t.apply_kernel = iv;
+  else if (k == "mg_plain") t.mg_plain = iv != 0;
+  else if (k == "mg_novec4") t.mg_novec4 = iv != 0;
+  else if (k == "mg_debug") t.mg_debug = iv != 0;
+  else if (k == "mg_replicate_cells") t.mg_replicate_cells = (long long)value;
+  else if (k == "mg_wmask") t.mg_wmask = iv;
+  else if (k == "mg_scale") t.mg_scale = (float)value;
+  else if (k == "force_comm") t.force_comm = iv != 0;
+  else { oi::set_error("%s: unknown key '%s'", __func__, key); return OI_BAD_ARG; }
+  oi::set_default_tune(t);
+  return OI_OK;
+}
+// take the CURRENT process defaults into a live handle (launch shapes only: the layout, the capacity of the
+// partial-sum array and the multigrid hierarchy were fixed when the handle was built)
+extern "C" oi_status oi_tort_retune(oi_tort* h) {
+  if (!h) { oi::set_error("%s: null handle", __func__); return OI_BAD_ARG; }
+  const oi::Tune old = h->g.tune;
+  oi::Tune t = oi::default_tune();
+  t.max_blocks = old.max_blocks;
+  t.cg1_compact = old.cg1_compact;
+  t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
+  t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale;
+  t.force_comm = old.force_comm;
+  h->g.tune = t;
+  return OI_OK;
 }

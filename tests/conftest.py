@@ -25,3 +25,18 @@ def goldens():
     import json
     with open(os.path.join(GOLDEN, "sample_goldens.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture
+def oi_option():
+    """Set a named process default of the library (oi_tort_set_option) for one test; `reset` is restored afterwards."""
+    import openimpala_amd as oia
+    changed = []
+
+    def setter(key, value, reset=0):
+        oia.set_option(key, value)
+        changed.append((key, reset))
+
+    yield setter
+    for key, reset in changed:
+        oia.set_option(key, reset)

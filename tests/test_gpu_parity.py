@@ -86,10 +86,24 @@ def test_mask_codes_apply_bit_exact(shape, direction):
     assert np.array_equal(t.apply(v, oia.KERNEL_UNFUSED), want)
     try:
         for rows in (8, 16, 32):  # LDS tile heights of the z-marching kernel
-            oia.set_tuning(rows, 0, rows)
-            assert np.array_equal(t.apply(v, oia.KERNEL_FUSED), want), f"tile rows {rows}"
+            for tile_map in (0, 1, 2):  # block -> tile orders
+                oia.set_tuning(rows, 0, rows)
+                oia.set_option("tile_map", tile_map)
+                oia.set_option("apply_kernel", 1)  # the LDS-tiled form
+                t.retune()
+                assert np.array_equal(t.apply(v, oia.KERNEL_FUSED), want), f"tile rows {rows}, map {tile_map}"
+        # the wave-autonomous apply (default): chunk lengths down to one plane, every block -> tile order
+        oia.set_option("apply_kernel", 0)
+        for zchunk in (0, 1, 2, 3, 5, 64):
+            for tile_map in (0, 1, 2):
+                oia.set_tuning(16, zchunk, 32)
+                oia.set_option("tile_map", tile_map)
+                t.retune()
+                assert np.array_equal(t.apply(v, oia.KERNEL_FUSED), want), f"apply7 zchunk {zchunk}, map {tile_map}"
     finally:
         oia.set_tuning()
+        oia.set_option("tile_map", 2)
+        oia.set_option("apply_kernel", 0)
     t.destroy()
 
 
@@ -586,7 +600,7 @@ def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_stor
     assert out[1][3] < out[0][3]
 
 
-def test_multigrid_four_cells_per_thread_kernels_are_bit_identical(monkeypatch):
+def test_multigrid_four_cells_per_thread_kernels_are_bit_identical(oi_option):
     """Coarse levels whose rows split into groups of four cells run k_mg_pre4 / k_mg_post4 (16-byte row loads, x
     neighbours in registers): same arithmetic in the same order as the one-cell kernels, so the whole solve is
     bit-identical -- flow-through (open faces) and homogenization (periodic wrap of the group's edge cells and rows)."""
@@ -601,7 +615,7 @@ def test_multigrid_four_cells_per_thread_kernels_are_bit_identical(monkeypatch):
         return tau, it, rel, res, h.tensor().copy()
 
     fast = both()
-    monkeypatch.setenv("OI_MG_NOVEC4", "1")
+    oi_option("mg_novec4", 1)
     ref = both()
     assert fast[:3] == ref[:3] and fast[0] > 1.0
     assert fast[3] == ref[3] and all(r[0] for r in ref[3])

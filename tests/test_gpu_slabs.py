@@ -135,11 +135,11 @@ def test_slabs_multigrid_replicated_hierarchy(sample_phase, goldens, nranks, dir
 
 @pytest.mark.parametrize("nranks,direction,shape", [(2, 2, (64, 40, 52)), (4, 0, (64, 37, 45)), (3, 1, (96, 33, 40)),
                                                     (4, 2, (72, 48, 40))])
-def test_slabs_multigrid_distributed_levels(monkeypatch, nranks, direction, shape):
+def test_slabs_multigrid_distributed_levels(oi_option, nranks, direction, shape):
     """Slab boundaries on multiples of 16 / 8 planes: the first coarse levels keep the slab partition
     (ghost-plane exchanges inside the cycle) until the slabs get thin or misaligned, the rest is
     replicated.  Same iteration count and answer as one GPU."""
-    monkeypatch.setenv("OI_MG_REPLICATE_CELLS", "600")
+    oi_option("mg_replicate_cells", 600)
     phase = o.gen_spheres(shape, 33, 5, 0.45)
     ref = o.tortuosity(phase, 1, direction, -1.0, 1.0, eps=1e-10)
     assert ref["status"] == 0

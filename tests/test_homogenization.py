@@ -146,12 +146,12 @@ def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nranks,nzs", [(2, 48), (3, 37), (4, 64)])
-def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, monkeypatch, nranks, nzs):
+def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, oi_option, nranks, nzs):
     """The same on a ring of z-slabs: slab-partitioned periodic levels (ring exchange of their ghost planes) and the
     replicated tail; same iteration counts as on one GPU."""
     import threading
     import openimpala_amd as oia
-    monkeypatch.setenv("OI_MG_REPLICATE_CELLS", "600")
+    oi_option("mg_replicate_cells", 600)
     sub = np.ascontiguousarray(sample_phase[:nzs, :28, :44])
     want, _ = o.effective_diffusivity(sub, 1, eps=1e-10)
     single = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-10, precond=oia.PRECOND_MG)
@@ -184,7 +184,7 @@ def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, monkeypatch, nrank
 
 
 @pytest.mark.gpu
-def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, monkeypatch):
+def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, oi_option):
     """The two kernel families behind OI_PRECOND_MG on the cell problems (OI_MG_PLAIN selects the plain one): same
     iteration counts, chi fields equal to solver tolerance."""
     import openimpala_amd as oia
@@ -198,7 +198,7 @@ def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, monkeypa
         return out
 
     tiled = run()
-    monkeypatch.setenv("OI_MG_PLAIN", "1")
+    oi_option("mg_plain", 1)
     plain = run()
     for k in range(3):
         assert tiled[0][k][0] and plain[0][k][0] and abs(tiled[0][k][1] - plain[0][k][1]) <= 1
