@@ -249,6 +249,135 @@ __global__ void __launch_bounds__(64 * NW) k_apply7(G g, const uint8_t* __restri
   }
 }
 
+// ------------------------------------------------------------------ dense single-kernel CG iteration (structure test)
+// r = r_in - alpha q_in; p = r + beta p_in; q = A p; stores r_out, p_out, q_out; 49 B/voxel; five dot products
+template <int RY>
+struct CgPlane {
+  v2d p[RY + 2];
+  v2d r[RY];
+  double xh;
+  unsigned short cc[RY];
+};
+template <int RY, int NW, int D>
+__global__ void __launch_bounds__(64 * NW) k_cg7d(G g, const uint8_t* __restrict__ code, const double* __restrict__ r_in,
+                                                   const double* __restrict__ q_in, const double* __restrict__ p_in,
+                                                   double* __restrict__ r_out, double* __restrict__ q_out,
+                                                   double* __restrict__ p_out, double alpha, double beta,
+                                                   double* __restrict__ partials, int zchunk, int tiles_x, int tiles_y, int nzc,
+                                                   int map) {
+  constexpr int RING = D + 2;
+  __shared__ double red[NW][5];
+  const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nzc, map);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zc = L / (tiles_x * tiles_y);
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i0 = tx * 128, j0 = (ty * NW + w) * RY;
+  const bool in_x = i0 + 2 * lane < g.pitch;
+  const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);
+  const int hrow = j0 + (lane >> 1);
+  const int hi_ = (lane & 1) ? i0 + 128 : i0 - 1;
+  const bool hvalid = lane < 2 * RY && hrow < g.ny && hi_ >= 0 && hi_ < g.pitch;
+  const unsigned lane_b16 = 16u * lane, lane_b2 = 2u * lane;
+  const long long urow = (long long)j0 * g.pitch + i0;
+  const unsigned hoff_b = hvalid ? (unsigned)(((lane >> 1) * g.pitch + (hi_ - i0 + 1)) * 8) : 0u;
+  CgPlane<RY> P[RING];
+  // kind 0: z neighbour only (centre rows, nothing stored); 1: output plane
+  auto load_plane = [&](CgPlane<RY>& pl, int gz, bool out) {
+    const long long po = (long long)gz * g.plane + urow;
+    const char* rp = reinterpret_cast<const char*>(r_in + po);
+    const char* qp = reinterpret_cast<const char*>(q_in + po);
+    const char* pp = reinterpret_cast<const char*>(p_in + po);
+    char* ro = reinterpret_cast<char*>(r_out + po);
+    char* po_ = reinterpret_cast<char*>(p_out + po);
+#pragma unroll
+    for (int r = 0; r < RY + 2; ++r) {
+      const int j = j0 + r - 1;
+      const bool edge = (r == 0 || r == RY + 1);
+      v2d pv = {0.0, 0.0}, rv = {0.0, 0.0};
+      if ((!edge || out) && j >= 0 && j < g.ny && in_x) {
+        const long long off = (long long)(r - 1) * g.pitch * 8 + lane_b16;
+        const v2d a = *reinterpret_cast<const v2d*>(rp + off), b = *reinterpret_cast<const v2d*>(qp + off);
+        const v2d c = *reinterpret_cast<const v2d*>(pp + off);
+        rv.x = a.x - alpha * b.x; rv.y = a.y - alpha * b.y;
+        pv.x = rv.x + beta * c.x; pv.y = rv.y + beta * c.y;
+        if (out && !edge) {
+          __builtin_nontemporal_store(rv, reinterpret_cast<v2d*>(ro + off));
+          __builtin_nontemporal_store(pv, reinterpret_cast<v2d*>(po_ + off));
+        }
+      }
+      pl.p[r] = pv;
+      if (!edge) pl.r[r - 1] = rv;
+    }
+    double h = 0.0;
+    if (out && hvalid) {
+      const double a = *reinterpret_cast<const double*>(rp - 8 + hoff_b), b = *reinterpret_cast<const double*>(qp - 8 + hoff_b);
+      const double c = *reinterpret_cast<const double*>(pp - 8 + hoff_b);
+      h = (a - alpha * b) + beta * c;
+    }
+    pl.xh = h;
+    if (out) {
+      const char* cp = reinterpret_cast<const char*>(code + po);
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        unsigned short c = 0;
+        if (j0 + r < g.ny && in_x) c = *reinterpret_cast<const unsigned short*>(cp + (long long)r * g.pitch + lane_b2);
+        pl.cc[r] = c;
+      }
+    }
+  };
+  double s_rr = 0, s_pq = 0, s_zq = 0, s_qdq = 0;
+  auto compute = [&](int gz, const CgPlane<RY>& pv, const CgPlane<RY>& cu, const CgPlane<RY>& nx) {
+    char* qo = reinterpret_cast<char*>(q_out + (long long)gz * g.plane + urow);
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const v2d pc = cu.p[r + 1], ym = cu.p[r], yp = cu.p[r + 2], rc = cu.r[r];
+      const double lf = shr1(pc.y, lane_bcast(cu.xh, 2 * r)), rt = shl1(pc.x, lane_bcast(cu.xh, 2 * r + 1));
+      const unsigned c0 = cu.cc[r] & 0xffu, c1 = cu.cc[r] >> 8;
+      const double s0 = ((((lf + pc.y) + ym.x) + yp.x) + pv.p[r + 1].x) + nx.p[r + 1].x;
+      const double s1 = ((((pc.x + rt) + ym.y) + yp.y) + pv.p[r + 1].y) + nx.p[r + 1].y;
+      const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
+      const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
+      if (j0 + r < g.ny && in_x) {
+        v2d o = {q0, q1};
+        __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(qo + (long long)r * g.pitch * 8 + lane_b16));
+      }
+      s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
+      s_pq += pc.x * q0; s_pq += pc.y * q1;
+      s_zq += rc.x * q0; s_zq += rc.y * q1;
+      s_qdq += q0 * q0; s_qdq += q1 * q1;
+    }
+  };
+  load_plane(P[0], gs - 1, false);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (gs + d <= ge) load_plane(P[1 + d], gs + d, gs + d < ge);
+  for (int gz0 = gs; gz0 < ge; gz0 += RING) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      const int gz = gz0 + u;
+      if (gz < ge) {
+        const int ahead = gz + D;
+        if (ahead <= ge) load_plane(P[(u + 1 + D) % RING], ahead, ahead < ge);
+        compute(gz, P[u % RING], P[(u + 1) % RING], P[(u + 2) % RING]);
+      }
+    }
+  }
+  double sums[4] = {s_rr, s_pq, s_zq, s_qdq};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double v = sums[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[w][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int k = 0; k < NW; ++k) t += red[k][threadIdx.x];
+    partials[5 * blockIdx.x + threadIdx.x] = t;
+  }
+}
+
 static void cpu_apply(const G& g, const std::vector<uint8_t>& code, const std::vector<double>& v, std::vector<double>& q) {
   for (int gz = 1; gz <= g.nzl; ++gz)
     for (int j = 0; j < g.ny; ++j)
@@ -400,6 +529,7 @@ int main(int argc, char** argv) {
     printf("hipMemcpyDtoD                   %7.3f ms %7.1f GB/s\n", msf / 5, 16.0 * nn / (msf / 5) / 1e6);
   }
   // ---- apply variants at 1024^3
+  if (!(argc > 2 && !strcmp(argv[2], "cgonly")))
   for (int k = 0; k < nvar; ++k)
     for (int zchunk : {8, 12, 16, 24, 32, 64}) for (int map : {2}) {
       const Variant& V = variants[k];
@@ -411,5 +541,23 @@ int main(int argc, char** argv) {
              blocks, ms, 17.0 * nn / ms / 1e6, 17.0 * nn / ms / 1e6 / 8000.0);
       fflush(stdout);
     }
+  {  // dense CG-iteration structure test: three more vectors
+    double *r2, *q2, *p2, *p1;
+    CK(hipMalloc(&r2, n * 8)); CK(hipMalloc(&q2, n * 8)); CK(hipMalloc(&p2, n * 8)); CK(hipMalloc(&p1, n * 8));
+    CK(hipMemset(r2, 0, n * 8)); CK(hipMemset(q2, 0, n * 8)); CK(hipMemset(p2, 0, n * 8)); CK(hipMemcpy(p1, dv, n * 8, hipMemcpyDeviceToDevice));
+#define CG7(RY, NW, D, ZC, MAP)                                                                                              \
+    {                                                                                                                        \
+      const int by = RY * NW, tx = (g.pitch + 127) / 128, ty = (g.ny + by - 1) / by, nzc = (g.nzl + ZC - 1) / ZC;            \
+      const int blocks = tx * ty * nzc;                                                                                      \
+      const double ms = timeit([&] { hipLaunchKernelGGL((k_cg7d<RY, NW, D>), dim3(blocks), dim3(64 * NW), 0, 0, g, dc, dv, dq, p1, r2, q2, p2, 0.3, 0.2, dp, ZC, tx, ty, nzc, MAP); }, reps); \
+      printf("cg7d RY%d NW%d D%d zchunk %3d map %d blocks %6d  %7.3f ms  %7.1f GB/s (49 B/voxel)  frac %.3f\n", RY, NW, D, ZC, MAP, blocks, ms, 49.0 * nn / ms / 1e6, 49.0 * nn / ms / 1e6 / 8000.0); \
+      fflush(stdout);                                                                                                        \
+    }
+    CG7(4, 4, 1, 8, 2) CG7(4, 4, 1, 16, 2) CG7(4, 4, 1, 32, 2) CG7(4, 4, 1, 64, 0)
+    CG7(4, 8, 1, 8, 2) CG7(4, 8, 1, 16, 2) CG7(4, 8, 1, 32, 2)
+    CG7(2, 8, 1, 8, 2) CG7(2, 8, 1, 16, 2) CG7(2, 8, 2, 8, 2) CG7(2, 8, 2, 16, 2) CG7(2, 4, 2, 8, 2)
+    CG7(2, 16, 1, 8, 2) CG7(2, 16, 2, 8, 2) CG7(4, 4, 2, 8, 2) CG7(4, 4, 2, 16, 2)
+    CG7(3, 4, 1, 8, 2) CG7(3, 8, 1, 8, 2)
+  }
   return 0;
 }
