@@ -62,12 +62,16 @@ def parse():
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
     ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
+    ap.add_argument("--run-budget-s", type=float, default=600.0,
+                    help="wall-clock cap on start-up + warm-up + timed region (a collective that never returns at N > 1): past it "
+                         "rank 0 prints a line with value null and a note, and every rank leaves with exit code 3")
     ap.add_argument("--extras-budget-s", type=float, default=480.0,
                     help="wall-clock cap on everything after the timed region (solves to 1e-6, variants, homogenization, CPU "
                          "baseline): past it the JSON line is printed without the unfinished parts and the process exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=384)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-size", type=int, default=384, help="edge of the small second CPU sample")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU seconds spent on the small second sample")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU iterations on the bench configuration itself")
     ap.add_argument("--no-apply-bench", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-stored-p variant")
     ap.add_argument("--force-dist", action="store_true",
@@ -87,12 +91,54 @@ def make_structure(oia, args, shape, z0, nzl):
             f"overlapping spheres r={radius}, target porosity 0.4, seed 20251031")
 
 
-def cpu_baseline(oia, args):
-    """The oracle's matrix-free CG (same algorithm, OpenMP) on a bounded sample of the same
-    structure, timed on this box's host cores.  A reported baseline, not the target."""
+def kernels_sha():
+    """hash of the kernel source a PMC companion run must match (profiles/pmc_summary.json)"""
+    import hashlib
+    with open(os.path.join(ROOT, "openimpala_amd", "csrc", "oi_kernels.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed PMC companion run (tools/rocprof.sh) -- only if it was taken with THIS
+    kernel source; a stale file gives None, never an old number."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        ent = pmc.get(key)
+        if ent and ent.get("kernels_sha256") == kernels_sha():
+            return ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def cpu_cg_rate(o, code, x0, iters):
+    t0 = time.time()
+    o.cg_fixed(code, x0, iters)
+    return time.time() - t0
+
+
+def cpu_baseline(oia, args, full=None):
+    """The oracle's matrix-free CG (same algorithm, OpenMP), timed on this box's host cores: `--cpu-iters` iterations of
+    the bench configuration itself (`full` = (code, mask, description) downloaded from the GPU handle -- the oracle's own
+    mask pass would take minutes at 1024^3 and is not what is timed), plus a small second sample with a one-core figure.
+    A reported baseline, not the target."""
     import numpy as np
     from oracle import oracle as o
 
+    threads = o.lib().oi_oracle_num_threads()
+    out = {"unit": "Mvoxel-iters/s", "cores": threads, "kind": "port"}
+    label = "CPU restatement (matrix-free CG, OpenMP), not Hypre FlexGMRES+SMG"
+    if full is not None:
+        code, mask, desc = full
+        nvox = code.size
+        x0 = o.initial_field(mask, 0, 0.0, 1.0)
+        del mask
+        cpu_cg_rate(o, code, x0, 2)  # page faults, thread start-up
+        dt = cpu_cg_rate(o, code, x0, args.cpu_iters)
+        out["value"] = nvox * args.cpu_iters / dt / 1e6
+        out["sample"] = f"the bench configuration itself: {desc}, X direction, {args.cpu_iters} CG iterations in {dt:.1f} s; {label}"
+        del x0, code
+    # small second sample (and the one-core rate of the same restatement)
     n = args.cpu_size
     shape = (n, n, n)
     buf, desc = make_structure(oia, args, shape, 0, n)
@@ -100,31 +146,25 @@ def cpu_baseline(oia, args):
     buf.free()
     mask, nact = o.active_mask(phase, 1, 0)
     if nact == 0:
-        return None
+        return out if "value" in out else None
     code = o.codes(mask, 0)
     x0 = o.initial_field(mask, 0, 0.0, 1.0)
-    threads = o.lib().oi_oracle_num_threads()
-    o.cg_fixed(code, x0, 5)  # first call pays page faults and thread start-up
-    t0 = time.time()
-    o.cg_fixed(code, x0, 10)
-    per_iter = (time.time() - t0) / 10
+    cpu_cg_rate(o, code, x0, 5)
+    per_iter = cpu_cg_rate(o, code, x0, 10) / 10
     iters = int(max(10, min(20000, args.cpu_seconds / max(per_iter, 1e-6))))
-    t0 = time.time()
-    o.cg_fixed(code, x0, iters)
-    dt = time.time() - t0
-    # the same kernel on ONE core for reference (the reference's README advises OMP_NUM_THREADS=1 under MPI): a few iterations
-    one_core = None
-    try:
+    dt = cpu_cg_rate(o, code, x0, iters)
+    small = {"value": n ** 3 * iters / dt / 1e6, "sample": f"{n}^3 {desc}, X direction, {iters} CG iterations in {dt:.1f} s"}
+    try:  # the reference's README advises OMP_NUM_THREADS=1 under MPI: the same kernel on ONE core
         o.lib().oi_oracle_set_threads(1)
-        n1 = max(2, min(20, int(3.0 / max(per_iter * threads, 1e-6))))
-        t0 = time.time()
-        o.cg_fixed(code, x0, n1)
-        one_core = n ** 3 * n1 / (time.time() - t0) / 1e6
+        n1 = max(2, min(20, int(2.0 / max(per_iter * threads, 1e-6))))
+        small["one_core_value"] = n ** 3 * n1 / cpu_cg_rate(o, code, x0, n1) / 1e6
     finally:
         o.lib().oi_oracle_set_threads(threads)
-    return {"value": n ** 3 * iters / dt / 1e6, "unit": "Mvoxel-iters/s", "cores": threads, "kind": "port", "one_core_value": one_core,
-            "sample": f"{n}^3 {desc}, X direction, {iters} CG iterations in {dt:.1f} s, "
-                      "CPU restatement (matrix-free CG, OpenMP), not Hypre FlexGMRES+SMG"}
+    out["small_sample"] = small
+    if "value" not in out:
+        out["value"] = small["value"]
+        out["sample"] = small["sample"] + "; " + label
+    return out
 
 
 def main():
@@ -137,6 +177,27 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
+
+    # Whole-run watchdog: start-up, warm-up and the timed region of an N > 1 run contain collectives that this code has
+    # never executed on real multi-GPU hardware.  If one never returns, rank 0 still prints ONE line (value null + note)
+    # and every rank leaves through os._exit -- never by re-executing a process that has touched the GPU.
+    phase_box = {"phase": "start-up"}
+
+    def run_overrun():
+        if rank == 0:
+            print(json.dumps({"metric": "Mvoxel-iters/sec", "value": None, "unit": "Mvoxel-iters/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": f"{args.size}^3 two-phase {args.structure}, z-slabs over {world} GPU(s)"},
+                              "roofline": None, "cpu_baseline": None,
+                              "note": f"watchdog: no progress past '{phase_box['phase']}' within {args.run_budget_s:.0f} s "
+                                      "(a collective or launch did not return); nothing was measured"}), flush=True)
+        sys.stdout.flush()
+        os._exit(3)
+
+    run_watchdog = threading.Timer(args.run_budget_s, run_overrun)
+    run_watchdog.daemon = True
+    run_watchdog.start()
 
     use_dist = world > 1 or args.force_dist
     dist = None
@@ -152,9 +213,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            os.environ["OI_FORCE_COMM"] = "1"
 
     import openimpala_amd as oia
+    if args.force_dist:
+        oia.set_option("force_comm", 1)
 
     if use_dist:
         with _StdoutToStderr():
@@ -173,6 +235,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    phase_box["phase"] = "structure + handle creation (mask, codes, vectors)"
     n = args.size
     nz = args.nz if args.nz > 0 else n
     nvox = n * n * nz
@@ -204,13 +267,30 @@ def main():
 
     # ---- stand-alone stencil apply (the kernel the 70 %-of-roofline target names) ----
     apply_info = None
+    phase_box["phase"] = "stand-alone apply"
     if not args.no_apply_bench and args.kernel != "lean":
         ms = t.bench_apply(20, oia.KERNEL_FUSED)
         vox_local = n * n * nzl
         gbs = BYTES_PER_VOXEL["apply"] * vox_local / ms / 1e6
-        apply_info = {"kernel": "fused_a<PURE> (q = A v for ANY v, 17 B/voxel, every voxel streamed)", "ms_per_launch": ms,
+        apply_info = {"kernel": "k_apply7 (q = A v for ANY v, 17 B/voxel, every voxel streamed; wave-autonomous, DPP x-neighbours, "
+                                "z-sweep launch order)", "ms_per_launch": ms,
                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                      "gvoxel_per_s": vox_local / ms / 1e6}
+                      "gvoxel_per_s": vox_local / ms / 1e6, "traffic": pmc_traffic(f"apply:{n}:{world}")}
+        # what a plain 1 read : 1 write copy stream of the same size reaches on this box right now (16 B/voxel)
+        try:
+            cms = oia.stream_copy_bench(8 * vox_local, 10)
+            apply_info["copy_stream_same_box"] = {"ms": cms, "GBps": 16.0 * vox_local / cms / 1e6,
+                                                  "frac": 16.0 * vox_local / cms / 1e6 / HBM_PEAK_GBS,
+                                                  "what": "linear float4-class copy (8 x 16 B nontemporal loads in flight per lane), "
+                                                          "8 bytes read + 8 written per voxel of the same volume"}
+        except oia.OpenImpalaError as e:
+            apply_info["copy_stream_same_box"] = {"error": str(e)}
+        # the LDS-tiled form (round 1's kernel) for comparison
+        oia.set_option("apply_kernel", 1); oia.set_option("tile_map", 0); t.retune()
+        ms_lds = t.bench_apply(10, oia.KERNEL_FUSED)
+        oia.set_option("apply_kernel", 0); oia.set_option("tile_map", 2); t.retune()
+        apply_info["lds_tiled_form"] = {"kernel": "k_fused_a<PURE>, 64-plane chunks, XCD-contiguous order", "ms_per_launch": ms_lds,
+                                        "frac": BYTES_PER_VOXEL["apply"] * vox_local / ms_lds / 1e6 / HBM_PEAK_GBS}
         # the same stencil as the CG applies it: v vanishes off the free set, lines without a free voxel are skipped
         ms_cg = t.bench_apply(20, oia.KERNEL_LEAN)
         live = t.live_fraction(16)
@@ -220,39 +300,36 @@ def main():
                                    "dense_equivalent_GBps": BYTES_PER_VOXEL["apply"] * vox_local / ms_cg / 1e6}
 
     # ---- timed region: K CG iterations ----
+    phase_box["phase"] = "warm-up iterations"
     t.cg_begin()
     t.cg_iterate(args.warmup)
     t.sync()
     t.reset_kernel_times()
     barrier()
+    phase_box["phase"] = "timed region"
     t0 = time.perf_counter()
     t.cg_iterate(args.steps)
     t.sync()
     barrier()
     dt = time.perf_counter() - t0
+    phase_box["phase"] = "after the timed region"
+    run_watchdog.cancel()
     ktimes = t.kernel_times()
     it_done, relres, conv = t.cg_state()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # eps = 1e-300 keeps every step busy; should CG nevertheless finish inside the timed region (tiny volumes, huge
+    # --steps), the later launches return at once and only the iterations really done count
     steps_done = min(args.steps, max(0, it_done - args.warmup)) if conv else args.steps
-    value = nvox * args.steps / dt / 1e6
+    value = nvox * steps_done / dt / 1e6
     alg_bytes_iter = sum(BYTES_PER_VOXEL[k] for k in ktimes if k in BYTES_PER_VOXEL)
 
     # dominant kernel of the timed region, from the HIP events on the solver's stream
     main_k = max((k for k in ktimes if k in BYTES_PER_VOXEL), key=lambda k: ktimes[k][0])
     ms_launch = ktimes[main_k][0] / max(1, ktimes[main_k][1])
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_file):
-        try:
-            pmc = json.load(open(pmc_file))
-            ent = pmc.get(f"{main_k}:{n}:{world}")
-            if ent:
-                traffic = ent["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+    traffic = pmc_traffic(f"{main_k}:{n}:{world}")  # None unless a PMC companion run of THIS kernel source is committed
     # The CG-form kernels never move a line of r/q/p/x that holds no free voxel, and move
     # live lines whole.  ALGORITHMIC bytes of a launch = the code byte of every voxel + the kernel's vector
     # bytes (SURVEY 8(d) accounting, 60 of the 61 B) for every voxel of a LIVE line; `dense_equivalent` prices the
@@ -260,6 +337,10 @@ def main():
     # what the metric Mvoxel-iters/s counts) -- it may exceed the HBM peak and is not a bandwidth.
     # (the compacted vectors of the single-kernel iteration store lines of oia.line_voxels() = 8 voxels, one 64-byte
     # HBM burst; the dense vectors of the other variants are predicated on whole 128-byte cache lines)
+    if steps_done < args.steps:
+        extras_note_early = f"CG converged after {steps_done} of the {args.steps} timed steps; value counts the steps done"
+    else:
+        extras_note_early = None
     line_vox = oia.line_voxels() if main_k == "cg1" else 16
     nfree_frac = t.live_fraction(1)
     live16 = t.live_fraction(line_vox)
@@ -279,10 +360,13 @@ def main():
                 "ms_per_launch": ms_launch,
                 "bytes_per_voxel_iter_in_live_lines": alg_bytes_iter}
     t.cg_finish()
+    cpu_full = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_iters > 0 and args.kernel != "lean" and nvox <= 1100 ** 3:
+        cpu_full = (t.codes(), t.mask(), f"{n}x{n}x{nz} {desc}")  # (bit-identical to the oracle's own: tests/test_gpu_parity.py)
 
     # Everything below is reported beside the metric, never part of it.  A watchdog prints the line without the
     # unfinished parts if they overrun (a collective that never returns on some node must not cost the measurement).
-    extras = {"solve": None, "solve_mg": None, "variants": None, "homog": None, "cpu": None, "note": None}
+    extras = {"solve": None, "solve_mg": None, "variants": None, "homog": None, "cpu": None, "note": extras_note_early}
     emitted = threading.Lock()
 
     def emit():
@@ -292,7 +376,7 @@ def main():
             return
         out = {
             "metric": "Mvoxel-iters/sec", "value": value, "unit": "Mvoxel-iters/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, steps_done) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{n}x{n}x{nz} two-phase {desc}; phase 1, {args.direction} direction; matrix-free CG "
@@ -439,7 +523,7 @@ def main():
     extras["variants"] = variants
     extras["homog"] = homog
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        extras["cpu"] = cpu_baseline(oia, args)
+        extras["cpu"] = cpu_baseline(oia, args, cpu_full)
     watchdog.cancel()
     emit()
     if t is not None:

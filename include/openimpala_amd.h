@@ -86,7 +86,8 @@ void oi_tort_default_opts(oi_tort_opts* opts);
 typedef struct oi_tort_stats {
   int converged;          /* getSolverConverged() */
   int iterations;         /* getSolverIterations() */
-  double final_relres;    /* getFinalRelativeResidualNorm(): ||b - A x|| / ||b|| of the full system */
+  double final_relres;    /* getFinalRelativeResidualNorm(): ||r|| / ||b|| of the full system, r the solver's RECURRENCE residual
+                           * (what the stop test sees, as in HYPRE); oi_tort_true_residual recomputes b - A x independently */
   double flux_in;         /* getFluxIn() */
   double flux_out;        /* getFluxOut() */
   double active_vf;       /* getActiveVolumeFraction() */
@@ -186,6 +187,10 @@ oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int
  * nx*ny*nz_local doubles; variant = OI_KERNEL_UNFUSED | OI_KERNEL_FUSED */
 oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q, int variant);
 oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
+/* ||b - A x|| / ||b|| of the current solution recomputed from scratch on the device (A x by the stand-alone apply kernel,
+ * which no solver variant uses inside its iteration; one dense scratch vector, 8 bytes per voxel; collective on slabs).
+ * Same normalisation as stats.final_relres. */
+oi_status oi_tort_true_residual(oi_tort* h, double* relres);
 /* run the stand-alone stencil apply `reps` times on device-resident vectors and
  * return the HIP-event time of the launches (ms per launch); variant OI_KERNEL_LEAN = the apply as the CG
  * uses it (a vector that vanishes off the free set, live-line predication) */
@@ -274,6 +279,10 @@ oi_status oi_dev_malloc(void** ptr, size_t bytes);
 /* free / total memory of the current device (a volume needs 25-60 bytes per voxel) */
 oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 oi_status oi_dev_free(void* ptr);
+/* measurement aid: ms per launch of the library's reference copy stream (linear, 16-byte nontemporal accesses) between
+ * two scratch arrays of `bytes` each -- what a 1 read : 1 write stream reaches on this box; bench.py reports it beside
+ * the stencil apply */
+oi_status oi_dev_stream_copy_bench(size_t bytes, int reps, double* ms_per_copy);
 oi_status oi_dev_upload(void* dst_dev, const void* src_host, size_t bytes);
 oi_status oi_dev_download(void* dst_host, const void* src_dev, size_t bytes);
 int oi_device_count(void);

@@ -41,10 +41,10 @@ ABI_SYMBOLS = (
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
-    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
+    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
-    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
+    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host"
 ).split()
 
@@ -146,6 +146,7 @@ def lib():
     L.oi_tort_set_cg1_layout.restype = None
     L.oi_tort_set_option.argtypes = [C.c_char_p, C.c_double]
     L.oi_tort_retune.argtypes = [vp]
+    L.oi_tort_true_residual.argtypes = [vp, C.POINTER(C.c_double)]
     L.oi_tort_line_voxels.argtypes = []
     L.oi_tort_line_voxels.restype = i
     L.oi_comm_unique_id.argtypes = [vp]
@@ -162,6 +163,7 @@ def lib():
     L.oi_blobs_level.restype = u64
     L.oi_dev_malloc.argtypes = [pp, C.c_size_t]
     L.oi_dev_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.oi_dev_stream_copy_bench.argtypes = [C.c_size_t, i, C.POINTER(C.c_double)]
     L.oi_dev_free.argtypes = [vp]
     L.oi_dev_upload.argtypes = [vp, vp, C.c_size_t]
     L.oi_dev_download.argtypes = [vp, vp, C.c_size_t]
@@ -337,6 +339,13 @@ def set_cg1_layout(compact_lines=1):
     lib().oi_tort_set_cg1_layout(int(compact_lines))
 
 
+def stream_copy_bench(nbytes, reps=10):
+    """ms per launch of the library's reference copy stream between two scratch arrays of nbytes each."""
+    ms = C.c_double()
+    _check(lib().oi_dev_stream_copy_bench(int(nbytes), int(reps), C.byref(ms)))
+    return ms.value
+
+
 def set_option(key, value):
     """Named switch of the process defaults (see include/openimpala_amd.h); new handles only."""
     _check(lib().oi_tort_set_option(key.encode(), float(value)))
@@ -489,6 +498,12 @@ class TortuosityMI355:
         out = np.empty(self.shape, np.uint8)
         _check(lib().oi_tort_debug_get_codes(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def true_residual(self):
+        """||b - A x|| / ||b|| of the current solution, recomputed on the device with the stand-alone apply kernel."""
+        v = C.c_double()
+        _check(lib().oi_tort_true_residual(self._h, C.byref(v)))
+        return v.value
 
     def retune(self):
         """Take the current process defaults of the launch shapes (set_tuning, set_option) into this handle."""

@@ -137,6 +137,8 @@ int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, doub
 // the same for a CG vector (vanishing on non-free voxels): lines without a free voxel are skipped
 int launch_apply_cgvec(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials, const Ctrl* ctrl,
                        hipStream_t s);
+// dst = src (ndoubles even): the box's reference 1 read : 1 write stream, see k_stream_copy
+void launch_stream_copy(double* dst, const double* src, long long ndoubles, hipStream_t s);
 // q-free CG iteration of the capacity mode (x, r, p only): p.Ap without storing q, then
 // x += alpha p, r -= alpha A p with A p recomputed on the fly; partials {p.q} / {r.r, r.z}
 int launch_lean_dot(const Geom& g, const uint8_t* code, const double* p, double* partials, const Ctrl* ctrl,

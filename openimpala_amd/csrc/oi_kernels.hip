@@ -1308,6 +1308,32 @@ static int launch_apply7(const Geom& g, const uint8_t* code, const double* v, do
   return blocks;
 }
 
+// --------------------------------------------------------------------------------------
+// Reference stream of the box: a linear copy, every wave moving contiguous 8 KiB chunks with eight 16-byte nontemporal
+// loads in flight per lane and nontemporal stores -- the fastest of the copy forms tried on MI355X
+// (profiles/r02/apply_proto_*_copy_ceiling*.txt: 5.6-5.7 TB/s; grid-stride and plain-policy forms 4.8-5.4).  bench.py
+// reports it beside the stencil apply: what a 1 read : 1 write stream reaches on THIS box at the same moment.
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stream_copy(double* __restrict__ d, const double* __restrict__ s, long long n2) {
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  const long long nchunks = n2 / (64 * U);
+  for (long long c = wave; c < nchunks; c += nwaves) {
+    const long long t0 = c * 64 * U + lane;
+    v2d_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(s + 2 * (t0 + u * 64)));
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], reinterpret_cast<v2d_t*>(d + 2 * (t0 + u * 64)));
+  }
+  for (long long t = nchunks * 64 * U + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (long long)gridDim.x * blockDim.x)
+    *reinterpret_cast<v2d_t*>(d + 2 * t) = *reinterpret_cast<const v2d_t*>(s + 2 * t);
+}
+void launch_stream_copy(double* dst, const double* src, long long ndoubles, hipStream_t s) {
+  hipLaunchKernelGGL(k_stream_copy, dim3(8192), dim3(256), 0, s, dst, src, ndoubles / 2);
+}
+
 // q = A v for a CG vector (v vanishes on non-free voxels): the stand-alone apply with live-line predication
 int launch_apply_cgvec(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials, const Ctrl* ctrl,
                        hipStream_t s) {

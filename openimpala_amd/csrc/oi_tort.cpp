@@ -1089,6 +1089,43 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
   return OI_OK;
 }
 
+// ||b - A x|| / ||b|| of the CURRENT solution, recomputed from scratch: A x by the stand-alone apply (k_apply7 -- a kernel no
+// solver variant uses inside its iteration), squared norm over the owned planes by a fixed-order reduction.  x carries
+// the Dirichlet values, so on the free rows b - A x = -(A x); identity rows have no residual.  The convergence test and
+// stats.final_relres use the RECURRENCE residual r_k = r_{k-1} - alpha q (as HYPRE's Krylov solvers do); this entry point
+// is the independent check that the two agree.  Needs one dense scratch vector (8 bytes per voxel).
+extern "C" oi_status oi_tort_true_residual(oi_tort* h, double* relres) {
+  if (!h || !relres) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  *relres = std::numeric_limits<double>::quiet_NaN();
+  if (!h->vectors_ready) return OI_NO_PERCOLATION;
+  if (h->cg_active) { oi::set_error("%s: a CG run is open (oi_tort_cg_finish first)", __func__); return OI_BAD_ARG; }
+  HIPC(hipSetDevice(h->device));
+  const Geom& g = h->g;
+  double* q = nullptr;
+  if (hipMalloc((void**)&q, sizeof(double) * g.nvec) != hipSuccess) {
+    (void)hipGetLastError();
+    oi::set_error("%s: no room for a scratch vector of %lld doubles", __func__, g.nvec);
+    return OI_HIP_ERROR;
+  }
+  oi_status rc = OI_OK;
+  do {
+    if (hipMemsetAsync(q, 0, sizeof(double) * g.nvec, h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+    if ((rc = exchange_planes(h, h->x, sizeof(double) * g.plane)) != OI_OK) break;
+    Geom ga = g;
+    ga.tune.apply_kernel = 0;  // always the wave-autonomous apply: independent of the LDS-tiled solver kernels
+    if (launch_apply_tiled(ga, h->code, h->x, q, h->partials, nullptr, h->stream) < 0) { rc = OI_BAD_ARG; break; }
+    const int nb = launch_dot(g, q, q, h->partials, h->stream);
+    launch_finalize(h->partials, nb, 1, h->scal, nullptr, 0, 0, h->stream);
+    if (h->comm && (rc = h->comm->allreduce_sum_f64(h->scal, 1, h->stream)) != OI_OK) break;
+    if (hipMemcpyAsync(h->h_scal, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+    *relres = h->bnorm > 0.0 ? std::sqrt(h->h_scal[0]) / h->bnorm : std::sqrt(h->h_scal[0]);
+  } while (0);
+  (void)hipFree(q);
+  if (rc == OI_HIP_ERROR) oi::set_error("%s: HIP failure: %s", __func__, hipGetErrorString(hipGetLastError()));
+  return rc;
+}
+
 // checkMatrixProperties (TortuosityHypre.cpp:896-982) for the matrix-free operator: the
 // stored code of every voxel must equal the row the reference would assemble:
 //   inactive or Dirichlet cell -> identity row (code 0); the Dirichlet right-hand side
@@ -1319,6 +1356,37 @@ extern "C" oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
   OIC(ensure_device(-1, &device));
   HIPC(hipMemGetInfo(free_bytes, total_bytes));
   return OI_OK;
+}
+// time `reps` launches of the library's reference copy stream (two scratch arrays of `bytes` each, allocated here)
+extern "C" oi_status oi_dev_stream_copy_bench(size_t bytes, int reps, double* ms_per_copy) {
+  if (!ms_per_copy || reps < 1 || bytes < 4096) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  int device = 0;
+  OIC(ensure_device(-1, &device));
+  const long long nd = (long long)(bytes / 16) * 2;
+  double *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  oi_status st = OI_OK;
+  float ms = 0.f;
+  if (hipMalloc((void**)&a, nd * 8) != hipSuccess || hipMalloc((void**)&b, nd * 8) != hipSuccess) {
+    oi::set_error("%s: not enough device memory for 2 x %zu bytes", __func__, bytes);
+    (void)hipGetLastError();
+    st = OI_HIP_ERROR;
+  } else if (hipMemset(a, 0, nd * 8) != hipSuccess || hipMemset(b, 0, nd * 8) != hipSuccess ||
+             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    st = OI_HIP_ERROR;
+  } else {
+    launch_stream_copy(b, a, nd, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps; ++r) launch_stream_copy(b, a, nd, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) st = OI_HIP_ERROR;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  if (st == OI_OK) *ms_per_copy = (double)ms / reps;
+  return st;
 }
 extern "C" oi_status oi_dev_upload(void* dst, const void* src, size_t bytes) {
   HIPC(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));

@@ -55,6 +55,18 @@ def test_watchdog_prints_the_line_without_the_unfinished_extras():
     assert d["value"] > 0 and "note" in d and d["homogenization"] is None
 
 
+def test_run_watchdog_reports_a_start_that_never_finishes():
+    """The whole-run watchdog (start-up + warm-up + timed region; a collective that never returns at N > 1): ONE line with a
+    null value and a note, exit code 3, no re-exec of a process that touched the GPU."""
+    p = subprocess.run([sys.executable, "bench.py", "--size", "256", "--steps", "6", "--warmup", "2", "--run-budget-s", "0.02"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["value"] is None and "watchdog" in d["note"]
+
+
 def test_smoke_entry_point():
     p = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)

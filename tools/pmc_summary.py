@@ -25,13 +25,15 @@ def bench_name(kernel):
     """rocprof kernel name -> the kernel key bench.py uses"""
     if kernel.startswith("k_cg1"):
         return "cg1"
+    if kernel.startswith("k_apply7"):
+        return "apply"
     if kernel.startswith("k_fused_a"):
         if ", true" not in kernel:
             return "fused_a"
-        return "apply" if kernel.rstrip().endswith(", 0>") else "apply_cgvec"  # LEAN = 3: the apply on a CG vector
+        return "apply_lds" if ", 0, " in kernel else "apply_cgvec"  # LEAN = 3: the apply on a CG vector
     if kernel.startswith("k_update_xr"):
         return "update_r" if kernel.startswith("k_update_xr<false") else "update_xr"
-    if kernel.startswith("k_apply"):
+    if kernel.startswith("k_apply<") or kernel == "k_apply":
         return "apply_direct"
     if kernel.startswith("k_update_p"):
         return "update_p"
@@ -66,9 +68,12 @@ def main(out):
             if bench_name(k):
                 traffic[bench_name(k)] += v / n * 1024.0 * scale
     if traffic:
+        import hashlib
         import json
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sha = hashlib.sha256(open(os.path.join(root, "openimpala_amd", "csrc", "oi_kernels.hip"), "rb").read()).hexdigest()
         tagname = os.environ.get("OI_PMC_KEY", "1024:1")
-        js = {f"{k}:{tagname}": {"hbm_bytes_per_launch": v, "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
+        js = {f"{k}:{tagname}": {"hbm_bytes_per_launch": v, "kernels_sha256": sha, "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
                                  "separate passes, KiB -> bytes, mean over launches"} for k, v in traffic.items()}
         with open(os.path.join(out, "pmc_summary.json"), "w") as f:
             json.dump(js, f, indent=1)
