@@ -163,8 +163,8 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
                    hipStream_t s);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
-               double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
-               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
+               double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
+               double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
                hipStream_t s);
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);

@@ -1657,6 +1657,21 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
 // --------------------------------------------------------------------------------------
 enum { R1_RR = 0, R1_RZ, R1_PQ, R1_ZQ, R1_QDQ, R1_ALPHA, R1_BETA, R1_STRIDE = 8 };
 
+// From the five sums of record k (all-reduced in multi-rank runs): alpha_k, the one-step extrapolation beta_{k+1}, and the
+// convergence test on the exact ||r_k||.  Evaluated (a) by EVERY block of kernel k + 1 in its prologue -- same inputs, same
+// arithmetic, same result everywhere, so no launch sits between the reduction and the next iteration -- and (b) by
+// k_scalars1 once per host batch, so that the last record of a batch is closed too.
+struct Cg1Scalars { double alpha, beta; bool converged; };
+__device__ __forceinline__ Cg1Scalars cg1_scalars_of(const double* rk, double tol2) {
+  Cg1Scalars o;
+  o.converged = rk[R1_RR] <= tol2;
+  o.alpha = safe_div(rk[R1_RZ], rk[R1_PQ]);
+  double rz_next = rk[R1_RZ] - 2.0 * o.alpha * rk[R1_ZQ] + o.alpha * o.alpha * rk[R1_QDQ];
+  if (!(rz_next > 0.0)) rz_next = 0.0;  // cancellation at exact convergence: restart direction
+  o.beta = safe_div(rz_next, rk[R1_RZ]);
+  return o;
+}
+
 // COMPACT: r, q and p live in the COMPACTED layout -- only the aligned kLV-voxel lines (8 voxels = 64 B) that hold a free
 // voxel are stored, in (plane, row, line) order; lineoff[(gz * ny + j) * LW + line] is a line's slot (-1:
 // not stored).  Same bytes as the predicated dense layout, but contiguous in HBM.  x stays dense.
@@ -1665,9 +1680,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
                                                    const double* __restrict__ r_in, double* __restrict__ r_out,
                                                    const double* __restrict__ q_in, double* __restrict__ q_out,
                                                    const PT* __restrict__ p_in, PT* __restrict__ p_out,
-                                                   const double* __restrict__ rec, int k, int xskip, int zchunk,
+                                                   double* rec, int k, int xskip, int zchunk,
                                                    int tiles_x, int tiles_y, int nzc, int part, int partial_base,
-                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl,
+                                                   double* __restrict__ partials, Ctrl* ctrl,
                                                    const int* __restrict__ lineoff, int LW, int fullline) {
   constexpr int BY = NW * R;
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
@@ -1682,10 +1697,19 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zsel = L / (tiles_x * tiles_y);
   const int zc = part == 0 ? zsel : (part == 1 ? (zsel == 0 ? 0 : nzc - 1) : zsel + 1);
 
+  // record k - 1 is complete (kernel boundary / all-reduce): close it here instead of in a launch of its own
   double beta = 0.0, alpha_prev = 0.0, alpha_prev2 = 0.0;
   if (k > 0) {
-    alpha_prev = rec[R1_STRIDE * (k - 1) + R1_ALPHA];
-    beta = rec[R1_STRIDE * (k - 1) + R1_BETA];
+    double* rk1 = rec + R1_STRIDE * (k - 1);
+    const Cg1Scalars sc = cg1_scalars_of(rk1, ctrl->tol2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (every block holds the same values; one writes them for the host)
+      rk1[R1_ALPHA] = sc.alpha;
+      rk1[R1_BETA] = sc.beta;
+      if (sc.converged) ctrl->done = k;  // = (k - 1) + 1: iterations after which ||r|| <= tol
+    }
+    if (sc.converged) return;
+    alpha_prev = sc.alpha;
+    beta = sc.beta;
   }
   // x is touched every iteration (xskip = 0) or every second one (xskip = 1): an even kernel
   // k >= 2 adds alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}; p_{k-2} is what the p_out buffer
@@ -1897,9 +1921,9 @@ void tune_set_cg1_tile(Tune& t, int tile_rows) {
 
 template <int R, int NW, typename PT, bool JAC, bool COMPACT>
 static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
-                         const double* q_in, double* q_out, const void* p_in, void* p_out, const double* rec, int k,
+                         const double* q_in, double* q_out, const void* p_in, void* p_out, double* rec, int k,
                          int zchunk, int tiles_x, int tiles_y, int nzc, int part, int partial_base, double* partials,
-                         const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+                         Ctrl* ctrl, const int* lineoff, hipStream_t s) {
   hipLaunchKernelGGL((k_cg1<R, NW, PT, JAC, COMPACT>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in,
                      q_out, (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
                      partial_base, partials, ctrl, lineoff, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
@@ -1907,8 +1931,8 @@ static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double*
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                          const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
-                         const double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, int part,
-                         int partial_base, double* partials, const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+                         double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, int part,
+                         int partial_base, double* partials, Ctrl* ctrl, const int* lineoff, hipStream_t s) {
 #define OI_CG1K(JAC, CMP)                                                                                              \
   launch_cg1_k<R, NW, PT, JAC, CMP>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, \
                                     tiles_y, nzc, part, partial_base, partials, ctrl, lineoff, s)
@@ -1922,8 +1946,8 @@ static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double*
 // launch can hide the plane exchange.  Returns the number of blocks launched; they write
 // partials [partial_base, partial_base + blocks).
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
-               double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, const double* rec, int k,
-               double* partials, const Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
+               double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
+               double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
                hipStream_t s) {
   // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
   // off on large planes; locals only, handles may be driven from several host threads
@@ -1966,12 +1990,10 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
 // after the 5 sums of kernel k are in rec[k] (all-reduced in multi-rank runs): convergence
 // test on the exact ||r_k||, alpha_k, and beta_{k+1} from the one-step extrapolation
 __device__ __forceinline__ void cg1_scalars(double* rk, Ctrl* ctrl, int k) {
-  if (!ctrl->done && rk[R1_RR] <= ctrl->tol2) { ctrl->done = k + 1; }
-  const double alpha = safe_div(rk[R1_RZ], rk[R1_PQ]);
-  double rz_next = rk[R1_RZ] - 2.0 * alpha * rk[R1_ZQ] + alpha * alpha * rk[R1_QDQ];
-  if (!(rz_next > 0.0)) rz_next = 0.0;  // cancellation at exact convergence: restart direction
-  rk[R1_ALPHA] = alpha;
-  rk[R1_BETA] = safe_div(rz_next, rk[R1_RZ]);
+  const Cg1Scalars sc = cg1_scalars_of(rk, ctrl->tol2);
+  if (!ctrl->done && sc.converged) { ctrl->done = k + 1; }
+  rk[R1_ALPHA] = sc.alpha;
+  rk[R1_BETA] = sc.beta;
 }
 
 // one wave per component: lane l adds partials l, l+64, ... in order, then a shuffle tree --

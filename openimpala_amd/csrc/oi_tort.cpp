@@ -66,7 +66,8 @@ struct oi_tort {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t comm_stream = nullptr;         // ghost-plane exchange of the single-kernel variant
-  hipEvent_t ev_boundary = nullptr, ev_exchanged = nullptr;
+  hipStream_t aux_stream = nullptr;          // interior chunks of a slab with neighbours, beside the boundary chunks
+  hipEvent_t ev_boundary = nullptr, ev_exchanged = nullptr, ev_start = nullptr, ev_interior = nullptr;
 
   // device memory
   uint64_t *open = nullptr, *active = nullptr /* reach_lo, then the mask */, *rhi = nullptr;
@@ -210,8 +211,11 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   for (void* d : pin)
     if (d) (void)hipHostFree(d);
   if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
   if (h->ev_boundary) (void)hipEventDestroy(h->ev_boundary);
   if (h->ev_exchanged) (void)hipEventDestroy(h->ev_exchanged);
+  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_interior) (void)hipEventDestroy(h->ev_interior);
   if (h->mg) oi::mg_destroy(h->mg);
   if (h->z) (void)hipFree(h->z);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -257,6 +261,36 @@ static oi_status exchange_cg_vec(oi_tort* h, void* base, size_t elem, hipStream_
                              le * (pf[g.nzl + 2] - pf[g.nzl + 1]), s);
 }
 
+// Compacted planes travel as line lists whose length every rank derives from its OWN copy of the code bytes (ghost planes
+// included).  exchange_v skips zero-length messages on each side independently, so neighbours that disagreed on a length
+// would dead-lock the send/recv group: prove the agreement once, at set-up.  Every rank sends each neighbour {lines it
+// will send, lines it expects} and compares; the verdict is max-reduced so that all ranks fail together.
+static oi_status check_plane_message_lengths(oi_tort* h, hipStream_t s) {
+  if (!h->comm) return OI_OK;
+  const Geom& g = h->g;
+  const std::vector<long long>& pf = h->plane_first;
+  unsigned long long* d = h->counters;  // 8 device words: [0,1] to below, [2,3] from below, [4,5] to above, [6,7] from above
+  unsigned long long host[8] = {(unsigned long long)(pf[2] - pf[1]), (unsigned long long)(pf[1] - pf[0]), 0, 0,
+                                (unsigned long long)(pf[g.nzl + 1] - pf[g.nzl]), (unsigned long long)(pf[g.nzl + 2] - pf[g.nzl + 1]), 0, 0};
+  HIPC(hipMemcpyAsync(d, host, sizeof host, hipMemcpyHostToDevice, s));
+  OIC(h->comm->exchange(d + 0, d + 2, d + 4, d + 6, 2 * sizeof(unsigned long long), s));
+  unsigned long long back[8];
+  HIPC(hipMemcpyAsync(back, d, sizeof back, hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipMemsetAsync(d, 0, sizeof host, s));  // (the counters are reused by the set-up passes that follow)
+  int bad = 0;
+  if (h->comm->rank > 0 && (back[2] != host[1] || back[3] != host[0])) bad = 1;                   // below: its send = my expect, ...
+  if (h->comm->rank < h->comm->size - 1 && (back[6] != host[5] || back[7] != host[4])) bad = 1;  // above
+  OIC(h->comm->allreduce_max_i32_host(&bad, 1, s));
+  if (bad) {
+    oi::set_error("slab %d of %d: neighbours disagree on the stored-line count of a ghost plane (send %llu / expect %llu below, "
+                  "send %llu / expect %llu above; they report %llu / %llu and %llu / %llu)", h->comm->rank, h->comm->size, host[0], host[1],
+                  host[4], host[5], back[2], back[3], back[6], back[7]);
+    return OI_BAD_ARG;
+  }
+  return OI_OK;
+}
+
 extern "C" int oi_tort_line_voxels(void) { return oi::kLV; }
 // Process DEFAULTS of the launch shapes and layouts: a handle copies them when it is created (oi::Tune in its
 // Geom) and is not touched by later calls; oi_tort_retune re-reads them for one handle.
@@ -277,8 +311,11 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   hipStream_t s = h->stream;
   if (h->comm) {
     HIPC(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPC(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     HIPC(hipEventCreateWithFlags(&h->ev_boundary, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_exchanged, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_interior, hipEventDisableTiming));
   }
 
   OIC(dmalloc(h, &h->open, (size_t)g.nwords));
@@ -396,6 +433,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
       h->plane_first.resize((size_t)g.nzl + 3);
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
       h->nvec_cg = std::max<long long>(16, (long long)oi::kLV * h->plane_first[g.nzl + 2]);
+      OIC(check_plane_message_lengths(h, s));
     }
   }
   OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
@@ -645,31 +683,34 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
                         h->partials, h->ctrl, 0, 0, 0, h->lineoff, s);
       }
       if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
-      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 1, s); }
+      // (alpha_k, beta_{k+1} and the stop test are formed in the prologue of kernel k + 1; cg_iterate closes the last record)
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 0, s); }
     } else {
-      // slab with neighbours: the two boundary chunks first, their q planes travel on the comm
-      // stream (RCCL point-to-point over xGMI) while the interior chunks march on the solver stream
+      // slab with neighbours: the two boundary chunks and the interior chunks are two launches on two streams that run
+      // SIDE BY SIDE (neither depends on the other; back to back on one stream each pays its own ramp-up and tail: 1.18
+      // against 1.03 ms at 128 planes).  The boundary chunks' q planes travel on the comm stream (RCCL point-to-point over
+      // xGMI) as soon as THAT launch is done, while the interior chunks still march.
       int nb_b, nb_i;
       {
-        PROF(K_CG1);
+        PROF(K_CG1);  // one scope over both launches: the time until both have finished
+        HIPC(hipEventRecord(h->ev_start, s));
+        HIPC(hipStreamWaitEvent(h->aux_stream, h->ev_start, 0));
         nb_b = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
                           h->partials, h->ctrl, 1, 1, 0, h->lineoff, s);
-      }
-      HIPC(hipEventRecord(h->ev_boundary, s));
-      // (a transport whose exchange may not overlap its own collectives keeps everything on the solver stream)
-      hipStream_t xs = h->comm->exchange_overlaps ? h->comm_stream : s;
-      HIPC(hipStreamWaitEvent(xs, h->ev_boundary, 0));
-      OIC(exchange_cg_vec(h, qb[out], sizeof(double), xs));  // the ONE plane exchange per iteration
-      HIPC(hipEventRecord(h->ev_exchanged, xs));
-      {
-        PROF(K_CG1);
+        HIPC(hipEventRecord(h->ev_boundary, s));
         nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 2, nb_b, h->lineoff, s);
+                          h->partials, h->ctrl, 1, 2, nb_b < 0 ? 0 : nb_b, h->lineoff, h->aux_stream);
+        HIPC(hipEventRecord(h->ev_interior, h->aux_stream));
+        // (a transport whose exchange may not overlap its own collectives keeps everything on the solver stream)
+        hipStream_t xs = h->comm->exchange_overlaps ? h->comm_stream : s;
+        HIPC(hipStreamWaitEvent(xs, h->ev_boundary, 0));
+        OIC(exchange_cg_vec(h, qb[out], sizeof(double), xs));  // the ONE plane exchange per iteration
+        HIPC(hipEventRecord(h->ev_exchanged, xs));
+        HIPC(hipStreamWaitEvent(s, h->ev_interior, 0));
       }
       if (nb_b < 0 || nb_i < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s); }
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
-      launch_scalars1(rk, h->ctrl, k, s);
       HIPC(hipStreamWaitEvent(s, h->ev_exchanged, 0));  // the next kernel reads the ghost planes of q
     }
   } else if (h->fused) {
@@ -754,11 +795,17 @@ extern "C" oi_status oi_tort_cg_iterate(oi_tort* h, int n) {
   if (!h->cg_active) { oi::set_error("%s: no CG run is open (oi_tort_cg_begin first)", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
   const int limit = h->maxiter + (h->cg1 ? 1 : 0);  // kernel k of the single-kernel variant completes iteration k
+  int issued = 0;
   for (int i = 0; i < n; ++i) {
     if (h->iters_issued >= limit) break;
     OIC(cg_one_iteration(h, h->iters_issued));
     ++h->iters_issued;
+    ++issued;
   }
+  // single-kernel iteration: records are closed (alpha, beta, stop test) by the NEXT kernel's prologue; close the last one
+  // of this batch here so that the host sees the flag and cg_finish finds alpha
+  if (h->cg1 && issued > 0)
+    launch_scalars1(h->rec + (size_t)kRec1Stride * (h->iters_issued - 1), h->ctrl, h->iters_issued - 1, h->stream);
   return OI_OK;
 }
 
