@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -106,8 +107,13 @@ bool read_values(const File& f, size_t entry, std::vector<uint64_t>& out) {
   if (ts == 0 || count > (1ull << 32)) return false;
   const size_t inline_bytes = f.big ? 8 : 4, val = entry + (f.big ? 12 : 8);
   size_t pos = val;
-  if (ts * count > inline_bytes) pos = f.big ? (size_t)f.u64(val) : f.u32(val);
-  if (pos + ts * count > f.d.size()) return false;
+  const uint64_t need = (uint64_t)ts * count;  // (ts <= 8, count <= 2^32: no wrap)
+  if (need > inline_bytes) {
+    const uint64_t p64 = f.big ? f.u64(val) : f.u32(val);
+    if (p64 > f.d.size()) return false;
+    pos = (size_t)p64;
+  }
+  if (need > f.d.size() || pos > f.d.size() - need) return false;  // checked form of pos + need <= size
   out.resize(count);
   for (uint64_t i = 0; i < count; ++i) {
     if (ts == 1) out[i] = f.d[pos + i];
@@ -371,7 +377,7 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
       const size_t rows_here = pg.tiled ? ch : std::min(ch, H - cy * ch);
       const size_t expect = row_bytes * rows_here;
       const uint64_t o = pg.offs[ci], n = pg.counts[ci];
-      if (o + n > f.d.size()) { oi::set_error("'%s': chunk outside file", path); return OI_IO_ERROR; }
+      if (n > f.d.size() || o > f.d.size() - n) { oi::set_error("'%s': chunk outside file", path); return OI_IO_ERROR; }  // (o + n may wrap)
       const uint8_t* src = f.d.data() + o;
       size_t avail = n;
       if (pg.comp != 1 || pg.predictor == 2) {
@@ -450,10 +456,19 @@ extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int
   const Ifd& p0 = pages[0];
   if ((st = check_first_page(path, p0)) != OI_OK) return st;
   const size_t W = p0.w, H = p0.h, D = pages.size();
+  // dimensions come from the file: they must fit the int interface and their product must not wrap before malloc sees it
+  if (W == 0 || H == 0 || W > (size_t)INT_MAX || H > (size_t)INT_MAX || D > (size_t)INT_MAX || W > SIZE_MAX / H) {
+    oi::set_error("'%s': image dimensions %zu x %zu x %zu are out of range", path, W, H, D);
+    return OI_IO_ERROR;
+  }
   if (nz_local < 0) nz_local = (int)D - z0;
   if (nz_local < 1 || (size_t)z0 + (size_t)nz_local > D) {
     oi::set_error("'%s': planes [%d, %d) are outside the stack of %zu", path, z0, z0 + nz_local, D);
     return OI_BAD_ARG;
+  }
+  if (W * H > SIZE_MAX / (size_t)nz_local) {
+    oi::set_error("'%s': %zu x %zu x %d voxels overflow the address space", path, W, H, nz_local);
+    return OI_IO_ERROR;
   }
   uint8_t* out = (uint8_t*)malloc(W * H * (size_t)nz_local);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
@@ -516,6 +531,12 @@ extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_fil
     if (st == OI_OK && k == 0) {
       p0 = pages[0];
       st = check_first_page(name.c_str(), p0);
+      if (st == OI_OK && (p0.w == 0 || p0.h == 0 || p0.w > (size_t)INT_MAX || p0.h > (size_t)INT_MAX ||
+                          (size_t)p0.w > SIZE_MAX / (size_t)p0.h || (size_t)p0.w * p0.h > SIZE_MAX / (size_t)num_files)) {
+        oi::set_error("'%s': image dimensions %llu x %llu x %d are out of range", name.c_str(), (unsigned long long)p0.w,
+                      (unsigned long long)p0.h, num_files);
+        st = OI_IO_ERROR;
+      }
       if (st == OI_OK) {
         out = (uint8_t*)malloc((size_t)p0.w * p0.h * (size_t)num_files);
         if (!out) { oi::set_error("out of memory"); st = OI_IO_ERROR; }

@@ -354,7 +354,12 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   { PROF(K_SEED); launch_seed(g, h->open, h->active, h->rhi, s); }
   const int sweeps_per_round = 8;
   int sweeps = 0;
-  const long long max_rounds = 4LL * ((long long)g.nx + g.ny + g.nz) + 64;
+  // Run to the fixed point, always: the fill is monotone (a round either claims a voxel or is the last), so it ends after at
+  // most one round per voxel.  The reference caps its sweeps at nx + ny + nz + 2 and only warns (:328,382); a cap here
+  // would silently hand an incomplete mask -- wrong active_vf and tau with status OK -- to serpentine paths that cross
+  // slab boundaries once per round.  The bound below is a guard against a broken transport, not a budget: it is an error.
+  const long long max_rounds = (long long)g.nx * g.ny * g.nz + 8;
+  bool fixed_point = false;
   for (long long round = 0; round < max_rounds; ++round) {
     HIPC(hipMemsetAsync(h->changed, 0, sizeof(int), s));
     OIC(exchange_planes(h, h->active, sizeof(uint64_t) * g.wplane));
@@ -368,7 +373,11 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     HIPC(hipStreamSynchronize(s));
     int ch = *h->h_changed;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&ch, 1, s));
-    if (!ch) break;
+    if (!ch) { fixed_point = true; break; }
+  }
+  if (!fixed_point) {
+    oi::set_error("flood fill did not reach its fixed point within %lld rounds (one per voxel): transport failure?", max_rounds);
+    return OI_HIP_ERROR;
   }
   h->st.flood_sweeps = sweeps;
   OIC(exchange_planes(h, h->active, sizeof(uint64_t) * g.wplane));

@@ -173,3 +173,24 @@ def test_slabs_multigrid_compacted_lines(sample_phase, goldens, nranks):
     assert outs[0]["tau"] == pytest.approx(g["tau"][2], rel=1e-7)
     assert outs[0]["tau"] == pytest.approx(tau1, rel=1e-8)
     assert abs(outs[0]["st"]["iterations"] - it1) <= 2
+
+
+def test_serpentine_path_across_many_thin_slabs_reaches_the_fixed_point():
+    """A single pore channel that snakes up and down in z while it advances in x crosses every slab boundary once per
+    wall; reachability moves across a boundary only once per flood round, so 12 slabs x 200 walls need ~2200 rounds --
+    more than the 4 (nx + ny + nz) + 64 = 1776 a capped fill would allow.  The fill runs to its fixed point: the whole
+    channel is active on every slab, and the solve sees one long 1-voxel-wide conductor."""
+    nx, ny, nz, nranks = 401, 3, 24, 12
+    phase = np.zeros((nz, ny, nx), np.uint8)
+    phase[:, 1, 0::2] = 1                      # vertical shafts at even x
+    for m, i in enumerate(range(1, nx, 2)):    # joined alternately at the top and at the bottom
+        phase[0 if m % 2 else nz - 1, 1, i] = 1
+    n_path = int(phase.sum())
+    single = oia.TortuosityMI355(phase, 1, 0, eps=1e-9, precond=oia.PRECOND_JACOBI, kernel=oia.KERNEL_FUSED1)
+    assert single.stats().n_active == n_path and np.array_equal(single.mask(), phase)
+    single.destroy()
+    outs = run_slabs(phase, 1, 0, nranks, eps=1e-9, precond=oia.PRECOND_JACOBI, kernel=oia.KERNEL_FUSED1, maxiter=20)
+    mask = np.concatenate([r["mask"] for r in outs])
+    assert np.array_equal(mask, phase)
+    assert all(r["st"]["n_active"] == n_path for r in outs)
+    assert all(r["st"]["flood_sweeps"] > 8 * 1776 for r in outs)

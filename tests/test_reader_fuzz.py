@@ -65,3 +65,45 @@ def test_corrupted_hdf5_files_are_errors(tmp_path):
     h5write.write_h5(str(a), arr)
     h5write.write_h5(str(b), arr, chunks=(4, 10, 14), gzip=True, shuffle=True)
     run_batch(tmp_path, "hdf5", "image", [a.read_bytes(), b.read_bytes()], 45)
+
+
+def _classic_tiff(width, height, strip_offset, strip_bytes, bps=1, pages=1):
+    """Minimal little-endian TIFF whose directory CLAIMS the given geometry (values are not made consistent on purpose)."""
+    import struct
+    out = bytearray(b"II*\x00" + struct.pack("<I", 8))
+    for k in range(pages):
+        tags = [(256, 4, 1, width), (257, 4, 1, height), (258, 3, 1, bps), (259, 3, 1, 1), (262, 3, 1, 1),
+                (273, 4, 1, strip_offset), (277, 3, 1, 1), (278, 4, 1, height), (279, 4, 1, strip_bytes)]
+        ifd = struct.pack("<H", len(tags)) + b"".join(struct.pack("<HHII", *t) for t in tags)
+        nxt = len(out) + len(ifd) + 4 if k + 1 < pages else 0
+        out += ifd + struct.pack("<I", nxt)
+    return bytes(out) + b"\x00" * 64
+
+
+def _bigtiff(width, height, strip_offset, strip_bytes):
+    import struct
+    out = bytearray(b"II+\x00" + struct.pack("<HHQ", 8, 0, 16))
+    tags = [(256, 16, 1, width), (257, 16, 1, height), (258, 3, 1, 8), (259, 3, 1, 1), (262, 3, 1, 1),
+            (273, 16, 1, strip_offset), (277, 3, 1, 1), (278, 16, 1, height), (279, 16, 1, strip_bytes)]
+    out += struct.pack("<Q", len(tags)) + b"".join(struct.pack("<HHQQ", *t) for t in tags) + struct.pack("<Q", 0)
+    return bytes(out) + b"\x00" * 64
+
+
+def test_crafted_tiff_headers_are_refused(tmp_path):
+    """64-bit values taken from the file must not wrap: W = H = 2^31 over 4 pages multiplies to 0 bytes, a LONG8 strip
+    offset near 2^64 plus its byte count wraps below the file size.  libtiff validates these fields for the reference."""
+    cases = {
+        "huge_dims.tif": _classic_tiff(2 ** 31, 2 ** 31, 8, 16, pages=4),
+        "huge_width.tif": _classic_tiff(2 ** 32 - 1, 3, 8, 16),
+        "zero_height.tif": _classic_tiff(16, 0, 8, 16),
+        "strip_past_end.tif": _classic_tiff(16, 16, 2 ** 32 - 8, 32, bps=8),
+        "big_wrap.tif": _bigtiff(16, 16, 2 ** 64 - 8, 256),
+        "big_dims.tif": _bigtiff(2 ** 40, 2 ** 40, 16, 16),
+    }
+    paths = []
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        paths.append(str(tmp_path / name))
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, "tiff", "-"] + paths, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("batch done"), (r.returncode, r.stderr[-500:])
+    assert r.stdout.split()[:len(cases)] == ["err"] * len(cases), r.stdout
