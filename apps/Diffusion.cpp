@@ -126,7 +126,7 @@ int main(int argc, char* argv[]) {
     if (!in.query("threshold_val", threshold)) in.query("threshold_value", threshold);
     in.query("phase_id", phase_id);
     in.query("solver_type", solver_str);
-    in.query("box_size", box_size);  // AMReX max grid size: meaningless for a flat array, accepted
+    in.query("box_size", box_size);  // AMReX max grid size: only the remspot filter depends on it (it runs per box)
     in.query("verbose", verbose);
     in.query("write_plotfile", write_plotfile);
     in.query("calculation_method", method);
@@ -325,6 +325,7 @@ int main(int argc, char* argv[]) {
     int tverbose = verbose;
     in.query("tortuosity.verbose", tverbose);
     in.query("tortuosity.remspot_passes", opts.remspot_passes);
+    opts.remspot_box_size = box_size;  // the filter runs per box of ba.maxSize(box_size), as in the reference
     // default: the multigrid cycle (the role of SMG in the reference's FlexGMRES, tens of iterations);
     // jacobi / none select the plain single-kernel CG iteration (O(10 N) iterations)
     std::string precond = "mg", kernel = "auto";
@@ -353,7 +354,6 @@ int main(int argc, char* argv[]) {
     if (ngpus > 1 && transport == "rccl" && oi_device_count() < ngpus)
       throw std::runtime_error("gpu.ngpus = " + std::to_string(ngpus) + " but only " + std::to_string(oi_device_count()) +
                                " GPU(s) are visible (gpu.transport = local runs the slabs on one GPU)");
-    if (ngpus > 1 && opts.remspot_passes > 0) throw std::runtime_error("tortuosity.remspot_passes needs gpu.ngpus = 1");
 
     if (verbose > 0) std::cout << "Calculating Volume Fraction for Phase ID: " << phase_id << "\n";
     long long phase_voxels = 0, total_voxels = 0;

@@ -62,6 +62,7 @@ int main(int argc, char* argv[]) {
     oi_tort_default_opts(&opts);
     in.query("hypre.eps", opts.eps);
     in.query("tortuosity.remspot_passes", opts.remspot_passes);
+    opts.remspot_box_size = box_size;
     opts.precond = OI_PRECOND_MG;  // one multigrid cycle per Krylov iteration, as FlexGMRES + SMG in the reference
     int hypre_maxiter = 0;
     if (in.query("hypre.maxiter", hypre_maxiter) && hypre_maxiter > 0) opts.maxiter = hypre_maxiter;  // counts the same kind of iteration
@@ -81,7 +82,7 @@ int main(int argc, char* argv[]) {
     if (verbose >= 1)
       std::cout << "\n--- Tortuosity Test Configuration ---\n  TIF File:          " << tifffile << "\n  Phase ID:          " << phase_id
                 << "\n  Direction:         " << direction_str << "\n  Solver:            " << solver_str
-                << "\n  Box Size:          " << box_size << " (ignored: no BoxArray)\n  Threshold Value:   " << threshold << "\n";
+                << "\n  Box Size:          " << box_size << " (remspot boxes only: no BoxArray)\n  Threshold Value:   " << threshold << "\n";
 
     // ---- read + threshold (:196-227) ----
     uint8_t* phase = nullptr;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OI_ABI_VERSION 1
+#define OI_ABI_VERSION 2
 
 typedef enum oi_status {
   OI_OK = 0,
@@ -68,6 +68,7 @@ typedef struct oi_tort_opts {
   int maxiter;
   int precond;        /* OI_PRECOND_* */
   int remspot_passes; /* tortuosity.remspot_passes (TortuosityHypre.cpp:254-256), default 0 */
+  int remspot_box_size; /* the inputs file's box_size (default 32): the filter runs per box, see oi_remspot; works on z-slabs */
   int verbose;        /* 0 silent .. 3 */
   int check_every;    /* host looks at the device convergence flag every this many iterations (<=0: auto) */
   int kernel;         /* OI_KERNEL_* */
@@ -148,9 +149,15 @@ oi_status oi_tort_get_mask(oi_tort* h, uint8_t* mask);
 oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phase_id, int64_t* phase_count,
                              int64_t* total_count);
 
-/* tortuosity_remspot (Tortuosity_filcc.F90:88-177), one whole-domain pass per `passes`,
- * in place on a host array (host-side: the filter is sequential by definition). */
-oi_status oi_remspot(uint8_t* phase, int nx, int ny, int nz, int passes);
+/* preconditionPhaseFab (TortuosityHypre.cpp:248-292) on a host array, in place, computed on the device: `passes` passes
+ * of tortuosity_remspot (Tortuosity_filcc.F90:88-177) over the boxes ba.maxSize(box_size) makes of the domain
+ * (Diffusion.cpp:266-268; box_size 32 is the reference's default).  The reference filters every box in place in its own
+ * fab, so a cell sees the new value of an earlier neighbour only inside its own box -- the result depends on box_size,
+ * and this entry point reproduces that dependence for ONE OpenMP thread (with several the reference's tiles race).
+ * box_size <= 0: the whole domain as one box.  Box cuts follow AMReX's BoxList::maxSize as published (AMReX itself is
+ * not available here); releases before the 2019 rewrite put the larger blocks at the high end instead, which differs
+ * only when box_size does not divide an extent. */
+oi_status oi_remspot(uint8_t* phase, int nx, int ny, int nz, int passes, int box_size);
 
 /* change hypre.eps of an existing handle (takes effect at the next solve / cg_begin) */
 oi_status oi_tort_set_eps(oi_tort* h, double eps);

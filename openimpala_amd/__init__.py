@@ -26,7 +26,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OI_LIB_PATH", os.path.join(_HERE, "libopenimpala_amd.so"))  # (override: A/B builds)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OI_OK, OI_BAD_ARG, OI_NO_PERCOLATION, OI_NOT_CONVERGED, OI_FLUX_NOT_CONSERVED = 0, 1, 2, 3, 4
 OI_HIP_ERROR, OI_RCCL_ERROR, OI_NO_DEVICE, OI_IO_ERROR = 5, 6, 7, 8
@@ -64,7 +64,7 @@ class OpenImpalaError(RuntimeError):
 
 class Opts(C.Structure):
     _fields_ = [("eps", C.c_double), ("maxiter", C.c_int), ("precond", C.c_int), ("remspot_passes", C.c_int),
-                ("verbose", C.c_int), ("check_every", C.c_int), ("kernel", C.c_int), ("profile", C.c_int),
+                ("remspot_box_size", C.c_int), ("verbose", C.c_int), ("check_every", C.c_int), ("kernel", C.c_int), ("profile", C.c_int),
                 ("device", C.c_int), ("p_storage", C.c_int)]
 
 
@@ -113,7 +113,7 @@ def lib():
     L.oi_tort_get_solution.argtypes = [vp, vp]
     L.oi_tort_get_mask.argtypes = [vp, vp]
     L.oi_volume_fraction.argtypes = [vp, C.c_size_t, i, i64p, i64p]
-    L.oi_remspot.argtypes = [vp, i, i, i, i]
+    L.oi_remspot.argtypes = [vp, i, i, i, i, i]
     L.oi_effdiff_create.argtypes = [pp, vp, i, i, i, i, C.POINTER(Opts)]
     L.oi_effdiff_create_slab.argtypes = [pp, vp, vp, i, i, i, i, i, i, i, C.POINTER(Opts)]
     L.oi_effdiff_solve.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(d)]
@@ -398,10 +398,11 @@ class VolumeFraction:
         return pc / tc if tc else 0.0
 
 
-def remspot(phase, passes=1):
+def remspot(phase, passes=1, box_size=32):
+    """preconditionPhaseFab: `passes` remspot passes per box of ba.maxSize(box_size) (<= 0: one box = the whole domain)."""
     q = np.ascontiguousarray(phase, np.uint8).copy()
     nz, ny, nx = q.shape
-    _check(lib().oi_remspot(q.ctypes.data_as(C.c_void_p), nx, ny, nz, passes))
+    _check(lib().oi_remspot(q.ctypes.data_as(C.c_void_p), nx, ny, nz, passes, int(box_size)))
     return q
 
 

@@ -205,7 +205,9 @@ void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipSt
 void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipStream_t s);
 void launch_codes_out(const Geom& g, const uint8_t* code, uint8_t* dense, hipStream_t s);
 // one relaxation sweep of the (sequentially defined) remspot pass, see oi_kernels.hip
-void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nz, int* changed, hipStream_t s);
+// (arrays with one ghost plane below and above the nzl owned planes; cut*[c] != 0: cell c starts a box along that axis)
+void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nzl, int z0, int nz, const uint8_t* cutx,
+                          const uint8_t* cuty, const uint8_t* cutz, int* changed, hipStream_t s);
 // *out += number of aligned x-groups of `group` voxels (owned planes) with at least one free voxel
 void launch_count_live_groups(const Geom& g, const uint8_t* code, int group, unsigned long long* out, hipStream_t s);
 

@@ -2272,30 +2272,39 @@ void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipS
   hipLaunchKernelGGL(k_pitch_out, dim3(cap_blocks((long long)g.nzl * g.ny * g.nx, 256, 8192)), dim3(256), 0, s, g,
                      vec, dense);
 }
-// tortuosity_remspot (Tortuosity_filcc.F90:88-177) is sequential: voxels are visited x-fastest and a
-// flip is seen by the voxels visited later.  Voxel m therefore depends on the NEW values of its -x/-y/-z
-// neighbours and the OLD values of its +x/+y/+z neighbours: a triangular system.  Sweeping
-//     cur[m] = f(old[m]; cur[m-1], cur[m-sy], cur[m-sz]; old[m+1], old[m+sy], old[m+sz])
-// in any order converges to its unique solution (= the sequential result) in as many sweeps as the
-// longest chain of flipped voxels, a handful in practice; `changed` counts the updates of a sweep.
+// tortuosity_remspot (Tortuosity_filcc.F90:88-177) as preconditionPhaseFab runs it (TortuosityHypre.cpp:264-289): every
+// box of the BoxArray is filtered IN PLACE in its own fab, x fastest, tile by tile; neighbours in other boxes are read from
+// ghost cells filled before the pass.  A voxel therefore depends on the NEW values of those of its -x/-y/-z neighbours
+// that lie in the SAME box (any tile order visits them first) and on the OLD values of everything else: a triangular
+// system.  Sweeping
+//     cur[m] = f(old[m]; cur or old [m-1], [m-sy], [m-sz]; old[m+1], old[m+sy], old[m+sz])
+// in any order converges to its unique solution (= the sequential result) in as many sweeps as the longest chain of
+// flipped voxels, a handful in practice; `changed` counts the updates of a sweep.  cutx/cuty/cutz[c] != 0 marks the first
+// cell of a box along that axis (global index); arrays carry one ghost plane below and above the nzl owned planes
+// (global planes [z0, z0 + nzl)), so a z-slab relaxes with its neighbours: `old` ghosts travel once per pass, `cur`
+// ghosts once per sweep.
 __global__ void __launch_bounds__(256) k_remspot_sweep(const uint8_t* __restrict__ old, uint8_t* __restrict__ cur, int nx,
-                                                        int ny, int nz, int* __restrict__ changed) {
-  const long long n = (long long)nx * ny * nz, sy = nx, sz = (long long)nx * ny;
+                                                        int ny, int nzl, int z0, int nz, const uint8_t* __restrict__ cutx,
+                                                        const uint8_t* __restrict__ cuty, const uint8_t* __restrict__ cutz,
+                                                        int* __restrict__ changed) {
+  const long long sy = nx, sz = (long long)nx * ny, n = sz * nzl;
   int ch = 0;
-  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(m % nx), j = (int)((m / nx) % ny), k = (int)(m / sz);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % nx), j = (int)((t / nx) % ny), kl = (int)(t / sz), k = z0 + kl;
+    const long long m = t + sz;  // (one ghost plane first)
     const uint8_t c = old[m];
-    const bool connected = (i > 0 && cur[m - 1] == c) || (i < nx - 1 && old[m + 1] == c) ||
-                           (j > 0 && cur[m - sy] == c) || (j < ny - 1 && old[m + sy] == c) ||
-                           (k > 0 && cur[m - sz] == c) || (k < nz - 1 && old[m + sz] == c);
+    const bool connected = (i > 0 && (cutx[i] ? old[m - 1] : cur[m - 1]) == c) || (i < nx - 1 && old[m + 1] == c) ||
+                           (j > 0 && (cuty[j] ? old[m - sy] : cur[m - sy]) == c) || (j < ny - 1 && old[m + sy] == c) ||
+                           (k > 0 && (cutz[k] ? old[m - sz] : cur[m - sz]) == c) || (k < nz - 1 && old[m + sz] == c);
     const uint8_t v = connected ? c : (uint8_t)(c == 0 ? 1 : 0);
     if (cur[m] != v) { cur[m] = v; ch = 1; }
   }
   if (ch) atomicOr(changed, 1);
 }
-void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nz, int* changed, hipStream_t s) {
-  hipLaunchKernelGGL(k_remspot_sweep, dim3(cap_blocks((long long)nx * ny * nz, 256, 8192)), dim3(256), 0, s, old, cur, nx,
-                     ny, nz, changed);
+void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nzl, int z0, int nz, const uint8_t* cutx,
+                          const uint8_t* cuty, const uint8_t* cutz, int* changed, hipStream_t s) {
+  hipLaunchKernelGGL(k_remspot_sweep, dim3(cap_blocks((long long)nx * ny * nzl, 256, 8192)), dim3(256), 0, s, old, cur, nx,
+                     ny, nzl, z0, nz, cutx, cuty, cutz, changed);
 }
 
 // counts the aligned groups of `group` voxels (along x, within a row) of the owned planes that hold at

@@ -228,6 +228,7 @@ extern "C" void oi_tort_default_opts(oi_tort_opts* o) {
   o->maxiter = 0;
   o->precond = OI_PRECOND_DEFAULT;  // the reference's solve is multigrid-preconditioned too
   o->remspot_passes = 0;
+  o->remspot_box_size = 32;  // the reference's default box_size (Diffusion.cpp:129, ba.maxSize)
   o->verbose = 0;
   o->check_every = 0;
   o->kernel = OI_KERNEL_AUTO;
@@ -551,28 +552,65 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
 
 // preconditionPhaseFab (TortuosityHypre.cpp:248-292): `passes` remspot passes on a private copy of the
 // phase field, on the device (dense nx*ny*nz bytes).  *out_dev is hipMalloc'ed.
-static oi_status remspot_private_copy(const uint8_t* phase, bool on_device, int nx, int ny, int nz, int passes,
-                                      int device_opt, uint8_t** out_dev) {
+// first cells of the boxes ba.maxSize(box_size) cuts an axis of n cells into (Diffusion.cpp:266-268).  AMReX 25.03 is
+// not in this image; this restates BoxList::maxSize as published (Src/Base/AMReX_BoxList.cpp): chunk and length are
+// halved while both are even, numblk = ceil(len / chunk), sz = len / numblk, extra = len % numblk, the first `extra`
+// blocks get sz + 1 (older releases chopped the larger blocks off the HIGH end; the two agree when box_size divides n).
+static void box_cut_flags(int n, int chunk, std::vector<uint8_t>& flag) {
+  flag.assign((size_t)n, 0);
+  if (chunk <= 0 || n <= chunk) return;
+  int ratio = 1, bs = chunk, nlen = n;
+  while ((bs % 2 == 0) && (nlen % 2 == 0)) { ratio *= 2; bs /= 2; nlen /= 2; }
+  const int numblk = (nlen + bs - 1) / bs, sz = nlen / numblk, extra = nlen % numblk;
+  for (int b = 1; b < numblk; ++b) flag[(size_t)(((b < extra) ? b * (sz + 1) : b * sz + extra) * ratio)] = 1;
+}
+
+// preconditionPhaseFab (TortuosityHypre.cpp:248-292): `passes` remspot passes on a private copy of the phase field, on
+// the device.  `phase` holds this rank's planes [z0, z0 + nzl) of nz (dense nx*ny*nzl bytes); with `comm` the slabs
+// relax together (ghost planes of the pre-pass field once per pass, of the relaxing field once per sweep).
+// *out_dev is hipMalloc'ed; *out_phase points at its first owned plane.
+static oi_status remspot_private_copy(oi_comm* comm, const uint8_t* phase, bool on_device, int nx, int ny, int nz, int z0,
+                                      int nzl, int passes, int box_size, int device_opt, uint8_t** out_dev,
+                                      uint8_t** out_phase) {
   int device = 0;
-  OIC(ensure_device(device_opt, &device));
-  const size_t n = (size_t)nx * ny * nz;
-  uint8_t *old = nullptr, *cur = nullptr;
+  OIC(ensure_device(comm ? comm->device : device_opt, &device));
+  if (comm && comm->size <= 1) comm = nullptr;
+  const size_t plane = (size_t)nx * ny, n = plane * (size_t)nzl, ntot = n + 2 * plane;
+  uint8_t *old = nullptr, *cur = nullptr, *cuts = nullptr;
   int *changed = nullptr, *h_changed = nullptr;
+  hipStream_t s = nullptr;
   oi_status rc = OI_OK;
+  std::vector<uint8_t> fx, fy, fz;
+  box_cut_flags(nx, box_size, fx);
+  box_cut_flags(ny, box_size, fy);
+  box_cut_flags(nz, box_size, fz);
   do {
-    if (hipMalloc((void**)&old, n) != hipSuccess || hipMalloc((void**)&cur, n) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&old, ntot) != hipSuccess || hipMalloc((void**)&cur, ntot) != hipSuccess ||
+        hipMalloc((void**)&cuts, (size_t)nx + ny + nz) != hipSuccess ||
         hipMalloc((void**)&changed, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&h_changed, sizeof(int)) != hipSuccess ||
-        hipMemcpy(old, phase, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemsetAsync(old, 0, ntot, s) != hipSuccess ||
+        hipMemcpyAsync(old + plane, phase, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(cuts, fx.data(), (size_t)nx, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(cuts + nx, fy.data(), (size_t)ny, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(cuts + nx + ny, fz.data(), (size_t)nz, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
       rc = OI_HIP_ERROR;
       break;
     }
     for (int pass = 0; pass < passes && rc == OI_OK; ++pass) {
-      if (hipMemcpy(cur, old, n, hipMemcpyDeviceToDevice) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+      // FillBoundary: the neighbours' pre-pass boundary planes
+      if (comm && (rc = comm->exchange(old + plane, old, old + plane * (size_t)nzl, old + plane * (size_t)(nzl + 1), plane, s)) != OI_OK) break;
+      if (hipMemcpyAsync(cur, old, ntot, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = OI_HIP_ERROR; break; }
       for (long long sweep = 0;; ++sweep) {
-        if (hipMemset(changed, 0, sizeof(int)) != hipSuccess) { rc = OI_HIP_ERROR; break; }
-        launch_remspot_sweep(old, cur, nx, ny, nz, changed, nullptr);
-        if (hipMemcpy(h_changed, changed, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = OI_HIP_ERROR; break; }
-        if (!*h_changed) break;
+        if (hipMemsetAsync(changed, 0, sizeof(int), s) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+        if (comm && (rc = comm->exchange(cur + plane, cur, cur + plane * (size_t)nzl, cur + plane * (size_t)(nzl + 1), plane, s)) != OI_OK) break;
+        launch_remspot_sweep(old, cur, nx, ny, nzl, z0, nz, cuts, cuts + nx, cuts + nx + ny, changed, s);
+        if (hipMemcpyAsync(h_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+        int ch = *h_changed;
+        if (comm && (rc = comm->allreduce_max_i32_host(&ch, 1, s)) != OI_OK) break;
+        if (!ch) break;
         if (sweep > (long long)nx + ny + nz + 8) { oi::set_error("remspot relaxation did not settle"); rc = OI_HIP_ERROR; break; }
       }
       std::swap(old, cur);  // the settled field is the input of the next pass
@@ -580,19 +618,23 @@ static oi_status remspot_private_copy(const uint8_t* phase, bool on_device, int 
   } while (0);
   if (rc == OI_HIP_ERROR && !*oi::last_error()) oi::set_error("remspot: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   if (cur) (void)hipFree(cur);
+  if (cuts) (void)hipFree(cuts);
   if (changed) (void)hipFree(changed);
   if (h_changed) (void)hipHostFree(h_changed);
+  if (s) (void)hipStreamDestroy(s);
   if (rc != OI_OK) { if (old) (void)hipFree(old); return rc; }
   *out_dev = old;
+  *out_phase = old + plane;
   return OI_OK;
 }
 
 static oi_status create_whole(oi_tort** out, const uint8_t* phase, bool on_device, int nx, int ny, int nz, int phase_id,
                               int dir, double vlo, double vhi, const oi_tort_opts* opts) {
   if (opts && opts->remspot_passes > 0 && phase && nx > 0 && ny > 0 && nz > 0) {
-    uint8_t* priv = nullptr;
-    OIC(remspot_private_copy(phase, on_device, nx, ny, nz, opts->remspot_passes, opts->device, &priv));
-    const oi_status st = create_common(out, nullptr, priv, true, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
+    uint8_t *priv = nullptr, *priv_phase = nullptr;
+    OIC(remspot_private_copy(nullptr, phase, on_device, nx, ny, nz, 0, nz, opts->remspot_passes, opts->remspot_box_size,
+                             opts->device, &priv, &priv_phase));
+    const oi_status st = create_common(out, nullptr, priv_phase, true, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
     (void)hipFree(priv);
     return st;
   }
@@ -613,9 +655,14 @@ extern "C" oi_status oi_tort_create_device(oi_tort** out, const uint8_t* phase_d
 extern "C" oi_status oi_tort_create_slab(oi_tort** out, oi_comm* comm, const uint8_t* phase, int on_device,
                                          int nx, int ny, int nz_global, int z0, int nz_local, int phase_id,
                                          int dir, double vlo, double vhi, const oi_tort_opts* opts) {
-  if (opts && opts->remspot_passes > 0 && comm && comm->size > 1) {
-    oi::set_error("remspot is defined on the whole domain (sequential); run it before slabbing");
-    return OI_BAD_ARG;
+  if (opts && opts->remspot_passes > 0 && phase && nx > 0 && ny > 0 && nz_local > 0 && z0 >= 0 && z0 + nz_local <= nz_global) {
+    // every rank filters its slab; boxes that straddle a slab boundary relax across it (collective)
+    uint8_t *priv = nullptr, *priv_phase = nullptr;
+    OIC(remspot_private_copy(comm, phase, on_device != 0, nx, ny, nz_global, z0, nz_local, opts->remspot_passes,
+                             opts->remspot_box_size, opts->device, &priv, &priv_phase));
+    const oi_status st = create_common(out, comm, priv_phase, true, nx, ny, nz_global, z0, nz_local, phase_id, dir, vlo, vhi, opts);
+    (void)hipFree(priv);
+    return st;
   }
   return create_common(out, comm, phase, on_device != 0, nx, ny, nz_global, z0, nz_local, phase_id, dir, vlo, vhi,
                        opts);
@@ -1310,12 +1357,13 @@ extern "C" oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phas
 
 // tortuosity_remspot (Tortuosity_filcc.F90:88-177) on a host array: in place, x-fastest order, one box.
 // Runs on the device like everything else (no CPU path).
-extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes) {
+extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes, int box_size) {
   if (!q || nx < 1 || ny < 1 || nz < 1 || passes < 0) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (passes == 0) return OI_OK;
   uint8_t* dev = nullptr;
-  OIC(remspot_private_copy(q, false, nx, ny, nz, passes, -1, &dev));
-  const hipError_t e = hipMemcpy(q, dev, (size_t)nx * ny * nz, hipMemcpyDeviceToHost);
+  uint8_t* dev_phase = nullptr;
+  OIC(remspot_private_copy(nullptr, q, false, nx, ny, nz, 0, nz, passes, box_size, -1, &dev, &dev_phase));
+  const hipError_t e = hipMemcpy(q, dev_phase, (size_t)nx * ny * nz, hipMemcpyDeviceToHost);
   (void)hipFree(dev);
   HIPC(e);
   return OI_OK;

@@ -178,6 +178,69 @@ void oi_oracle_remspot(uint8_t* q, int nx, int ny, int nz) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* The same filter AS THE REFERENCE RUNS IT (preconditionPhaseFab,                */
+/* src/props/TortuosityHypre.cpp:264-289): per pass, FillBoundary, then every     */
+/* box of the BoxArray -- Diffusion.cpp:266-268: ba.maxSize(box_size), box_size   */
+/* 32 by default -- is filtered IN PLACE in its own fab, tile by tile             */
+/* (MFIter with TilingIfNotGPU; AMReX's default tile is 1024000 x 8 x 8 cells).   */
+/* A cell therefore sees the NEW value of a neighbour that lies in the SAME box   */
+/* and was visited earlier, and the value from BEFORE the pass (the fab's ghost   */
+/* cells) of a neighbour in another box.  One OpenMP thread: with several, tiles  */
+/* of a box run concurrently and the reference's own result is a race.            */
+/* Box cuts: AMReX 25.03's BoxList::maxSize (third party, not in this image) as   */
+/* published in Src/Base/AMReX_BoxList.cpp: per axis, halve chunk and length     */
+/* while both are even (ratio), numblk = ceil(len / chunk), sz = len / numblk,    */
+/* extra = len % numblk; block b spans [(b < extra ? b (sz+1) : b sz + extra),    */
+/* ...) x ratio -- the larger blocks first.  (Older AMReX releases chopped from   */
+/* the high end, i.e. larger blocks last; the two agree whenever box_size divides */
+/* the extent.)                                                                   */
+/* ------------------------------------------------------------------------- */
+int oi_oracle_box_cuts(int n, int chunk, int* first /* >= n + 1 ints: first cell of each block, then n */) {
+  if (chunk <= 0 || n <= chunk) { first[0] = 0; first[1] = n; return 1; }
+  int ratio = 1, bs = chunk, nlen = n;
+  while ((bs % 2 == 0) && (nlen % 2 == 0)) { ratio *= 2; bs /= 2; nlen /= 2; }
+  const int numblk = (nlen + bs - 1) / bs, sz = nlen / numblk, extra = nlen % numblk;
+  for (int b = 0; b <= numblk; ++b) first[b] = ((b < extra) ? b * (sz + 1) : b * sz + extra) * ratio;
+  return numblk;
+}
+
+void oi_oracle_remspot_boxes(uint8_t* q, int nx, int ny, int nz, int box_size) {
+  const i64 n = (i64)nx * ny * nz;
+  uint8_t* old = (uint8_t*)malloc((size_t)n); /* what FillBoundary put into every fab's ghost cells */
+  memcpy(old, q, (size_t)n);
+  int* cx = (int*)malloc(sizeof(int) * (size_t)(nx + 2));
+  int* cy = (int*)malloc(sizeof(int) * (size_t)(ny + 2));
+  int* cz = (int*)malloc(sizeof(int) * (size_t)(nz + 2));
+  const int nbx = oi_oracle_box_cuts(nx, box_size, cx), nby = oi_oracle_box_cuts(ny, box_size, cy),
+            nbz = oi_oracle_box_cuts(nz, box_size, cz);
+  const int tile = 8; /* FabArrayBase::mfiter_tile_size = (1024000, 8, 8) */
+  for (int bz = 0; bz < nbz; ++bz)
+    for (int by = 0; by < nby; ++by)
+      for (int bx = 0; bx < nbx; ++bx) {
+        const int x0 = cx[bx], x1 = cx[bx + 1], y0 = cy[by], y1 = cy[by + 1], z0 = cz[bz], z1 = cz[bz + 1];
+        /* value of a neighbour as this box's fab holds it: in place inside the box, ghost (pre-pass) outside */
+#define FABVAL(i, j, k) (((i) >= x0 && (i) < x1 && (j) >= y0 && (j) < y1 && (k) >= z0 && (k) < z1) ? q[IDX(i, j, k)] : old[IDX(i, j, k)])
+        for (int tz = z0; tz < z1; tz += tile)
+          for (int ty = y0; ty < y1; ty += tile)
+            for (int k = tz; k < tz + tile && k < z1; ++k)
+              for (int j = ty; j < ty + tile && j < y1; ++j)
+                for (int i = x0; i < x1; ++i) {
+                  const uint8_t c = q[IDX(i, j, k)];
+                  int connected = 0;
+                  if (i > 0 && FABVAL(i - 1, j, k) == c) connected = 1;
+                  if (i < nx - 1 && FABVAL(i + 1, j, k) == c) connected = 1;
+                  if (j > 0 && FABVAL(i, j - 1, k) == c) connected = 1;
+                  if (j < ny - 1 && FABVAL(i, j + 1, k) == c) connected = 1;
+                  if (k > 0 && FABVAL(i, j, k - 1) == c) connected = 1;
+                  if (k < nz - 1 && FABVAL(i, j, k + 1) == c) connected = 1;
+                  if (!connected) q[IDX(i, j, k)] = (c == 0) ? 1 : 0;
+                }
+#undef FABVAL
+      }
+  free(old); free(cx); free(cy); free(cz);
+}
+
+/* ------------------------------------------------------------------------- */
 /* parallelFloodFill   (src/props/TortuosityHypre.cpp:297-389): 6-connected      */
 /* reachability from the seed cells, restricted to phase == phase_id.  The      */
 /* reference sweeps to a fixed point (<= nx+ny+nz+2 sweeps); the fixed point is */

@@ -69,6 +69,9 @@ def lib():
         L.oi_oracle_gen_blobs.argtypes = [_u8p, i, i, i, u64, i, u64]
         L.oi_oracle_volume_fraction.argtypes = [_u8p, ll, i, C.POINTER(ll), C.POINTER(ll)]
         L.oi_oracle_remspot.argtypes = [_u8p, i, i, i]
+        L.oi_oracle_remspot_boxes.argtypes = [_u8p, i, i, i, i]
+        L.oi_oracle_box_cuts.argtypes = [i, i, C.POINTER(i)]
+        L.oi_oracle_box_cuts.restype = i
         L.oi_oracle_active_mask.argtypes = [_u8p, i, i, i, i, i, _u8p]
         L.oi_oracle_active_mask.restype = ll
         L.oi_oracle_fillmtx.argtypes = [_u8p, _u8p, i, i, i, i, i, _f64p, d, d, _f64p, _f64p, _f64p]
@@ -144,12 +147,22 @@ def volume_fraction(phase, phase_id):
     return pc.value, tc.value
 
 
-def remspot(phase, passes=1):
+def remspot(phase, passes=1, box_size=0):
+    """box_size <= 0: the whole domain as one box; > 0: per box of ba.maxSize(box_size), as the reference runs it."""
     q = np.ascontiguousarray(phase, np.uint8).copy()
     nx, ny, nz = _dims(q)
     for _ in range(passes):
-        lib().oi_oracle_remspot(q, nx, ny, nz)
+        if box_size > 0:
+            lib().oi_oracle_remspot_boxes(q, nx, ny, nz, int(box_size))
+        else:
+            lib().oi_oracle_remspot(q, nx, ny, nz)
     return q
+
+
+def box_cuts(n, chunk):
+    first = (C.c_int * (n + 2))()
+    nb = lib().oi_oracle_box_cuts(int(n), int(chunk), first)
+    return [first[b] for b in range(nb + 1)]
 
 
 def active_mask(phase, phase_id, direction):

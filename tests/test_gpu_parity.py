@@ -241,7 +241,7 @@ def test_value_caches_and_refreshes(sample):
 
 def test_remspot_option_matches_oracle(sample):
     sub = np.ascontiguousarray(sample[:30, :30, :30])
-    ref = o.tortuosity(o.remspot(sub, 1), 1, 0, eps=1e-10)
+    ref = o.tortuosity(o.remspot(sub, 1, box_size=32), 1, 0, eps=1e-10)  # (30^3 < 32: one box either way)
     t = oia.TortuosityMI355(sub, 1, 0, eps=1e-10, remspot_passes=1)
     assert t.value() == pytest.approx(ref["tau"], rel=1e-8)
 
@@ -540,10 +540,22 @@ def test_remspot_on_the_device_equals_the_sequential_pass():
             want = ph.copy()
             for _ in range(passes):
                 want = o.remspot(want)
-            assert np.array_equal(oia.remspot(ph, passes), want), (shape, passes)
+            assert np.array_equal(oia.remspot(ph, passes, box_size=0), want), (shape, passes)
     k, j, i = np.indices((9, 11, 13))
     board = ((i + j + k) & 1).astype(np.uint8)
-    assert np.array_equal(oia.remspot(board, 1), o.remspot(board))
+    assert np.array_equal(oia.remspot(board, 1, box_size=0), o.remspot(board))
+    # as the reference runs it: per box of ba.maxSize(box_size), in place inside a box, pre-pass values across boxes.
+    # Extents that box_size does not divide (100 -> 28 + 24 + 24 + 24), checkerboards (every voxel flips: the result
+    # depends on every box boundary), several passes
+    assert o.box_cuts(100, 32) == [0, 28, 52, 76, 100] and o.box_cuts(64, 32) == [0, 32, 64] and o.box_cuts(30, 32) == [0, 30]
+    assert o.box_cuts(70, 32) == [0, 24, 48, 70]
+    for shape, box in (((45, 70, 100), 32), ((40, 33, 65), 16), ((9, 11, 13), 4), ((20, 20, 20), 8)):
+        for ph in (o.gen_bernoulli(shape, 11, 0.5), (np.indices(shape).sum(0) & 1).astype(np.uint8)):
+            for passes in (1, 2):
+                want = o.remspot(ph, passes, box_size=box)
+                assert np.array_equal(oia.remspot(ph, passes, box_size=box), want), (shape, box, passes)
+    noise = o.gen_bernoulli((45, 70, 100), 11, 0.5)
+    assert not np.array_equal(o.remspot(noise, 1, box_size=32), o.remspot(noise, 1))  # the box decomposition matters
     # through the solver's constructor (host and device entry points): same mask as the oracle after the pass
     ph = o.gen_bernoulli((24, 28, 32), 3, 0.6)
     clean = o.remspot(ph)

@@ -194,3 +194,19 @@ def test_serpentine_path_across_many_thin_slabs_reaches_the_fixed_point():
     assert np.array_equal(mask, phase)
     assert all(r["st"]["n_active"] == n_path for r in outs)
     assert all(r["st"]["flood_sweeps"] > 8 * 1776 for r in outs)
+
+
+@pytest.mark.parametrize("nranks,box", [(2, 32), (3, 16), (4, 8)])
+def test_remspot_on_slabs_equals_the_single_domain(nranks, box):
+    """preconditionPhaseFab runs on every rank of the reference; boxes that straddle a slab boundary relax across it
+    (ghost planes of the relaxing field travel every sweep).  Same mask and answer as the single-domain handle and as
+    the oracle's box-wise pass."""
+    phase = o.gen_bernoulli((44, 40, 52), 17, 0.62)
+    clean = o.remspot(phase, 2, box_size=box)
+    ref = o.tortuosity(clean, 1, 2, eps=1e-10)
+    outs = run_slabs(phase, 1, 2, nranks, eps=1e-10, remspot_passes=2, remspot_box_size=box, precond=oia.PRECOND_JACOBI,
+                     kernel=oia.KERNEL_FUSED1)
+    mask = np.concatenate([r["mask"] for r in outs])
+    assert np.array_equal(mask, ref["mask"])
+    assert all(r["status"] == oia.OI_OK for r in outs)
+    assert outs[0]["tau"] == pytest.approx(ref["tau"], rel=1e-8)
