@@ -322,8 +322,13 @@ oi_status oi_read_raw(const char* path, int nx, int ny, int nz, int dtype, doubl
                       uint8_t** phase);
 oi_status oi_read_raw_planes(const char* path, int nx, int ny, int nz, int dtype, double threshold, int z0, int nz_local,
                              uint8_t** phase);
-/* HDF5Reader::threshold (HDF5Reader.cpp:111-187,333-402): rank-3 dataset `dataset` (e.g. "image"),
- * dims (Z,Y,X) in C order; classic-format files, contiguous/compact/chunked, deflate + shuffle */
+/* HDF5Reader::threshold (HDF5Reader.cpp:111-187,333-402): rank-3 dataset `dataset` (e.g. "image" or "g1/g2/image"),
+ * dims (Z,Y,X) in C order.  Read straight from the file format (no libhdf5): the default ("earliest") format AND the
+ * "latest" format of HDF5 >= 1.10 / h5py libver='latest' -- superblock v0-v3, v1 / v2 object headers, symbol-table and
+ * compact-link groups, contiguous / compact / chunked layouts with v1 B-tree, single-chunk, implicit, fixed-array and
+ * extensible-array chunk indexes (filtered, paged), deflate + shuffle, (u)int8-64 / float32 / float64 of either byte
+ * order.  Refused with a message that names the feature: dense (fractal-heap) groups, v2-B-tree chunk indexes (two or
+ * more unlimited dimensions), virtual datasets, other filters. */
 oi_status oi_read_hdf5(const char* path, const char* dataset, double threshold, uint8_t** phase, int* nx, int* ny,
                        int* nz);
 /* planes [z0, z0 + nz_local) only (nz_local < 0: all from z0): the hyperslab a rank reads (HDF5Reader.cpp:255-331) */

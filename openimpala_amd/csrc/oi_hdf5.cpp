@@ -4,10 +4,13 @@
 // hyperslab reads :255-329, threshold :333-402) for the files that pipeline produces:
 // rank-3 datasets of (u)int8/16/32/64 or float32/64, dims in C order (Z, Y, X) -> X is
 // the unit-stride axis.  Implemented directly on the HDF5 file format (spec 1.x/2.0):
-// superblock v0/v1, v1 object headers (+ continuation blocks), symbol-table groups (v1
-// B-tree + local heap), contiguous, compact and chunked (v1 chunk B-tree) layouts, optional
-// deflate / shuffle filters (zlib).  "Latest format" files (superblock v2/v3, v2 object
-// headers, fractal-heap groups) are reported as unsupported, never guessed.
+// superblock v0/v1 AND v2/v3, v1 and v2 ("OHDR") object headers (+ continuation blocks), symbol-table groups (v1
+// B-tree + local heap) and new-style groups with compact link messages, contiguous, compact and chunked layouts --
+// layout message v3 (v1 chunk B-tree) and v4 (what libver = latest writes since HDF5 1.10: single-chunk, implicit,
+// fixed-array and extensible-array chunk indexes, plain and filtered entries, paged data blocks) --, optional deflate /
+// shuffle filters (zlib).  Reported as unsupported, never guessed: groups with dense link storage (fractal heap: more
+// than eight links unless the writer changed the threshold), version-2 B-tree chunk indexes (datasets with two or
+// more unlimited dimensions), virtual datasets, other filters.  Metadata checksums are not verified.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -58,6 +61,7 @@ struct Mapped {
 struct H5 {
   Mapped f;
   uint64_t base = 0;
+  int so = 8, sl = 8;  // size of offsets / lengths (superblock)
   std::string err;
 
   bool ok(uint64_t off, uint64_t n) const { return off <= f.size() && n <= f.size() - off; }
@@ -74,10 +78,47 @@ struct Msg {
   uint16_t size;
 };
 
+// version-2 object header ("OHDR", what libver = latest writes): prefix, messages of chunk 0, continuation chunks ("OCHK")
+bool read_object_header_v2(const H5& h, uint64_t addr, std::vector<Msg>& out) {
+  if (!h.ok(addr, 8) || h.f[addr + 4] != 2) return false;
+  const unsigned flags = h.f[addr + 5];
+  uint64_t p = addr + 6;
+  if (flags & 0x20) p += 16;  // access, modification, change, birth times
+  if (flags & 0x10) p += 4;   // max compact / min dense attributes
+  const int szbytes = 1 << (flags & 3);
+  if (!h.ok(p, (uint64_t)szbytes)) return false;
+  const uint64_t size0 = h.le(p, szbytes);
+  p += szbytes;
+  const uint64_t mhdr = 4 + ((flags & 0x04) ? 2 : 0);  // type 1, size 2, flags 1, [creation order 2]
+  struct Block { uint64_t off, len; };
+  std::vector<Block> blocks{{p, size0}};
+  for (size_t b = 0; b < blocks.size() && b < 4096; ++b) {
+    if (!h.ok(blocks[b].off, blocks[b].len)) return false;
+    uint64_t q = blocks[b].off;
+    const uint64_t end = blocks[b].off + blocks[b].len;
+    while (q + mhdr <= end && out.size() < 65536) {
+      Msg m;
+      m.type = h.f[q];
+      m.size = (uint16_t)h.le(q + 1, 2);
+      m.off = q + mhdr;
+      if (m.off + m.size > end) break;  // (the gap in front of the checksum)
+      if (m.type == 0x10 && m.size >= h.so + h.sl) {
+        const uint64_t coff = h.base + h.le(m.off, h.so), clen = h.le(m.off + h.so, h.sl);
+        if (clen < 8 || !h.ok(coff, clen) || memcmp(&h.f[coff], "OCHK", 4) != 0) return false;
+        blocks.push_back({coff + 4, clen - 8});  // between the signature and the checksum
+      }
+      out.push_back(m);
+      q = m.off + m.size;
+    }
+  }
+  return true;
+}
+
 // v1 object header: all messages, following continuation messages (type 0x10)
 bool read_object_header(const H5& h, uint64_t addr, std::vector<Msg>& out) {
   if (!h.ok(addr, 16)) return false;
-  if (h.f[addr] != 1) return false;  // version 2 headers start with "OHDR"
+  if (memcmp(&h.f[addr], "OHDR", 4) == 0) return read_object_header_v2(h, addr, out);
+  if (h.f[addr] != 1) return false;
   const int nmsgs = (int)h.le(addr + 2, 2);
   struct Block { uint64_t off, len; };
   std::vector<Block> blocks{{addr + 16, h.le(addr + 8, 4)}};
@@ -139,9 +180,44 @@ bool group_lookup(const H5& h, uint64_t btree, uint64_t heap, const std::string&
   return false;
 }
 
+// new-style group: a hard link called `name` among the compact Link messages (type 6) of the group's object header.
+// returns 1 found, 0 not found, -1 the group keeps its links in a fractal heap (dense storage: not read)
+int link_lookup(const H5& h, const std::vector<Msg>& msgs, const std::string& name, uint64_t& obj_addr) {
+  bool dense = false;
+  for (const Msg& m : msgs) {
+    if (m.type == 0x0002 && m.size >= 2) {  // Link Info: is there a fractal heap?
+      const unsigned fl = h.f[m.off + 1];
+      const uint64_t p = m.off + 2 + ((fl & 1) ? 8 : 0);
+      if (p + (uint64_t)h.so <= m.off + m.size && h.le(p, h.so) != (h.so == 8 ? kUndef : ((1ULL << (8 * h.so)) - 1))) dense = true;
+    }
+    if (m.type != 0x0006 || m.size < 4) continue;
+    const uint64_t end = m.off + m.size;
+    if (h.f[m.off] != 1) continue;
+    const unsigned fl = h.f[m.off + 1];
+    uint64_t p = m.off + 2;
+    unsigned ltype = 0;
+    if (fl & 0x08) ltype = h.f[p++];
+    if (fl & 0x04) p += 8;  // creation order
+    if (fl & 0x10) p += 1;  // character set
+    const int lb = 1 << (fl & 3);
+    if (p + (uint64_t)lb > end) continue;
+    const uint64_t nlen = h.le(p, lb);
+    p += lb;
+    if (nlen > end - p) continue;
+    const bool match = nlen == name.size() && memcmp(&h.f[p], name.data(), (size_t)nlen) == 0;
+    p += nlen;
+    if (match && ltype == 0 && p + (uint64_t)h.so <= end) {
+      obj_addr = h.base + h.le(p, h.so);
+      return 1;
+    }
+    if (match) return 0;  // soft / external link: not followed
+  }
+  return dense ? -1 : 0;
+}
+
 struct Dataset {
   int rank = 0;
-  uint64_t dims[4] = {0, 0, 0, 0};
+  uint64_t dims[4] = {0, 0, 0, 0}, maxdims[4] = {0, 0, 0, 0};  // maxdims: ~0 = unlimited
   int type_class = -1, type_size = 0;
   bool big_endian = false, is_signed = false;
   int layout = -1;  // 0 compact, 1 contiguous, 2 chunked
@@ -150,6 +226,10 @@ struct Dataset {
   uint64_t chunk_btree = kUndef;
   int chunk_rank = 0;  // rank + 1
   uint64_t chunk_dims[5] = {0};
+  // layout message v4: how the chunks are indexed
+  int chunk_index = 0;          // 0 = v1 B-tree (layout v3); 1 single chunk, 2 implicit, 3 fixed array, 4 extensible array, 5 v2 B-tree
+  uint64_t index_addr = kUndef; // single: the chunk; implicit: the first chunk; arrays: their header
+  uint64_t single_size = 0;     // single filtered chunk: stored size
   bool f_deflate = false, f_shuffle = false, f_other = false;
 };
 
@@ -164,6 +244,8 @@ bool parse_dataset(const H5& h, uint64_t addr, Dataset& d, std::string& why) {
       const uint64_t dimoff = o + (ver == 1 ? 8 : 4);
       if (d.rank > 4) { why = "rank > 4"; return false; }
       for (int i = 0; i < d.rank; ++i) d.dims[i] = h.le(dimoff + 8ULL * i, 8);
+      const bool has_max = h.f[o + 2] & 1;  // (same flag position in versions 1 and 2)
+      for (int i = 0; i < d.rank; ++i) d.maxdims[i] = has_max ? h.le(dimoff + 8ULL * (d.rank + i), 8) : d.dims[i];
     } else if (m.type == 0x0003) {  // datatype
       const uint32_t cv = (uint32_t)h.le(o, 4);
       d.type_class = cv & 0x0f;
@@ -173,19 +255,46 @@ bool parse_dataset(const H5& h, uint64_t addr, Dataset& d, std::string& why) {
       d.type_size = (int)h.le(o + 4, 4);
     } else if (m.type == 0x0008) {  // data layout
       const int ver = h.f[o];
-      if (ver != 3) { why = "data layout message version " + std::to_string(ver) + " (only 3 is read)"; return false; }
+      if (ver != 3 && ver != 4) { why = "data layout message version " + std::to_string(ver) + " (3 and 4 are read)"; return false; }
       d.layout = h.f[o + 1];
-      if (d.layout == 1) {
-        d.data_addr = h.le(o + 2, 8);
-        d.data_size = h.le(o + 10, 8);
+      if (ver == 4 && d.layout == 2) {  // chunked, HDF5 >= 1.10 with libver = latest
+        const unsigned cflags = h.f[o + 2];
+        d.chunk_rank = h.f[o + 3];
+        const int enc = h.f[o + 4];
+        if (d.chunk_rank > 5 || d.chunk_rank < 2 || enc < 1 || enc > 8) { why = "chunk rank / dimension encoding out of range"; return false; }
+        uint64_t q = o + 5;
+        for (int i = 0; i < d.chunk_rank; ++i, q += enc) d.chunk_dims[i] = h.le(q, enc);
+        d.chunk_index = h.f[q++];
+        if (d.chunk_index == 1) {
+          if (cflags & 0x02) { d.single_size = h.le(q, h.sl); q += h.sl + 4; }  // filtered size, filter mask
+        } else if (d.chunk_index == 3) {
+          q += 1;  // page bits (also in the array header)
+        } else if (d.chunk_index == 4) {
+          q += 5;  // max bits, index elements, min pointers, min elements, page bits (all in the array header)
+        } else if (d.chunk_index == 5) {
+          q += 6;  // node size, split %, merge %
+        } else if (d.chunk_index != 2) {
+          why = "unknown chunk indexing type " + std::to_string(d.chunk_index);
+          return false;
+        }
+        d.index_addr = h.le(q, h.so);
+        if (h.so < 8 && d.index_addr == (1ULL << (8 * h.so)) - 1) d.index_addr = kUndef;
+      } else if (ver == 4 && d.layout == 3) {
+        why = "virtual datasets are not supported";
+        return false;
+      } else if (d.layout == 1) {
+        d.data_addr = h.le(o + 2, h.so);
+        if (h.so < 8 && d.data_addr == (1ULL << (8 * h.so)) - 1) d.data_addr = kUndef;
+        d.data_size = h.le(o + 2 + h.so, h.sl);
       } else if (d.layout == 0) {
         d.data_size = h.le(o + 2, 2);
         d.compact_off = o + 4;
       } else if (d.layout == 2) {
         d.chunk_rank = h.f[o + 2];
-        d.chunk_btree = h.le(o + 3, 8);
+        d.chunk_btree = h.le(o + 3, h.so);
+        if (h.so < 8 && d.chunk_btree == (1ULL << (8 * h.so)) - 1) d.chunk_btree = kUndef;
         if (d.chunk_rank > 5) { why = "chunk rank > 5"; return false; }
-        for (int i = 0; i < d.chunk_rank; ++i) d.chunk_dims[i] = h.le(o + 11 + 4ULL * i, 4);
+        for (int i = 0; i < d.chunk_rank; ++i) d.chunk_dims[i] = h.le(o + 3 + h.so + 4ULL * i, 4);
       }
     } else if (m.type == 0x000B) {  // filter pipeline
       const int ver = h.f[o];
@@ -250,6 +359,175 @@ bool for_each_chunk(const H5& h, const Dataset& d, uint64_t node, F&& fn, int de
 }
 
 
+// ---- chunk indexes of layout message version 4 (H5Dsingle.c, H5Dnone.c, H5Dfarray.c / H5FA*.c, H5Dearray.c / H5EA*.c) ----
+// One entry of a fixed / extensible array: the chunk's address and, for filtered datasets (client id 1), its stored
+// size and filter mask.
+struct ChunkEntry { uint64_t addr = kUndef, nbytes = 0; };
+bool read_entry(const H5& h, uint64_t p, int entry_size, bool filtered, uint64_t plain_bytes, ChunkEntry& e) {
+  if (!h.ok(p, (uint64_t)entry_size)) return false;
+  e.addr = h.le(p, h.so);
+  if (h.so < 8 && e.addr == (1ULL << (8 * h.so)) - 1) e.addr = kUndef;
+  e.nbytes = plain_bytes;
+  if (filtered) {
+    const int nb = entry_size - h.so - 4;
+    if (nb < 1 || nb > 8) return false;
+    e.nbytes = h.le(p + h.so, nb);
+  }
+  return true;
+}
+// MSB-first bit of a page-initialisation bitmap (H5VM_bit_get)
+inline bool bit_msb(const H5& h, uint64_t base, uint64_t bit) { return (h.f[base + bit / 8] >> (7 - bit % 8)) & 1; }
+
+// element `idx` of a fixed array
+bool farray_get(const H5& h, uint64_t hdr, uint64_t idx, uint64_t plain_bytes, ChunkEntry& e, std::string& why) {
+  if (!h.ok(hdr, 12 + (uint64_t)h.sl + h.so) || memcmp(&h.f[hdr], "FAHD", 4) != 0) { why = "fixed-array header not found"; return false; }
+  const bool filtered = h.f[hdr + 5] == 1;
+  const int esz = h.f[hdr + 6], page_bits = h.f[hdr + 7];
+  const uint64_t nelmts = h.le(hdr + 8, h.sl);
+  uint64_t db = h.le(hdr + 8 + h.sl, h.so);
+  if (esz < h.so || page_bits > 40) { why = "fixed-array header out of range"; return false; }
+  if (idx >= nelmts || db == kUndef) { e = ChunkEntry(); return true; }  // (never written)
+  db += h.base;
+  if (!h.ok(db, 6 + (uint64_t)h.so) || memcmp(&h.f[db], "FADB", 4) != 0) { why = "fixed-array data block not found"; return false; }
+  const uint64_t page = 1ULL << page_bits;
+  uint64_t p = db + 6 + h.so;
+  if (nelmts <= page) return read_entry(h, p + idx * esz, esz, filtered, plain_bytes, e);
+  const uint64_t npages = (nelmts + page - 1) / page, bm = (npages + 7) / 8;
+  if (!h.ok(p, bm)) { why = "fixed-array page bitmap outside the file"; return false; }
+  const uint64_t pg = idx / page;
+  if (!bit_msb(h, p, pg)) { e = ChunkEntry(); return true; }  // page never initialised
+  p += bm + 4;                                                // bitmap, checksum of the prefix
+  p += pg * (page * esz + 4);                                 // whole pages in front (each with its checksum)
+  return read_entry(h, p + (idx % page) * esz, esz, filtered, plain_bytes, e);
+}
+
+struct EArray {
+  bool filtered = false;
+  int esz = 0, max_bits = 0, idx_elmts = 0, min_elmts = 0, min_ptrs = 0, page_bits = 0, off_size = 0;
+  uint64_t iblock = kUndef;
+  int nsblks = 0, iblock_nsblks = 0;
+  uint64_t ndblk_addrs = 0;
+  std::vector<uint64_t> ndblks, dblk_nelmts, start_idx, start_dblk;
+};
+int log2_of2(uint64_t v) { int n = 0; while (v > 1) { v >>= 1; ++n; } return n; }
+bool earray_open(const H5& h, uint64_t hdr, EArray& a, std::string& why) {
+  if (!h.ok(hdr, 12 + 6ULL * h.sl + h.so) || memcmp(&h.f[hdr], "EAHD", 4) != 0) { why = "extensible-array header not found"; return false; }
+  a.filtered = h.f[hdr + 5] == 1;
+  a.esz = h.f[hdr + 6]; a.max_bits = h.f[hdr + 7]; a.idx_elmts = h.f[hdr + 8]; a.min_elmts = h.f[hdr + 9];
+  a.min_ptrs = h.f[hdr + 10]; a.page_bits = h.f[hdr + 11];
+  a.iblock = h.le(hdr + 12 + 6ULL * h.sl, h.so);
+  if (a.esz < h.so || a.max_bits < 1 || a.max_bits > 64 || a.min_elmts < 1 || a.min_ptrs < 2 || (a.min_elmts & (a.min_elmts - 1)) ||
+      (a.min_ptrs & (a.min_ptrs - 1)) || a.page_bits > 40) { why = "extensible-array header out of range"; return false; }
+  a.off_size = (a.max_bits + 7) / 8;
+  a.nsblks = 1 + (a.max_bits - log2_of2((uint64_t)a.min_elmts));
+  if (a.nsblks < 1 || a.nsblks > 130) { why = "extensible-array header out of range"; return false; }
+  a.iblock_nsblks = 2 * log2_of2((uint64_t)a.min_ptrs);
+  a.ndblk_addrs = 2ULL * ((uint64_t)a.min_ptrs - 1);
+  uint64_t si = 0, sd = 0;
+  for (int u = 0; u < a.nsblks; ++u) {  // H5EA__hdr_init
+    const uint64_t nd = 1ULL << (u / 2), ne = (1ULL << ((u + 1) / 2)) * (uint64_t)a.min_elmts;
+    a.ndblks.push_back(nd); a.dblk_nelmts.push_back(ne); a.start_idx.push_back(si); a.start_dblk.push_back(sd);
+    if (ne && nd > (~0ULL - si) / ne) break;  // (indices beyond 2^64: never reached)
+    si += nd * ne; sd += nd;
+  }
+  a.nsblks = (int)a.ndblks.size();
+  return true;
+}
+bool earray_get(const H5& h, const EArray& a, uint64_t idx, uint64_t plain_bytes, ChunkEntry& e, std::string& why) {
+  e = ChunkEntry();
+  if (a.iblock == kUndef) return true;
+  const uint64_t ib = h.base + a.iblock;
+  if (!h.ok(ib, 6 + (uint64_t)h.so) || memcmp(&h.f[ib], "EAIB", 4) != 0) { why = "extensible-array index block not found"; return false; }
+  uint64_t p = ib + 6 + h.so;
+  if (idx < (uint64_t)a.idx_elmts) return read_entry(h, p + idx * a.esz, a.esz, a.filtered, plain_bytes, e);
+  p += (uint64_t)a.idx_elmts * a.esz;
+  const uint64_t rel = idx - a.idx_elmts;
+  int u = 0;
+  while (u + 1 < a.nsblks && rel >= a.start_idx[u] + a.ndblks[u] * a.dblk_nelmts[u]) ++u;
+  if (rel >= a.start_idx[u] + a.ndblks[u] * a.dblk_nelmts[u]) return true;
+  const uint64_t within = rel - a.start_idx[u], di = within / a.dblk_nelmts[u], ei = within % a.dblk_nelmts[u];
+  const uint64_t nel = a.dblk_nelmts[u], page = 1ULL << a.page_bits;
+  const bool paged = nel > page;
+  uint64_t dblk = kUndef, page_bitmap = kUndef;
+  if (u < a.iblock_nsblks) {
+    if (!h.ok(p + (a.start_dblk[u] + di) * h.so, (uint64_t)h.so)) { why = "extensible-array index block outside the file"; return false; }
+    dblk = h.le(p + (a.start_dblk[u] + di) * h.so, h.so);
+  } else {
+    const uint64_t sp = p + a.ndblk_addrs * h.so + (uint64_t)(u - a.iblock_nsblks) * h.so;
+    if (!h.ok(sp, (uint64_t)h.so)) { why = "extensible-array index block outside the file"; return false; }
+    uint64_t sb = h.le(sp, h.so);
+    if (sb == kUndef) return true;
+    sb += h.base;
+    if (!h.ok(sb, 6 + (uint64_t)h.so + a.off_size) || memcmp(&h.f[sb], "EASB", 4) != 0) { why = "extensible-array super block not found"; return false; }
+    uint64_t q = sb + 6 + h.so + a.off_size;
+    if (paged) {
+      const uint64_t per = ((nel / page) + 7) / 8;  // page-init bitmap bytes per data block
+      page_bitmap = q + di * per;
+      q += a.ndblks[u] * per;
+    }
+    if (!h.ok(q + di * h.so, (uint64_t)h.so)) { why = "extensible-array super block outside the file"; return false; }
+    dblk = h.le(q + di * h.so, h.so);
+  }
+  if (dblk == kUndef) return true;
+  dblk += h.base;
+  if (!h.ok(dblk, 6 + (uint64_t)h.so + a.off_size) || memcmp(&h.f[dblk], "EADB", 4) != 0) { why = "extensible-array data block not found"; return false; }
+  uint64_t q = dblk + 6 + h.so + a.off_size;
+  if (!paged) return read_entry(h, q + ei * a.esz, a.esz, a.filtered, plain_bytes, e);
+  const uint64_t pg = ei / page;
+  if (page_bitmap != kUndef && h.ok(page_bitmap, (pg + 8) / 8) && !bit_msb(h, page_bitmap, pg)) return true;  // page never initialised
+  q += 4 + pg * (page * a.esz + 4);  // checksum of the prefix, whole pages in front
+  return read_entry(h, q + (ei % page) * a.esz, a.esz, a.filtered, plain_bytes, e);
+}
+
+// every chunk of a layout-v4 dataset that overlaps planes [za, zb): fn(offsets, addr, nbytes)
+template <typename F>
+bool for_each_chunk_v4(const H5& h, const Dataset& d, uint64_t za, uint64_t zb, F&& fn, std::string& why) {
+  const int nd = d.chunk_rank - 1;  // = rank
+  uint64_t nch[4] = {1, 1, 1, 1}, maxch[4] = {1, 1, 1, 1};
+  int unlim = -1, nunlim = 0;
+  for (int i = 0; i < nd; ++i) {
+    if (d.chunk_dims[i] == 0) { why = "zero chunk dimension"; return false; }
+    nch[i] = (d.dims[i] + d.chunk_dims[i] - 1) / d.chunk_dims[i];
+    if (d.maxdims[i] == kUndef) { if (unlim < 0) unlim = i; ++nunlim; maxch[i] = 0; }
+    else maxch[i] = ((d.maxdims[i] > d.dims[i] ? d.maxdims[i] : d.dims[i]) + d.chunk_dims[i] - 1) / d.chunk_dims[i];
+  }
+  uint64_t plain = 1;
+  for (int i = 0; i < d.chunk_rank; ++i) plain *= d.chunk_dims[i];
+  if (d.chunk_index == 5) { why = "version-2 B-tree chunk index (two or more unlimited dimensions) is not supported"; return false; }
+  if (d.index_addr == kUndef) return true;  // nothing written yet
+  EArray ea;
+  if (d.chunk_index == 4 && !earray_open(h, h.base + d.index_addr, ea, why)) return false;
+  // linear chunk index = row-major offset over the MAXIMAL chunk grid (H5VM_array_offset_pre with max_down_chunks); an
+  // extensible array first moves its unlimited dimension to the front (H5VM_swizzle_coords)
+  int order[4] = {0, 1, 2, 3};
+  if (d.chunk_index == 4 && unlim > 0) { for (int i = unlim; i > 0; --i) order[i] = order[i - 1]; order[0] = unlim; }
+  const uint64_t c0a = za / d.chunk_dims[0], c0b = (zb + d.chunk_dims[0] - 1) / d.chunk_dims[0];
+  for (uint64_t c0 = c0a; c0 < c0b && c0 < nch[0]; ++c0)
+    for (uint64_t c1 = 0; c1 < nch[1]; ++c1)
+      for (uint64_t c2 = 0; c2 < nch[2]; ++c2) {
+        const uint64_t sc[4] = {c0, c1, c2, 0};
+        uint64_t idx = 0;
+        for (int k = 0; k < nd; ++k) {  // Horner over the (swizzled) coordinates; the slowest dimension's extent never enters
+          const int dim = order[k];
+          idx = (k == 0 ? 0 : idx * maxch[dim]) + sc[dim];
+        }
+        ChunkEntry e;
+        if (d.chunk_index == 1) {
+          e.addr = d.index_addr; e.nbytes = d.single_size ? d.single_size : plain;
+        } else if (d.chunk_index == 2) {
+          e.addr = d.index_addr + idx * plain; e.nbytes = plain;
+        } else if (d.chunk_index == 3) {
+          if (!farray_get(h, h.base + d.index_addr, idx, plain, e, why)) return false;
+        } else {
+          if (!earray_get(h, ea, idx, plain, e, why)) return false;
+        }
+        if (e.addr == kUndef) continue;  // never written: fill value
+        const uint64_t offs[5] = {c0 * d.chunk_dims[0], c1 * d.chunk_dims[1], c2 * d.chunk_dims[2], 0, 0};
+        if (!fn(offs, h.base + e.addr, e.nbytes)) return false;
+      }
+  return true;
+}
+
 }  // namespace
 
 // planes [z0, z0 + nz_local) of the dataset (nz_local < 0: all from z0; the hyperslab each rank of the reference
@@ -266,18 +544,26 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
     if (memcmp(&h.f[off], sig, 8) == 0) { sb = off; break; }
   if (sb == kUndef) { oi::set_error("'%s' is not an HDF5 file", path); return OI_IO_ERROR; }
   const int sbver = h.f[sb + 8];
-  if (sbver > 1) {
-    oi::set_error("'%s': HDF5 superblock version %d (\"latest format\") is not supported by the built-in reader; "
-                  "rewrite the file with the default (earliest) format", path, sbver);
+  uint64_t obj = 0;
+  if (sbver <= 1) {
+    if (!h.ok(sb, 96)) { oi::set_error("'%s': truncated superblock", path); return OI_IO_ERROR; }
+    if (h.f[sb + 13] != 8 || h.f[sb + 14] != 8) { oi::set_error("'%s': only 8-byte offsets/lengths are supported", path); return OI_IO_ERROR; }
+    const uint64_t p = sb + 24 + (sbver == 1 ? 4 : 0);
+    h.base = h.le(p, 8);
+    const uint64_t root_entry = p + 32;  // after base, free-space, end-of-file, driver addresses
+    obj = h.base + h.le(root_entry + 8, 8);
+  } else if (sbver <= 3) {  // "latest format": signature, version, offset size, length size, flags, base, extension, EOF, ROOT header
+    if (!h.ok(sb, 12 + 4ULL * 8 + 4)) { oi::set_error("'%s': truncated superblock", path); return OI_IO_ERROR; }
+    h.so = h.f[sb + 9]; h.sl = h.f[sb + 10];
+    if ((h.so != 4 && h.so != 8) || (h.sl != 4 && h.sl != 8)) { oi::set_error("'%s': offset / length sizes %d / %d are not supported", path, h.so, h.sl); return OI_IO_ERROR; }
+    h.base = h.le(sb + 12, h.so);
+    obj = h.base + h.le(sb + 12 + 3ULL * h.so, h.so);
+  } else {
+    oi::set_error("'%s': HDF5 superblock version %d is not known to this reader", path, sbver);
     return OI_IO_ERROR;
   }
-  if (h.f[sb + 13] != 8 || h.f[sb + 14] != 8) { oi::set_error("'%s': only 8-byte offsets/lengths are supported", path); return OI_IO_ERROR; }
-  const uint64_t p = sb + 24 + (sbver == 1 ? 4 : 0);
-  h.base = h.le(p, 8);
-  const uint64_t root_entry = p + 32;  // after base, free-space, end-of-file, driver addresses
-  uint64_t obj = h.base + h.le(root_entry + 8, 8);
 
-  // walk the dataset path through symbol-table groups
+  // walk the dataset path: symbol-table groups (old style) or compact link messages (new style)
   std::string rest = dataset;
   while (!rest.empty() && rest[0] == '/') rest.erase(0, 1);
   while (!rest.empty()) {
@@ -289,10 +575,15 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
     if (!read_object_header(h, obj, msgs)) { oi::set_error("'%s': unsupported group object header", path); return OI_IO_ERROR; }
     uint64_t bt = kUndef, hp = kUndef;
     for (const Msg& m : msgs)
-      if (m.type == 0x0011) { bt = h.base + h.le(m.off, 8); hp = h.base + h.le(m.off + 8, 8); }
-    if (bt == kUndef) { oi::set_error("'%s': group without a symbol table (new-style groups are not supported)", path); return OI_IO_ERROR; }
+      if (m.type == 0x0011 && m.size >= 16) { bt = h.base + h.le(m.off, 8); hp = h.base + h.le(m.off + 8, 8); }
     uint64_t next = 0;
-    if (!group_lookup(h, bt, hp, part, next)) { oi::set_error("'%s': no object '%s' (dataset '%s')", path, part.c_str(), dataset); return OI_IO_ERROR; }
+    if (bt != kUndef) {
+      if (!group_lookup(h, bt, hp, part, next)) { oi::set_error("'%s': no object '%s' (dataset '%s')", path, part.c_str(), dataset); return OI_IO_ERROR; }
+    } else {
+      const int r = link_lookup(h, msgs, part, next);
+      if (r < 0) { oi::set_error("'%s': the group holding '%s' keeps its links in a fractal heap (dense storage), which this reader does not parse", path, part.c_str()); return OI_IO_ERROR; }
+      if (r == 0) { oi::set_error("'%s': no object '%s' (dataset '%s')", path, part.c_str(), dataset); return OI_IO_ERROR; }
+    }
     obj = next;
   }
 
@@ -339,13 +630,14 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
     if (d.chunk_rank != 4) return fail("chunk rank does not match the dataset rank");
     if (d.chunk_dims[3] != es) return fail("chunk element size mismatch");
     const uint64_t cz = d.chunk_dims[0], cy = d.chunk_dims[1], cx = d.chunk_dims[2];
+    if (cz == 0 || cy == 0 || cx == 0 || cz > (1ULL << 31) || cy > (1ULL << 31) || cx > (1ULL << 31) || cz * cy > (1ULL << 40) / (cx * es))
+      return fail("chunk dimensions out of range");
     const uint64_t cbytes = cz * cy * cx * es;
     if (0.0 > threshold) memset(out, 1, n);  // chunks that were never written hold the fill value 0
     std::vector<uint8_t> raw(cbytes), tmp(cbytes);
     bool good = true;
     std::string cerr;
-    if (d.chunk_btree != kUndef) {
-      good = for_each_chunk(h, d, h.base + d.chunk_btree, [&](const uint64_t* offs, uint64_t addr, uint64_t nbytes) {
+    auto take_chunk = [&](const uint64_t* offs, uint64_t addr, uint64_t nbytes) {
         if (offs[0] >= zb || offs[0] + cz <= za) return true;  // chunk outside the requested planes
         if (!h.ok(addr, nbytes)) { cerr = "chunk outside the file"; return false; }
         const uint8_t* src = &h.f[addr];
@@ -369,7 +661,11 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
             }
         }
         return true;
-      });
+    };
+    if (d.chunk_index != 0) {
+      good = for_each_chunk_v4(h, d, za, zb, take_chunk, cerr);
+    } else if (d.chunk_btree != kUndef) {
+      good = for_each_chunk(h, d, h.base + d.chunk_btree, take_chunk);
     }
     if (!good) return fail(cerr.empty() ? "corrupt chunk index" : cerr.c_str());
   } else {

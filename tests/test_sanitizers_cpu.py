@@ -78,6 +78,26 @@ def test_corrupted_and_crafted_files_under_sanitizers(drivers, tmp_path):
         hp.append(str(p))
     out = run([reader, "hdf5", "image", str(a), str(b)] + hp)
     assert out.splitlines()[0].startswith("ok 28 20 12") and out.strip().endswith("batch done")
+    # the "latest format" structures (v2 object headers, fixed / extensible arrays), written by the real libhdf5
+    inc, lib = "/opt/conda/include", "/opt/conda/lib"
+    if os.path.exists(os.path.join(inc, "hdf5.h")) and os.path.exists(os.path.join(lib, "libhdf5.so")):
+        w = str(tmp_path / "h5w")
+        if subprocess.run(["gcc", "-O1", os.path.join(ROOT, "tests", "h5_libhdf5_writer.c"), "-I" + inc, "-L" + lib, "-lhdf5",
+                           "-Wl,-rpath," + lib, "-o", w], capture_output=True).returncode == 0:
+            srcs, good = [], []
+            for k, v in enumerate(("chunk_gz_shuf", "paged", "unlimz_tiny", "unlimx", "single_gz", "implicit", "nested_chunk")):
+                f = tmp_path / f"latest{k}.h5"
+                subprocess.run([w, str(f), v, "40", "40", "40", "u8"], check=True, timeout=120)
+                srcs.append(f.read_bytes())
+                if "nested" not in v:
+                    good.append(str(f))
+            lp = []
+            for t in range(140):
+                q = tmp_path / f"l{t}.h5"
+                q.write_bytes(bytes(corrupt(srcs[t % len(srcs)], t, rng)))
+                lp.append(str(q))
+            out = run([reader, "hdf5", "image"] + good + lp)
+            assert out.splitlines()[0].startswith("ok 40 40 40") and out.strip().endswith("batch done")
 
 
 def test_oracle_under_sanitizers(drivers):
