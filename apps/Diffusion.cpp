@@ -31,6 +31,7 @@
 
 #include "../include/TortuosityMI355.H"
 #include "Inputs.H"
+#include "Plotfile.H"
 
 namespace {
 
@@ -398,7 +399,8 @@ int main(int argc, char* argv[]) {
       double tau = std::numeric_limits<double>::quiet_NaN();
       oi_tort_stats st{};
       std::vector<double> phi;
-      bool have_phi = false;
+      std::vector<std::uint8_t> mask;
+      bool have_phi = false, have_mask = false;
       if (ngpus == 1) {
         using TM = OpenImpala::TortuosityMI355;
         std::unique_ptr<TM> solver_ptr(
@@ -411,7 +413,9 @@ int main(int argc, char* argv[]) {
         st = solver_ptr->stats();
         if (write_plotfile != 0 && st.converged) {
           phi.resize(vol.phase.size());
+          mask.resize(vol.phase.size());
           have_phi = oi_tort_get_solution(solver_ptr->handle(), phi.data()) == OI_OK;
+          have_mask = oi_tort_get_mask(solver_ptr->handle(), mask.data()) == OI_OK;
         }
       } else {
         // ---- z-slabs: slab boundaries on multiples of 16 planes where the volume allows it (keeps the
@@ -432,7 +436,7 @@ int main(int argc, char* argv[]) {
           const oi_status cs = oi_comm_unique_id(uid);
           if (cs != OI_OK) throw std::runtime_error(std::string(oi_status_string(cs)) + ": " + oi_last_error());
         }
-        if (write_plotfile != 0) phi.assign(vol.phase.size(), 0.0);
+        if (write_plotfile != 0) { phi.assign(vol.phase.size(), 0.0); mask.assign(vol.phase.size(), 0); }
         std::vector<double> taus(N, std::numeric_limits<double>::quiet_NaN());
         std::vector<oi_tort_stats> stats(N);
         std::vector<std::string> errors(N);
@@ -457,7 +461,8 @@ int main(int argc, char* argv[]) {
             }
             oi_tort_get_stats(h, &stats[r]);
             if (write_plotfile != 0 && stats[r].converged)
-              got_phi[r] = oi_tort_get_solution(h, phi.data() + plane * zb[r]) == OI_OK;
+              got_phi[r] = oi_tort_get_solution(h, phi.data() + plane * zb[r]) == OI_OK &&
+                           oi_tort_get_mask(h, mask.data() + plane * zb[r]) == OI_OK;
           } while (0);
           if (h) oi_tort_destroy(h);
         };
@@ -471,6 +476,7 @@ int main(int argc, char* argv[]) {
         tau = taus[0];
         st = stats[0];
         have_phi = write_plotfile != 0 && std::all_of(got_phi.begin(), got_phi.end(), [](int v) { return v != 0; });
+        have_mask = have_phi;
         if (verbose >= 1) {
           std::cout << "  z-slabs over " << N << (transport == "local" ? " in-process ranks (one GPU)" : " GPUs") << ":";
           for (int r = 0; r < N; ++r) std::cout << " [" << zb[r] << "," << zb[r + 1] << ")";
@@ -491,8 +497,18 @@ int main(int argc, char* argv[]) {
                   << s_.t_flux_s << "\n";
       }
       if (have_phi) {
-        // raw potential field instead of an AMReX plotfile: f64, x fastest, + a one-line header
+        // the reference's plotfile (TortuosityHypre.cpp:710-749): solution_potential, phase_id, active_mask on the boxes of
+        // ba.maxSize(box_size), in AMReX's single-level plotfile layout (apps/Plotfile.H) ...
         const auto base = results_dir / ("tortuosity_solution_" + std::to_string(static_cast<int>(dir)));
+        if (have_mask) {
+          std::vector<double> phase_d(vol.phase.begin(), vol.phase.end()), mask_d(mask.begin(), mask.end());
+          if (!OpenImpala::writeSingleLevelPlotfile(base.string(), vol.nx, vol.ny, vol.nz, {phi.data(), phase_d.data(), mask_d.data()},
+                                                    {"solution_potential", "phase_id", "active_mask"}, box_size))
+            std::cerr << "Warning: could not write plotfile " << base.string() << "\n";
+          else if (verbose >= 1)
+            std::cout << "  Plotfile written to " << base.string() << "\n";
+        }
+        // ... and the raw potential field beside it: f64, x fastest, + a one-line header
         std::ofstream(base.string() + ".raw", std::ios::binary)
             .write(reinterpret_cast<const char*>(phi.data()), static_cast<std::streamsize>(phi.size() * sizeof(double)));
         std::ofstream(base.string() + ".txt") << "solution_potential float64 little-endian nx=" << vol.nx

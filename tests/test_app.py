@@ -201,8 +201,64 @@ write_plotfile = 1
     import numpy as np
     phi = np.fromfile(tmp_path / "res" / "tortuosity_solution_2.raw").reshape(100, 100, 100)
     assert phi.min() >= g["vlo"] - 1e-9 and phi.max() <= g["vhi"] + 1e-9 and phi[0].min() == g["vlo"]
+    # the same field as an AMReX single-level plotfile (TortuosityHypre.cpp:710-749), re-read by an independent parser
+    pf = read_plotfile(tmp_path / "res" / "tortuosity_solution_2")
+    assert pf["vars"] == ["solution_potential", "phase_id", "active_mask"] and pf["domain"] == (100, 100, 100)
+    assert pf["nboxes"] == 64  # ba.maxSize(32) of 100^3: 4 x 4 x 4 boxes (28 + 24 + 24 + 24 per axis)
+    assert np.array_equal(pf["data"][0], phi)
+    from oracle import oracle as o
+    sample = o.read_tiff_phase(os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif"))
+    assert np.array_equal(pf["data"][1], sample.astype(np.float64))
+    mask, _ = o.active_mask(sample, 1, 2)
+    assert np.array_equal(pf["data"][2], mask.astype(np.float64))
     r = subprocess.run([app, _inputs(tmp_path, text), "gpu.ngpus=4", "gpu.transport=rccl"], capture_output=True, text=True)
     assert r.returncode == 1 and "GPU(s) are visible" in r.stderr
+
+
+def read_plotfile(path):
+    """Independent reader of AMReX's single-level plotfile layout (Header, Level_0/Cell_H, Cell_D FAB records)."""
+    import re
+    import numpy as np
+    hdr = open(path / "Header").read().split("\n")
+    assert hdr[0] == "HyperCLaw-V1.1"
+    ncomp = int(hdr[1])
+    names = hdr[2:2 + ncomp]
+    q = 2 + ncomp
+    assert hdr[q] == "3" and float(hdr[q + 1]) == 0.0 and hdr[q + 2] == "0"
+    lo = [float(v) for v in hdr[q + 3].split()]
+    hi = [float(v) for v in hdr[q + 4].split()]
+    assert hdr[q + 5].strip() == ""
+    m = re.fullmatch(r"\(\((\d+),(\d+),(\d+)\) \((\d+),(\d+),(\d+)\) \(0,0,0\)\) ", hdr[q + 6])
+    dom = tuple(int(v) for v in m.groups())
+    assert dom[:3] == (0, 0, 0) and lo == [0, 0, 0] and hi == [dom[3] + 1, dom[4] + 1, dom[5] + 1]
+    assert hdr[q + 7].split() == ["0"] and hdr[q + 8].split() == ["1", "1", "1"] and hdr[q + 9] == "0" and hdr[q + 10] == "0"
+    level, ngrids, _t = hdr[q + 11].split()
+    ngrids = int(ngrids)
+    assert level == "0" and hdr[q + 12] == "0"
+    assert hdr[q + 13 + 3 * ngrids] == "Level_0/Cell"
+    ch = open(path / "Level_0" / "Cell_H").read().split("\n")
+    assert ch[0] == "1" and ch[1] == "1" and int(ch[2]) == ncomp and ch[3] == "0" and ch[4] == f"({ngrids} 0"
+    boxes = []
+    for l in ch[5:5 + ngrids]:
+        m = re.fullmatch(r"\(\((\d+),(\d+),(\d+)\) \((\d+),(\d+),(\d+)\) \(0,0,0\)\)", l)
+        boxes.append(tuple(int(v) for v in m.groups()))
+    assert ch[5 + ngrids] == ")" and int(ch[6 + ngrids]) == ngrids
+    nx, ny, nz = dom[3] + 1, dom[4] + 1, dom[5] + 1
+    data = np.full((ncomp, nz, ny, nx), np.nan)
+    blob = open(path / "Level_0" / "Cell_D_00000", "rb").read()
+    for g in range(ngrids):
+        tag, fname, off = ch[7 + ngrids + g].split()
+        assert tag == "FabOnDisk:" and fname == "Cell_D_00000"
+        off = int(off)
+        end = blob.index(b"\n", off)
+        line = blob[off:end].decode()
+        b = boxes[g]
+        assert line == "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))((%d,%d,%d) (%d,%d,%d) (0,0,0)) %d" % (b + (ncomp,))
+        sx, sy, sz = b[3] - b[0] + 1, b[4] - b[1] + 1, b[5] - b[2] + 1
+        arr = np.frombuffer(blob, "<f8", ncomp * sx * sy * sz, end + 1).reshape(ncomp, sz, sy, sx)
+        data[:, b[2]:b[5] + 1, b[1]:b[4] + 1, b[0]:b[3] + 1] = arr
+    assert not np.isnan(data).any()  # the boxes tile the domain
+    return {"vars": names, "domain": (nx, ny, nz), "nboxes": ngrids, "data": data}
 
 
 @pytest.mark.gpu
