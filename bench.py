@@ -261,6 +261,7 @@ def main():
         t = oia.TortuosityMI355(buf, 1, direction, 0.0, 1.0, shape=shape, **kw)
     t_create = time.time() - t_create
     buf.free()
+    placement = t.placement()
     st = t.stats()
     if st.active_vf <= 0:
         raise RuntimeError("synthetic structure does not percolate")
@@ -360,6 +361,18 @@ def main():
                 "ms_per_launch": ms_launch,
                 "bytes_per_voxel_iter_in_live_lines": alg_bytes_iter}
     t.cg_finish()
+    if main_k == "cg1" and args.kernel == "fused1":
+        # in-situ ceiling of the CG kernel's traffic mix: a kernel that only moves the six double-buffered vectors where
+        # they lie (3 read, 3 written, 16-byte nontemporal accesses), HIP events on the handle's stream
+        try:
+            sms, sbytes = t.bench_stream(10)
+            roofline["stream_3r3w_same_vectors"] = {
+                "ms": sms, "GBps": sbytes / sms / 1e6, "frac_of_peak": sbytes / sms / 1e6 / HBM_PEAK_GBS,
+                "cg_kernel_vs_this_stream": achieved / (sbytes / sms / 1e6),
+                "what": "d_j = s_j over r2,q2,p[1] -> r,q,p[0] of this handle (whole vectors, same placement); the CG kernel also "
+                        "streams x, the code bytes and the line table"}
+        except oia.OpenImpalaError as e:
+            roofline["stream_3r3w_same_vectors"] = {"error": str(e)}
     cpu_full = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_iters > 0 and args.kernel != "lean" and nvox <= 1100 ** 3:
         cpu_full = (t.codes(), t.mask(), f"{n}x{n}x{nz} {desc}")  # (bit-identical to the oracle's own: tests/test_gpu_parity.py)
@@ -392,6 +405,8 @@ def main():
             "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
                         "flood_sweeps": st.flood_sweeps},
             "device_bytes": st.bytes_device,
+            # where the CG vectors were put (slots of one arena) and what the placement search measured, ms per iteration
+            "vector_placement": placement,
         }
         if extras["note"]:
             out["note"] = extras["note"]

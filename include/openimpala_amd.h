@@ -198,6 +198,18 @@ oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
  * which no solver variant uses inside its iteration; one dense scratch vector, 8 bytes per voxel; collective on slabs).
  * Same normalisation as stats.final_relres. */
 oi_status oi_tort_true_residual(oi_tort* h, double* relres);
+/* Where the vectors of the single-kernel iteration were put.  When a vector is larger than the 256 MB Infinity Cache,
+ * x and the six double-buffered vectors are slots of ONE arena, with spare slots ("place_slots", memory permitting), and
+ * `place_trials` placements (oi_tort_set_option, default 32) are timed with the real kernel when the handle is built,
+ * the fastest kept: on MI355X the iteration time depends on the distances between the arrays read and the arrays
+ * written (HBM address mapping).  nslots = 0: no arena.  slots7[0..5] = slots of r, q, p[0], r2,
+ * q2, p[1]; slots7[6] = number of slots in front of x.  ms_first / ms_best = ms per iteration of the in-order layout
+ * and of the layout kept (0 when nothing was timed).  The results of the solve do not depend on the placement. */
+oi_status oi_tort_placement(oi_tort* h, int* nslots, int* slots7, int* tried, double* ms_first, double* ms_best);
+/* ms per pass of a kernel that only MOVES the six double-buffered vectors of the single-kernel iteration where they lie
+ * (three read, three written, 16-byte nontemporal accesses): the in-situ ceiling of that traffic mix on this card at
+ * this placement.  Only between CG runs (the vectors are scratch then). */
+oi_status oi_tort_bench_stream(oi_tort* h, int reps, double* ms_per_pass, double* bytes_per_pass);
 /* run the stand-alone stencil apply `reps` times on device-resident vectors and
  * return the HIP-event time of the launches (ms per launch); variant OI_KERNEL_LEAN = the apply as the CG
  * uses it (a vector that vanishes off the free set, live-line predication) */
@@ -230,6 +242,10 @@ int oi_tort_line_voxels(void);
  *   "mg_plain" "mg_novec4" "mg_debug"   multigrid cross-check kernels / per-level norms
  *   "mg_replicate_cells" "mg_wmask" "mg_scale"   multigrid level distribution and cycle shape
  *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
+ *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 32; 0 = separate
+ *                   allocations in order, no spare slots; see oi_tort_placement)
+ *   "place_slots"   slots of the vector arena (default 12, 6 to 16: six are used, spare ones widen the choice; fewer are
+ *                   taken when less than a quarter of the card would stay free)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
  * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM seed the same defaults, read ONCE per process.
  * OI_BAD_ARG for an unknown key. */

@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
-    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
+    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_tort_placement oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
@@ -147,6 +147,8 @@ def lib():
     L.oi_tort_set_option.argtypes = [C.c_char_p, C.c_double]
     L.oi_tort_retune.argtypes = [vp]
     L.oi_tort_true_residual.argtypes = [vp, C.POINTER(C.c_double)]
+    L.oi_tort_bench_stream.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.oi_tort_placement.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oi_tort_line_voxels.argtypes = []
     L.oi_tort_line_voxels.restype = i
     L.oi_comm_unique_id.argtypes = [vp]
@@ -499,6 +501,20 @@ class TortuosityMI355:
         out = np.empty(self.shape, np.uint8)
         _check(lib().oi_tort_debug_get_codes(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def bench_stream(self, reps=10):
+        """(ms per pass, bytes per pass) of a 3-read / 3-write stream over the handle's own CG vectors (oi_tort_bench_stream)."""
+        ms, nb = C.c_double(0.0), C.c_double(0.0)
+        _check(lib().oi_tort_bench_stream(self._h, reps, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
+    def placement(self):
+        """Slots of the single-kernel iteration's vectors and what the placement search measured (oi_tort_placement)."""
+        n, tried = C.c_int(0), C.c_int(0)
+        slots = (C.c_int * 7)()
+        first, best = C.c_double(0.0), C.c_double(0.0)
+        _check(lib().oi_tort_placement(self._h, C.byref(n), slots, C.byref(tried), C.byref(first), C.byref(best)))
+        return {"nslots": n.value, "slots": list(slots)[:6], "x_after_slots": slots[6], "tried": tried.value, "ms_in_order": first.value, "ms_kept": best.value}
 
     def true_residual(self):
         """||b - A x|| / ||b|| of the current solution, recomputed on the device with the stand-alone apply kernel."""

@@ -33,6 +33,10 @@ struct Tune {
   long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
+  int place_trials = 32; // single-kernel CG: vector placements (slots of one arena) timed when the handle is built, the
+                         // fastest kept; 0 = separate allocations in order, no spare slots (env OI_PLACE_TRIALS)
+  int place_slots = 12;  // slots of that arena (6 are used; the spare ones widen the choice), memory permitting
+                         // (env OI_PLACE_SLOTS)
   int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
   int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
 };
@@ -139,6 +143,8 @@ int launch_apply_cgvec(const Geom& g, const uint8_t* code, const double* v, doub
                        hipStream_t s);
 // dst = src (ndoubles even): the box's reference 1 read : 1 write stream, see k_stream_copy
 void launch_stream_copy(double* dst, const double* src, long long ndoubles, hipStream_t s);
+void launch_stream_3r3w(double* d0, double* d1, double* d2, const double* s0, const double* s1, const double* s2,
+                        long long ndoubles, hipStream_t s);
 // q-free CG iteration of the capacity mode (x, r, p only): p.Ap without storing q, then
 // x += alpha p, r -= alpha A p with A p recomputed on the fly; partials {p.q} / {r.r, r.z}
 int launch_lean_dot(const Geom& g, const uint8_t* code, const double* p, double* partials, const Ctrl* ctrl,

@@ -484,11 +484,11 @@ template <typename F>
 bool for_each_chunk_v4(const H5& h, const Dataset& d, uint64_t za, uint64_t zb, F&& fn, std::string& why) {
   const int nd = d.chunk_rank - 1;  // = rank
   uint64_t nch[4] = {1, 1, 1, 1}, maxch[4] = {1, 1, 1, 1};
-  int unlim = -1, nunlim = 0;
+  int unlim = -1;
   for (int i = 0; i < nd; ++i) {
     if (d.chunk_dims[i] == 0) { why = "zero chunk dimension"; return false; }
     nch[i] = (d.dims[i] + d.chunk_dims[i] - 1) / d.chunk_dims[i];
-    if (d.maxdims[i] == kUndef) { if (unlim < 0) unlim = i; ++nunlim; maxch[i] = 0; }
+    if (d.maxdims[i] == kUndef) { if (unlim < 0) unlim = i; maxch[i] = 0; }
     else maxch[i] = ((d.maxdims[i] > d.dims[i] ? d.maxdims[i] : d.dims[i]) + d.chunk_dims[i] - 1) / d.chunk_dims[i];
   }
   uint64_t plain = 1;

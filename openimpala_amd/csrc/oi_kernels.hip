@@ -85,6 +85,8 @@ Tune default_tune() {
     if (const char* e = getenv("OI_MG_WMASK")) g_tune_defaults.mg_wmask = atoi(e);
     if (const char* e = getenv("OI_MG_SCALE")) g_tune_defaults.mg_scale = (float)atof(e);
     if (getenv("OI_FORCE_COMM")) g_tune_defaults.force_comm = 1;
+    if (const char* e = getenv("OI_PLACE_TRIALS")) g_tune_defaults.place_trials = atoi(e);
+    if (const char* e = getenv("OI_PLACE_SLOTS")) g_tune_defaults.place_slots = atoi(e);
   }
   return g_tune_defaults;
 }
@@ -1329,6 +1331,37 @@ __global__ void __launch_bounds__(256) k_stream_copy(double* __restrict__ d, con
   }
   for (long long t = nchunks * 64 * U + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (long long)gridDim.x * blockDim.x)
     *reinterpret_cast<v2d_t*>(d + 2 * t) = *reinterpret_cast<const v2d_t*>(s + 2 * t);
+}
+// the same walk over three sources and three destinations: what the memory system gives a kernel that moves the six
+// double-buffered vectors of the single-kernel CG and does nothing else (d_j = s_j; the CG kernel's own ceiling is below
+// this: it also streams x, the code bytes and the line table)
+__global__ void __launch_bounds__(256) k_stream_3r3w(double* __restrict__ d0, double* __restrict__ d1, double* __restrict__ d2,
+                                                     const double* __restrict__ s0, const double* __restrict__ s1,
+                                                     const double* __restrict__ s2, long long n2) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  const long long nchunks = n2 / (64 * U);
+  for (long long c = wave; c < nchunks; c += nwaves) {
+    const long long t0 = c * 64 * U + lane;
+    v2d_t a[U], b[U], e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(s0 + 2 * (t0 + u * 64)));
+      b[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(s1 + 2 * (t0 + u * 64)));
+      e[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(s2 + 2 * (t0 + u * 64)));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      __builtin_nontemporal_store(a[u], reinterpret_cast<v2d_t*>(d0 + 2 * (t0 + u * 64)));
+      __builtin_nontemporal_store(b[u], reinterpret_cast<v2d_t*>(d1 + 2 * (t0 + u * 64)));
+      __builtin_nontemporal_store(e[u], reinterpret_cast<v2d_t*>(d2 + 2 * (t0 + u * 64)));
+    }
+  }
+}
+void launch_stream_3r3w(double* d0, double* d1, double* d2, const double* s0, const double* s1, const double* s2,
+                        long long ndoubles, hipStream_t s) {
+  hipLaunchKernelGGL(k_stream_3r3w, dim3(8192), dim3(256), 0, s, d0, d1, d2, s0, s1, s2, ndoubles / 2);
 }
 void launch_stream_copy(double* dst, const double* src, long long ndoubles, hipStream_t s) {
   hipLaunchKernelGGL(k_stream_copy, dim3(8192), dim3(256), 0, s, dst, src, ndoubles / 2);

@@ -80,6 +80,16 @@ struct oi_tort {
   long long* plane_first_dev = nullptr;
   std::vector<long long> plane_first;   // first slot of every plane, gz = 0 .. nzl + 2
   long long nvec_cg = 0;                // elements of r / q / p (= g.nvec in the dense layout)
+  // single-kernel variant: r, q, p[0], r2, q2, p[1] are SLOTS of one arena; which six of the nslots they take is
+  // chosen by timing (place_vectors): the HBM address mapping makes the iteration time depend on where the three
+  // vectors read and the three written lie relative to each other
+  char* slot_arena = nullptr;
+  size_t x_bytes = 0;  // > 0: x lies in the arena too
+  int nslots = 0;
+  size_t slot_bytes = 0;
+  int placement[7] = {0, 1, 2, 3, 4, 5, 0};
+  int placement_tried = 0;
+  double placement_ms_first = 0.0, placement_ms_best = 0.0;
   double* z = nullptr;                  // preconditioned residual of the multigrid variant
   bool lean = false;  // OI_KERNEL_LEAN: no q vector, A p recomputed in the update pass
   oi::MgHierarchy* mg = nullptr;
@@ -203,6 +213,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->slot_arena) { (void)hipFree(h->slot_arena); h->r = h->q = h->r2 = h->q2 = nullptr; h->p[0] = h->p[1] = nullptr; if (h->x_bytes) h->x = nullptr; }
   void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->plane_first_dev,
                  h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
   for (void* d : dev)
@@ -305,6 +316,136 @@ extern "C" void oi_tort_set_cg1_layout(int compact_lines) {
 }
 
 // ---- construction ----------------------------------------------------------------------
+static oi_status cg_one_iteration(oi_tort* h, int k);
+
+// ---- placement of the vectors of the single-kernel iteration --------------------------------------------------------------
+// MI355X: the time of a kernel that streams several arrays at the same offsets depends on the DISTANCES between the
+// arrays it reads and the arrays it writes (HBM address mapping: tools/hbm_window.hip, profiles/r02/hbm_window_*.txt --
+// a plain copy runs at 4.6 to 6.0 TB/s depending on which address bit separates source and destination).  The six
+// double-buffered vectors laid out one after the other are in the slowest class at 1024^3.  So the vectors are slots
+// of ONE arena with (memory permitting) three spare slots, and which slot holds which vector is decided by timing the
+// real kernel on a few placements when the handle is built.  The arithmetic does not see the choice.
+static constexpr int kMaxSlots = 16;  // array bound (Tune::place_slots)
+static constexpr size_t kSlotAlign = (size_t)2 << 20;
+static constexpr size_t kPlaceMinBytes = (size_t)256 << 20;  // below this a vector sits in the 256 MB Infinity Cache
+
+// pl[0..5] = slots of r, q, p[0], r2, q2, p[1]; pl[6] = number of slots in FRONT of x (x lies in the same arena)
+static void assign_slots(oi_tort* h, const int* pl) {
+  auto slot = [&](int k) { return h->slot_arena + (size_t)pl[k] * h->slot_bytes + (pl[k] >= pl[6] ? h->x_bytes : 0); };
+  h->r = (double*)slot(0); h->q = (double*)slot(1); h->p[0] = slot(2);
+  h->r2 = (double*)slot(3); h->q2 = (double*)slot(4); h->p[1] = slot(5);
+  if (h->x_bytes) h->x = (double*)(h->slot_arena + (size_t)pl[6] * h->slot_bytes);
+  for (int k = 0; k < 7; ++k) h->placement[k] = pl[k];
+}
+
+static oi_status alloc_vector_slots(oi_tort* h) {
+  const size_t vec = (size_t)h->nvec_cg * sizeof(double);
+  h->slot_bytes = (vec + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+  const bool search = h->g.tune.place_trials > 0 && vec >= kPlaceMinBytes;
+  int want = 6;
+  if (search) {
+    // x joins the arena (where it lies between the other vectors matters as much as where they lie)
+    h->x_bytes = ((size_t)h->g.nvec * sizeof(double) + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
+    size_t free_b = 0, total_b = 0;
+    HIPC(hipMemGetInfo(&free_b, &total_b));
+    // spare slots only while a quarter of the card stays free for the caller's own arrays
+    const int most = std::min(kMaxSlots, std::max(6, h->g.tune.place_slots));
+    for (want = most; want > 6 && (size_t)want * h->slot_bytes + h->x_bytes + total_b / 4 > free_b; --want) {}
+  }
+  for (;; want = 6) {
+    if (hipMalloc((void**)&h->slot_arena, (size_t)want * h->slot_bytes + h->x_bytes) == hipSuccess) break;
+    (void)hipGetLastError();
+    h->slot_arena = nullptr;
+    if (want == 6) { oi::set_error("out of device memory for the CG vectors (%zu bytes)", 6 * h->slot_bytes + h->x_bytes); return OI_HIP_ERROR; }
+  }
+  h->nslots = want;
+  h->bytes_device += (size_t)want * h->slot_bytes + h->x_bytes;
+  const int first[7] = {0, 1, 2, 3, 4, 5, 0};  // x, then the six vectors in order
+  assign_slots(h, first);
+  return OI_OK;
+}
+
+// time the 2-cycle (kernel 2: reads r2,q2,p[1], writes r,q,p[0] and x; kernel 3: the other way) on `place_trials`
+// placements and keep the fastest.  Zeroed vectors and records: the launches are ordinary iterations of the zero system
+// (tol2 < 0 so that they do not stop); cg_begin initialises everything afterwards.  Every rank runs the same number
+// of launches (the slab path has collectives inside), the choice itself is local.
+static oi_status place_vectors(oi_tort* h) {
+  const int trials = h->g.tune.place_trials;
+  if (!h->slot_arena || !h->x_bytes || trials <= 0 || h->hist_cap < 4) return OI_OK;
+  hipStream_t s = h->stream;
+  HIPC(hipMemsetAsync(h->slot_arena, 0, (size_t)h->nslots * h->slot_bytes + h->x_bytes, s));
+  HIPC(hipMemsetAsync(h->rec, 0, sizeof(double) * kRec1Stride * h->hist_cap, s));
+  Ctrl c;
+  c.done = 0; c.pad = 0; c.tol2 = -1.0;
+  *h->h_ctrl = c;
+  HIPC(hipMemcpyAsync(h->ctrl, h->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+  const int profile = h->opts.profile;
+  h->opts.profile = 0;
+  hipEvent_t a = nullptr, b = nullptr;
+  HIPC(hipEventCreate(&a)); HIPC(hipEventCreate(&b));
+  int best[7] = {0, 1, 2, 3, 4, 5, 0};
+  double best_ms = 0.0;
+  unsigned rng = 20260001u;
+  auto rnd = [&](int m) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % (unsigned)m); };
+  oi_status rc = OI_OK;
+  const int nrandom = trials - trials / 3;
+  for (int t = 0; t < trials && rc == OI_OK; ++t) {
+    int pl[7];
+    if (t < nrandom) {  // the in-order layout, then random ones
+      int perm[kMaxSlots + 1];
+      for (int k = 0; k < h->nslots; ++k) perm[k] = k;
+      int xfront = 0;
+      if (t > 0) {
+        for (int k = h->nslots - 1; k > 0; --k) std::swap(perm[k], perm[rnd(k + 1)]);
+        xfront = rnd(h->nslots + 1);
+      }
+      for (int k = 0; k < 6; ++k) pl[k] = perm[k];
+      pl[6] = xfront;
+    } else {  // then small changes of the best one: a vector to a free slot, two vectors swapped, x moved
+      for (int k = 0; k < 7; ++k) pl[k] = best[k];
+      const int what = rnd(h->nslots > 6 ? 3 : 2);
+      if (what == 0) {
+        const int i = rnd(6), j = (i + 1 + rnd(5)) % 6;
+        std::swap(pl[i], pl[j]);
+      } else if (what == 1) {
+        pl[6] = (pl[6] + 1 + rnd(h->nslots)) % (h->nslots + 1);
+      } else {
+        bool used[kMaxSlots] = {false};
+        for (int k = 0; k < 6; ++k) used[pl[k]] = true;
+        int nth = rnd(h->nslots - 6);
+        for (int v = 0; v < h->nslots; ++v)
+          if (!used[v] && nth-- == 0) { pl[rnd(6)] = v; break; }
+      }
+    }
+    assign_slots(h, pl);
+    for (int rep = (t == 0 ? 0 : 1); rep < 2 && rc == OI_OK; ++rep) {  // one untimed cycle at the very start
+      if (rep == 1 && hipEventRecord(a, s) != hipSuccess) rc = OI_HIP_ERROR;
+      if (rc == OI_OK) rc = cg_one_iteration(h, 2);
+      if (rc == OI_OK) rc = cg_one_iteration(h, 3);
+    }
+    float ms = 0.f;
+    if (rc == OI_OK && (hipEventRecord(b, s) != hipSuccess || hipEventSynchronize(b) != hipSuccess ||
+                        hipEventElapsedTime(&ms, a, b) != hipSuccess)) rc = OI_HIP_ERROR;
+    if (rc != OI_OK) break;
+    const double per_iter = 0.5 * ms;
+    if (h->opts.verbose > 2)
+      fprintf(stderr, "[openimpala_amd]   placement %2d: x after %d slots, %d %d %d | %d %d %d  %.3f ms\n", t, pl[6], pl[0], pl[1], pl[2],
+              pl[3], pl[4], pl[5], per_iter);
+    if (t == 0) h->placement_ms_first = per_iter;
+    if (t == 0 || per_iter < best_ms) { best_ms = per_iter; for (int k = 0; k < 7; ++k) best[k] = pl[k]; }
+    h->placement_tried = t + 1;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  h->opts.profile = profile;
+  OIC(rc);
+  assign_slots(h, best);
+  h->placement_ms_best = best_ms;
+  if (h->opts.verbose > 1)
+    fprintf(stderr, "[openimpala_amd] vector placement: %d slots, %d tried, %.3f -> %.3f ms per iteration (x after %d slots, %d %d %d | %d %d %d)\n",
+            h->nslots, h->placement_tried, h->placement_ms_first, best_ms, best[6], best[0], best[1], best[2], best[3], best[4], best[5]);
+  return OI_OK;
+}
+
 static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   Geom& g = h->g;
   const double t0 = now_s();
@@ -423,7 +564,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   h->maxiter = h->opts.maxiter > 0 ? h->opts.maxiter : 40 * (g.nx + g.ny + g.nz);
   h->hist_cap = h->maxiter + 2;
   OIC(dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap));
-  OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+  // (x of the single-kernel variant may join the vector arena, see alloc_vector_slots)
   h->nvec_cg = g.nvec;
   const bool want_mg = h->opts.precond == OI_PRECOND_MG;
   h->mg_tiled = g.tune.mg_plain ? 0 : 1;
@@ -446,16 +587,18 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
       OIC(check_plane_message_lengths(h, s));
     }
   }
-  OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
-  if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)h->nvec_cg));
   if (h->cg1) {
-    OIC(dmalloc(h, &h->r2, (size_t)h->nvec_cg));
-    OIC(dmalloc(h, &h->q2, (size_t)h->nvec_cg));
     OIC(dmalloc(h, &h->rec, (size_t)kRec1Stride * h->hist_cap));
-  }
-  for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
-    HIPC(hipMalloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
-    h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
+    OIC(alloc_vector_slots(h));
+    if (!h->x_bytes) OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+  } else {
+    OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+    OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
+    if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)h->nvec_cg));
+    for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
+      HIPC(hipMalloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
+      h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
+    }
   }
   if (want_mg) {
     OIC(dmalloc(h, &h->z, (size_t)h->nvec_cg));
@@ -468,6 +611,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
       fprintf(stderr, "[openimpala_amd] multigrid hierarchy: %d levels (replicated from level %d), %.1f MB\n",
               mg_levels(h->mg), mg_replicated_from(h->mg), mg_bytes / 1e6);
   }
+  if (h->cg1) OIC(place_vectors(h));
   h->vectors_ready = true;
   h->st.t_setup_s = now_s() - t2;
   h->st.bytes_device = (double)h->bytes_device;
@@ -1197,6 +1341,44 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
 // the Dirichlet values, so on the free rows b - A x = -(A x); identity rows have no residual.  The convergence test and
 // stats.final_relres use the RECURRENCE residual r_k = r_{k-1} - alpha q (as HYPRE's Krylov solvers do); this entry point
 // is the independent check that the two agree.  Needs one dense scratch vector (8 bytes per voxel).
+// ms per pass of a kernel that only moves the handle's six double-buffered CG vectors (r2, q2, p[1] -> r, q, p[0]) where
+// they lie: the in-situ ceiling of a 3-read / 3-write stream, reported by bench.py beside the CG kernel's own rate.
+// Only between CG runs (the vectors are scratch then; cg_begin initialises them).
+extern "C" oi_status oi_tort_bench_stream(oi_tort* h, int reps, double* ms_per_pass, double* bytes_per_pass) {
+  if (!h || !ms_per_pass || reps < 1) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  if (!h->cg1 || !h->vectors_ready || h->cg_active || h->p_f32) {
+    oi::set_error("%s: needs the single-kernel variant (fp64 vectors) with no CG run in flight", __func__);
+    return OI_BAD_ARG;
+  }
+  HIPC(hipSetDevice(h->device));
+  const long long nd = h->nvec_cg / 512 * 512;
+  hipEvent_t a = nullptr, b = nullptr;
+  HIPC(hipEventCreate(&a)); HIPC(hipEventCreate(&b));
+  float ms = 0.f;
+  auto go = [&] { launch_stream_3r3w(h->r, h->q, (double*)h->p[0], h->r2, h->q2, (const double*)h->p[1], nd, h->stream); };
+  go();
+  oi_status st = OI_OK;
+  if (hipEventRecord(a, h->stream) != hipSuccess) st = OI_HIP_ERROR;
+  for (int r = 0; r < reps; ++r) go();
+  if (hipEventRecord(b, h->stream) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess)
+    st = OI_HIP_ERROR;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  OIC(st);
+  *ms_per_pass = ms / reps;
+  if (bytes_per_pass) *bytes_per_pass = 6.0 * 8.0 * (double)nd;
+  return OI_OK;
+}
+
+extern "C" oi_status oi_tort_placement(oi_tort* h, int* nslots, int* slots7, int* tried, double* ms_first, double* ms_best) {
+  if (!h) { oi::set_error("%s: null handle", __func__); return OI_BAD_ARG; }
+  if (nslots) *nslots = h->nslots;
+  if (slots7) for (int k = 0; k < 7; ++k) slots7[k] = h->placement[k];
+  if (tried) *tried = h->placement_tried;
+  if (ms_first) *ms_first = h->placement_ms_first;
+  if (ms_best) *ms_best = h->placement_ms_best;
+  return OI_OK;
+}
+
 extern "C" oi_status oi_tort_true_residual(oi_tort* h, double* relres) {
   if (!h || !relres) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *relres = std::numeric_limits<double>::quiet_NaN();
@@ -1554,6 +1736,8 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_wmask") t.mg_wmask = iv;
   else if (k == "mg_scale") t.mg_scale = (float)value;
   else if (k == "force_comm") t.force_comm = iv != 0;
+  else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
+  else if (k == "place_slots") t.place_slots = iv;
   else { oi::set_error("%s: unknown key '%s'", __func__, key); return OI_BAD_ARG; }
   oi::set_default_tune(t);
   return OI_OK;
@@ -1570,6 +1754,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
   t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale;
   t.force_comm = old.force_comm;
+  t.place_trials = old.place_trials; t.place_slots = old.place_slots;
   h->g.tune = t;
   return OI_OK;
 }

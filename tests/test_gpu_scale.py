@@ -119,3 +119,45 @@ def test_c5_share_4096x4096x512_porosity_02_jacobi_pcg():
     assert t.status == oia.OI_OK and st.converged and st.iterations < 200 and tau > 2.0
     assert flux_gap(st) <= 1e-6
     t.destroy(); buf.free()
+
+
+def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
+    """The single-kernel iteration keeps x and its six double-buffered vectors in slots of one arena and times a few
+    placements when the handle is built (on MI355X the iteration time depends on the distances between the arrays read
+    and the arrays written).  The choice is invisible to the arithmetic: the same residual history and the same tau with
+    the search off (separate allocations), with six slots (orderings only) and with spare slots; when the card is
+    nearly full the spare slots are given up, not the handle."""
+    shape = (512, 512, 512)
+    K = 30
+    buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
+    out = {}
+    for name, trials, slots in (("off", 0, 12), ("six", 6, 6), ("spare", 10, 12)):
+        oi_option("place_trials", trials, reset=32)
+        oi_option("place_slots", slots, reset=12)
+        t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
+        pl = t.placement()
+        if name == "off":
+            assert pl["tried"] == 0 and pl["ms_kept"] == 0.0
+        else:
+            assert pl["nslots"] == slots and pl["tried"] == trials and 0.0 < pl["ms_kept"] <= pl["ms_in_order"]
+            assert len(set(pl["slots"])) == 6 and all(0 <= v < slots for v in pl["slots"]) and 0 <= pl["x_after_slots"] <= slots
+        t.cg_begin(); t.cg_iterate(K + 1); t.sync()
+        its, rel, conv = t.cg_state()
+        t.cg_finish()
+        assert its == K and not conv
+        out[name] = (rel, t.true_residual(), t.stats().bytes_device)
+        t.destroy()
+    assert out["off"][0] == out["six"][0] == out["spare"][0]       # bit-identical recurrence residual
+    assert out["off"][1] == out["six"][1] == out["spare"][1]       # and iterate (its true residual)
+    assert out["spare"][2] > out["six"][2] >= out["off"][2]
+    # a nearly full card: a handle that fits without spare slots is still built, with six slots
+    oi_option("place_trials", 4, reset=32)
+    free, total = oia.device_memory()
+    hog = oia.DeviceBuffer(int(free - 0.26 * total))  # leaves 26 % of the card: spare slots would cut into the last quarter
+    t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
+    pl = t.placement()
+    assert pl["nslots"] == 6 and pl["tried"] == 4
+    t.cg_begin(); t.cg_iterate(K + 1); t.sync()
+    assert t.cg_state()[1] == out["off"][0]
+    t.cg_finish()
+    t.destroy(); hog.free(); buf.free()
