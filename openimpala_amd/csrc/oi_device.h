@@ -28,6 +28,7 @@ struct Tune {
   int cg1_xskip = 1;     // k_cg1: x touched every second iteration
   int cg1_fullline = 1;  // compacted layout: stored lines read and written whole
   int cg1_compact = 1;   // single-kernel variant: r, q, p stored as compacted live lines
+  int cg1_kernel = 0;    // compacted layout: 0 = k_cg1b (descriptor-addressed, all loads of a plane in one burst), 1 = k_cg1
   int apply_kernel = 0;  // stand-alone apply: 0 = wave-autonomous k_apply7, 1 = LDS-tiled k_fused_a<PURE>
   int mg_plain = 0, mg_novec4 = 0, mg_debug = 0;  // multigrid cross-check switches (env OI_MG_PLAIN / _NOVEC4 / _DEBUG)
   long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
@@ -170,7 +171,7 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
-               double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
+               double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff, const long long* plane_first,
                hipStream_t s);
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);

@@ -1942,6 +1942,395 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
   }
 }
 
+// --------------------------------------------------------------------------------------
+// k_cg1b: the same iteration (same arithmetic, same order of operations, bit-identical results) with the memory side
+// rebuilt.  What the shader counters said about k_cg1 (profiles/r02/k_cg1_sq_counters.txt): waves wait 83 % of their
+// time, the vector ALUs are busy 20 %, HBM is not pushing back -- and its ISA shows why: every `if (line stored)` is a
+// divergent branch with its loads inside, so a wave walks through up to FIVE dependent HBM round trips per plane (row 0's
+// r/q/p, row 0's x and p_{k-2}, row 1's r/q/p, row 1's x, the halo).  Here every access goes through a buffer
+// descriptor rebuilt per plane from scalars (plane base + 32-bit lane offset; a lane that has nothing to load or store
+// gets an out-of-range offset and the hardware drops it: predication without a branch).  All loads of a plane -- code
+// bytes and line slots two planes ahead, r/q/p, x, p_{k-2}, the halo's r/q/p -- are issued back to back in straight-line
+// code and waited for once.  Compacted layout only (the dense layout keeps k_cg1).
+// --------------------------------------------------------------------------------------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kOob = 0x7ffff000;          // lane offset that every descriptor's range check rejects
+constexpr long long kBufMax = 0x7fff0000;  // largest range (bytes) a descriptor may cover here
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double2 bld2(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ double bld1(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+__device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, int off, double a, double b) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(a, b)), r, off, 0, 0);
+}
+// the search direction through a descriptor; `off` is the byte offset the fp64 vectors use (fp32 storage: half of it).
+// Loads return the bits as they were stored (Pair / One); they are widened when they are used, not when they are issued,
+// so that no conversion sits between the loads of a plane.
+template <typename PT> struct PBuf;
+template <> struct PBuf<double> {
+  typedef double2 Pair;
+  typedef double One;
+  static constexpr int kLineBytes = 8 * kLV;
+  static __device__ __forceinline__ Pair ld_pair(__amdgpu_buffer_rsrc_t r, int off) { return bld2(r, off); }
+  static __device__ __forceinline__ One ld_one(__amdgpu_buffer_rsrc_t r, int off) { return bld1(r, off); }
+  static __device__ __forceinline__ double2 wide(Pair v) { return v; }
+  static __device__ __forceinline__ double wide1(One v) { return v; }
+  static __device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t r, int off, double a, double b) { bst2(r, off, a, b); }
+};
+template <> struct PBuf<float> {
+  typedef float2 Pair;
+  typedef float One;
+  static constexpr int kLineBytes = 4 * kLV;
+  static __device__ __forceinline__ Pair ld_pair(__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off >> 1, 0, 0));
+  }
+  static __device__ __forceinline__ One ld_one(__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off >> 1, 0, 0));
+  }
+  static __device__ __forceinline__ double2 wide(Pair f) { return make_double2((double)f.x, (double)f.y); }
+  static __device__ __forceinline__ double wide1(One f) { return (double)f; }
+  static __device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t r, int off, double a, double b) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, make_float2((float)a, (float)b)), r, off >> 1, 0, 0);
+  }
+};
+
+template <int R, int NW, typename PT, bool JACOBI>
+__global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
+                                                    const double* __restrict__ r_in, double* __restrict__ r_out,
+                                                    const double* __restrict__ q_in, double* __restrict__ q_out,
+                                                    const PT* __restrict__ p_in, PT* __restrict__ p_out,
+                                                    double* rec, int k, int xskip, int zchunk,
+                                                    int tiles_x, int tiles_y, int nzc, int part, int partial_base,
+                                                    double* __restrict__ partials, Ctrl* ctrl,
+                                                    const int* __restrict__ lineoff, const long long* __restrict__ plane_first,
+                                                    int LW, int fullline) {
+  constexpr int BY = NW * R;
+  constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
+  static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
+  if (ctrl->done) return;
+  // p_k of three consecutive planes (ring): the z neighbours are read from here, not carried in registers
+  __shared__ __attribute__((aligned(16))) double tile[3 * TS];
+  __shared__ double red[NW];
+
+  const int nsel = part == 0 ? nzc : (part == 1 ? min(2, nzc) : nzc - 2);
+  const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nsel, g.tune.tile_map);
+  const int tx = L % tiles_x, ty = (L / tiles_x) % tiles_y, zsel = L / (tiles_x * tiles_y);
+  const int zc = part == 0 ? zsel : (part == 1 ? (zsel == 0 ? 0 : nzc - 1) : zsel + 1);
+
+  double beta = 0.0, alpha_prev = 0.0, alpha_prev2 = 0.0;
+  if (k > 0) {
+    double* rk1 = rec + R1_STRIDE * (k - 1);
+    const Cg1Scalars sc = cg1_scalars_of(rk1, ctrl->tol2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      rk1[R1_ALPHA] = sc.alpha;
+      rk1[R1_BETA] = sc.beta;
+      if (sc.converged) ctrl->done = k;
+    }
+    if (sc.converged) return;
+    alpha_prev = sc.alpha;
+    beta = sc.beta;
+  }
+  const bool do_x = xskip ? (k >= 2 && (k & 1) == 0) : (k > 0);
+  if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
+
+  const int lane = threadIdx.x & 63;
+  const int wu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // the wave index as a SCALAR: rows are scalars too
+  const int i = tx * kBX + 2 * lane, j0 = ty * BY;
+  const bool in_x = i < g.pitch;
+  const int gs = 1 + zc * zchunk, ge = min(g.nzl + 1, gs + zchunk);
+  // per-lane parts of the offsets inside a plane (the row part is a scalar, added when the access is formed)
+  const int ivox = in_x ? i : kOob;                          // code bytes; x 8: x
+  const int ivox8 = in_x ? 8 * i : kOob;
+  const int ilin = in_x ? (i >> kLVs) * 4 : kOob;            // slot table
+  const int sub = (i & (kLV - 1)) * 8;                       // this lane's pair inside its line (fp64 bytes)
+  // halo lanes: waves 0 and 1 the rows below / above the tile (a voxel pair per lane), wave 2 the columns left / right
+  const int hrow = (wu == 0) ? j0 - 1 : j0 + BY;
+  const bool yhalo = (wu < 2) && in_x && hrow >= 0 && hrow < g.ny;
+  const int xh_row = j0 + (lane >> 1);
+  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const bool xhalo = (wu == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
+  const int hvox = yhalo ? hrow * g.pitch + i : (xhalo ? xh_row * g.pitch + xh_i : kOob);
+  const int hlin = yhalo ? (hrow * LW + (i >> kLVs)) * 4 : (xhalo ? (xh_row * LW + (xh_i >> kLVs)) * 4 : kOob);
+  const int hsub = yhalo ? sub : (xh_i & (kLV - 1)) * 8;
+  const bool is_halo = yhalo || xhalo;
+
+  const long long plane_lines4 = 4ll * g.ny * LW;
+  auto code_buf = [&](int p) { return buf_of(code + (long long)p * g.plane, g.plane); };
+  auto slot_buf = [&](int p) { return buf_of(reinterpret_cast<const char*>(lineoff) + (long long)p * plane_lines4, plane_lines4); };
+  auto x_buf = [&](int p) { return buf_of(x + (long long)p * g.plane, 8ll * g.plane); };
+  auto row_of = [&](int rr_) { return j0 + wu + rr_ * NW; };  // scalar
+
+  // ---- code bytes and line slots of plane p (they arrive one iteration before they are used) ----
+  auto codes_issue = [&](int p, unsigned short (&cn)[R], int (&ln)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) { cn[rr_] = 0; ln[rr_] = -1; }
+    if (p <= g.nzl + 1) {
+      const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
+#pragma unroll
+      for (int rr_ = 0; rr_ < R; ++rr_) {
+        const int j = row_of(rr_);
+        if (j < g.ny) {  // (scalar)
+          // (the row's offset is added into the LANE offset, not passed as the instruction's scalar offset: with the scalar
+          // offset the fp32-p build of this kernel read x from a wrong row now and then -- the compiler reuses the scalar
+          // register two instructions after the load that names it; profiles/r02/k_cg1b_soffset_hazard.txt)
+          cn[rr_] = __builtin_amdgcn_raw_buffer_load_b16(cb, ivox + j * g.pitch, 0, 0);
+          // a lane outside the row reads 0 from the range check, which would be slot 0: such lanes have code 0 and the
+          // slot is only looked at together with in_x
+          ln[rr_] = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, ilin + j * LW * 4, 0, 0);
+        }
+      }
+    }
+  };
+  unsigned hcode = 0;  // halo lanes: code byte(s) and slot of their halo voxel (pair) in the plane staged next
+  int hslot = 0;
+  auto halo_codes_issue = [&](int p) {
+    hcode = 0; hslot = 0;
+    if (p <= g.nzl + 1 && wu < 3) {
+      const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
+      if (wu < 2) hcode = __builtin_amdgcn_raw_buffer_load_b16(cb, hvox, 0, 0);
+      else hcode = __builtin_amdgcn_raw_buffer_load_b8(cb, hvox, 0, 0);
+      hslot = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, hlin, 0, 0);
+    }
+  };
+  typedef typename PBuf<PT>::Pair PPair;
+  struct Raw { double2 r[R], q[R], xv[R]; PPair p[R], pold[R]; int off[R], xoff[R]; };
+  struct HRaw { double2 r, q; PPair p; typename PBuf<PT>::One p1; };
+
+  // ---- issue every load of plane p: r, q, p of the tile rows; x and p_{k-2} where x is updated ----
+  auto plane_issue = [&](int p, const unsigned short (&cn)[R], const int (&ln)[R], long long pfa, long long pfb, Raw& raw, int mode) {
+    const long long nb = (long long)(8 * kLV) * (pfb - pfa);
+    const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
+    const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
+    const bool with_x = mode == 1 && do_x;
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const bool st = in_x && (fullline ? ln[rr_] >= 0 : cn[rr_] != 0);  // (ln = -1, cn = 0 on rows outside the volume)
+      raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
+      raw.r[rr_] = bld2(rb, raw.off[rr_]);
+      raw.q[rr_] = bld2(qb, raw.off[rr_]);
+      raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
+    }
+    if (with_x) {
+      const __amdgpu_buffer_rsrc_t xb = x_buf(p);
+      const __amdgpu_buffer_rsrc_t ob = buf_of(p_out + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
+#pragma unroll
+      for (int rr_ = 0; rr_ < R; ++rr_) {
+        raw.xoff[rr_] = raw.off[rr_] == kOob ? kOob : ivox8 + row_of(rr_) * g.pitch * 8;
+        raw.xv[rr_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(xb, raw.xoff[rr_], 0, 0));
+        if (xskip) raw.pold[rr_] = PBuf<PT>::ld_pair(ob, raw.off[rr_]);  // p_{k-2}
+      }
+    }
+  };
+  // mode 0: a halo plane owned by another block (nothing stored); 1: an output plane of this block (r_k, p_k stored, x
+  // updated); 2: a ghost plane of the slab, kept current by the block that marches over it (r_k, p_k)
+  auto plane_finish = [&](int p, const unsigned short (&cn)[R], long long pfa, long long pfb, const Raw& raw, double2 (&pn)[R],
+                          double2 (&rn)[R], int mode) {
+    const long long nb = (long long)(8 * kLV) * (pfb - pfa);
+    const __amdgpu_buffer_rsrc_t rob = buf_of(r_out + kLV * pfa, nb);
+    const __amdgpu_buffer_rsrc_t pob = buf_of(p_out + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
+    const __amdgpu_buffer_rsrc_t xb = x_buf(p);
+    const bool with_x = mode == 1 && do_x;
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      // (a lane without a stored line read zeros: r0 = r1 = 0, p = 0, exactly what the branch of k_cg1 leaves there)
+      const double2 rv = raw.r[rr_], qv = raw.q[rr_], pin = PBuf<PT>::wide(raw.p[rr_]);
+      const double r0 = rv.x - alpha_prev * qv.x, r1 = rv.y - alpha_prev * qv.y;
+      rn[rr_] = make_double2(r0, r1);
+      double z0 = r0, z1 = r1;
+      if (JACOBI) {
+        const unsigned short cc = cn[rr_];
+        if (cc & 0xff) z0 = r0 / (double)(cc & 0xff);
+        if (cc >> 8) z1 = r1 / (double)(cc >> 8);
+      }
+      pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
+      if (mode != 0) {
+        bst2(rob, raw.off[rr_], r0, r1);
+        if (with_x) {
+          const double2 xv = raw.xv[rr_];
+#ifdef OI_DEBUG_X
+          if (raw.xoff[rr_] != kOob) {
+            const double2 xv2 = ld2(x + (long long)p * g.plane + (long long)row_of(rr_) * g.pitch + i);
+            if (xv.x != xv2.x || xv.y != xv2.y)
+              printf("x mismatch k %d plane %d row %d i %d: buffer %g %g plain %g %g  xoff %d soff %d\n", k, p, row_of(rr_), i, xv.x, xv.y,
+                     xv2.x, xv2.y, raw.xoff[rr_], row_of(rr_) * g.pitch * 8);
+          }
+#endif
+          double a0 = alpha_prev * pin.x, a1 = alpha_prev * pin.y;
+          if (xskip) {
+            const double2 pold = PBuf<PT>::wide(raw.pold[rr_]);
+            a0 = alpha_prev2 * pold.x + a0; a1 = alpha_prev2 * pold.y + a1;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(xv.x + a0, xv.y + a1)), xb,
+                                                 raw.xoff[rr_], 0, 0);
+        }
+        PBuf<PT>::st_pair(pob, raw.off[rr_], pn[rr_].x, pn[rr_].y);
+      }
+    }
+  };
+  // ---- the halo of plane p (its code bytes and slots came an iteration ahead) ----
+  auto halo_offset = [&](long long pfa) { return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob; };
+  auto halo_issue = [&](long long pfa, long long pfb, int off, HRaw& h) {
+    h.r = h.q = make_double2(0.0, 0.0);
+    h.p = PPair();
+    h.p1 = 0;
+    if (wu < 3) {
+      const long long nb = (long long)(8 * kLV) * (pfb - pfa);
+      const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
+      const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
+      if (wu < 2) {
+        h.r = bld2(rb, off); h.q = bld2(qb, off); h.p = PBuf<PT>::ld_pair(pb, off);
+      } else {
+        h.r.x = bld1(rb, off); h.q.x = bld1(qb, off); h.p1 = PBuf<PT>::ld_one(pb, off);
+      }
+    }
+  };
+  auto stage_rows = [&](double* T, const double2 (&pn)[R]) {
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_)
+      *reinterpret_cast<double2*>(&T[(wu + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+  };
+  auto stage_halo = [&](double* T, const HRaw& hr) {
+    if (wu < 2) {
+      double2 h = make_double2(0.0, 0.0);
+      if (hcode) {
+        double z0 = hr.r.x - alpha_prev * hr.q.x, z1 = hr.r.y - alpha_prev * hr.q.y;
+        if (JACOBI) {
+          if (hcode & 0xff) z0 = z0 / (double)(hcode & 0xff);
+          if (hcode >> 8) z1 = z1 / (double)(hcode >> 8);
+        }
+        const double2 hp = PBuf<PT>::wide(hr.p);
+        h.x = PIo<PT>::rnd(z0 + beta * hp.x); h.y = PIo<PT>::rnd(z1 + beta * hp.y);
+      }
+      *reinterpret_cast<double2*>(&T[((wu == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+    } else if (wu == 2 && lane < 2 * BY) {
+      double h = 0.0;
+      if (hcode) {
+        double z = hr.r.x - alpha_prev * hr.q.x;
+        if (JACOBI) z = z / (double)hcode;
+        h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
+      }
+      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+    }
+  };
+
+  double2 pn_nxt[R], rn_cur[R], rn_nxt[R];
+  unsigned short cc_cur[R], cc_nxt[R], cc_nn[R];
+  int lo_cur[R], lo_nxt[R], lo_nn[R];
+  // first slots of planes gz - 1 .. gz + 2 (scalars, a plane ahead of their use)
+  auto pf_at = [&](int p) { return plane_first[min(p, g.nzl + 2)]; };
+  long long pfm = pf_at(gs - 1), pf0 = pf_at(gs), pf1 = pf_at(gs + 1), pf2 = pf_at(gs + 2);
+  int b_prev = 0, b_cur = TS, b_nxt = 2 * TS;  // ring positions (doubles) of planes gz - 1, gz, gz + 1
+  {
+    Raw raw;
+    HRaw hr;
+    halo_codes_issue(gs);
+    codes_issue(gs - 1, cc_nn, lo_nn);
+    codes_issue(gs, cc_cur, lo_cur);
+    codes_issue(gs + 1, cc_nxt, lo_nxt);
+    plane_issue(gs - 1, cc_nn, lo_nn, pfm, pf0, raw, gs == 1 ? 2 : 0);
+    plane_finish(gs - 1, cc_nn, pfm, pf0, raw, pn_nxt, rn_nxt, gs == 1 ? 2 : 0);
+    stage_rows(tile + b_prev, pn_nxt);
+    const int hoff = halo_offset(pf0);
+    plane_issue(gs, cc_cur, lo_cur, pf0, pf1, raw, 1);
+    halo_issue(pf0, pf1, hoff, hr);
+    plane_finish(gs, cc_cur, pf0, pf1, raw, pn_nxt, rn_cur, 1);
+    stage_rows(tile + b_cur, pn_nxt);
+    stage_halo(tile + b_cur, hr);
+    halo_codes_issue(gs + 1);
+  }
+  __syncthreads();
+
+  double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
+  for (int gz = gs; gz < ge; ++gz) {
+    // pf0 .. pf2 = first slots of planes gz, gz + 1, gz + 2
+    const long long pf3 = pf_at(gz + 3);
+    const int mode = gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
+    const bool more = gz + 1 < ge;
+    Raw raw;
+    HRaw hr;
+    // every load of this iteration, back to back: plane gz + 1's vectors and halo, plane gz + 2's codes and slots
+    const int hoff = halo_offset(pf1);  // (first: the slot came with the previous iteration's loads, nothing newer is waited for)
+    __builtin_amdgcn_sched_barrier(0);
+    plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
+    if (more) halo_issue(pf1, pf2, hoff, hr);
+    const unsigned hcode_now = hcode;
+    codes_issue(gz + 2, cc_nn, lo_nn);
+    if (more) halo_codes_issue(gz + 2);
+    const unsigned hcode_next = hcode;
+    const int hslot_next = hslot;
+    __builtin_amdgcn_sched_barrier(0);
+    plane_finish(gz + 1, cc_nxt, pf1, pf2, raw, pn_nxt, rn_nxt, mode);
+    if (more) {
+      stage_rows(tile + b_nxt, pn_nxt);
+      hcode = hcode_now;
+      stage_halo(tile + b_nxt, hr);
+    }
+    hcode = hcode_next; hslot = hslot_next;
+    const double* T = tile + b_cur;
+    const double* Tp = tile + b_prev;
+    const long long nbq = (long long)(8 * kLV) * (pf1 - pf0);
+    const __amdgpu_buffer_rsrc_t qob = buf_of(q_out + kLV * pf0, nbq);
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      const unsigned short cc = cc_cur[rr_];
+      const bool stored = in_x && lo_cur[rr_] >= 0;
+      const int qoff = (lo_cur[rr_] - (int)pf0) * (8 * kLV) + sub;
+      if (fullline && !cc && stored) bst2(qob, qoff, 0.0, 0.0);  // whole lines
+      if (cc) {  // q and every partial sum vanish where both voxels are non-free
+        const int base = (wu + rr_ * NW + 1) * kLP + 2 + 2 * lane;
+        const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
+        const double2 pc = *reinterpret_cast<const double2*>(&T[base]);
+        const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
+        const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
+        const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
+        const double2 zm = *reinterpret_cast<const double2*>(&Tp[base]);
+        const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
+        const double2 rc = rn_cur[rr_];
+        const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + zm.x) + pn_nxt[rr_].x;
+        const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + zm.y) + pn_nxt[rr_].y;
+        const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
+        const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
+        bst2(qob, qoff, q0, q1);
+        double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
+        if (JACOBI) {
+          if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
+          if (c1) { z1 = rc.y / (double)c1; d1 = q1 / (double)c1; }
+        }
+        s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
+        s_rz += rc.x * z0; s_rz += rc.y * z1;
+        s_pq += pc.x * q0; s_pq += pc.y * q1;
+        s_zq += z0 * q0; s_zq += z1 * q1;
+        s_qdq += q0 * d0; s_qdq += q1 * d1;
+      }
+    }
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      rn_cur[rr_] = rn_nxt[rr_];
+      cc_cur[rr_] = cc_nxt[rr_]; cc_nxt[rr_] = cc_nn[rr_];
+      lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
+    }
+    pf0 = pf1; pf1 = pf2; pf2 = pf3;
+    { const int t = b_prev; b_prev = b_cur; b_cur = b_nxt; b_nxt = t; }
+    __syncthreads();
+  }
+  const double t0 = block_sum(s_rr, red);
+  const double t1 = block_sum(s_rz, red);
+  const double t2 = block_sum(s_pq, red);
+  const double t3 = block_sum(s_zq, red);
+  const double t4 = block_sum(s_qdq, red);
+  if (threadIdx.x == 0) {
+    double* o = partials + 5 * ((long long)partial_base + blockIdx.x);
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
+  }
+}
+
 // k_cg1 tile shapes (Tune::cg1_rows x cg1_waves): 8 rows = 8 waves x 1 row per thread, 16 = 8 x 2, 32 = 16 waves x 2
 // rows (the 8-wave x 4-row form needs 194 VGPRs and fits only one block per CU; tile_rows 33 selects it)
 void tune_set_cg1_tile(Tune& t, int tile_rows) {
@@ -1961,11 +2350,32 @@ static void launch_cg1_k(int blocks, const Geom& g, const uint8_t* code, double*
                      q_out, (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part,
                      partial_base, partials, ctrl, lineoff, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
 }
+template <int R, int NW, typename PT, bool JAC>
+static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
+                          const double* q_in, double* q_out, const void* p_in, void* p_out, double* rec, int k,
+                          int zchunk, int tiles_x, int tiles_y, int nzc, int part, int partial_base, double* partials,
+                          Ctrl* ctrl, const int* lineoff, const long long* plane_first, hipStream_t s) {
+  hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
+                     (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
+                     partials, ctrl, lineoff, plane_first, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
+}
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                          const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
                          double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, int part,
-                         int partial_base, double* partials, Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+                         int partial_base, double* partials, Ctrl* ctrl, const int* lineoff, const long long* plane_first,
+                         hipStream_t s) {
+  // compacted layout: the descriptor-addressed kernel, unless a plane is too large for a 31-bit range or the tuning
+  // asks for the first form (cross-checks)
+  if (lineoff && plane_first && g.tune.cg1_kernel == 0 && 8ll * g.plane < kBufMax) {
+    if (jacobi)
+      launch_cg1b_k<R, NW, PT, true>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, tiles_y,
+                                     nzc, part, partial_base, partials, ctrl, lineoff, plane_first, s);
+    else
+      launch_cg1b_k<R, NW, PT, false>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, tiles_y,
+                                      nzc, part, partial_base, partials, ctrl, lineoff, plane_first, s);
+    return;
+  }
 #define OI_CG1K(JAC, CMP)                                                                                              \
   launch_cg1_k<R, NW, PT, JAC, CMP>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, \
                                     tiles_y, nzc, part, partial_base, partials, ctrl, lineoff, s)
@@ -1981,16 +2391,23 @@ static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double*
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
                double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
-               hipStream_t s) {
+               const long long* plane_first, hipStream_t s) {
   // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
   // off on large planes; locals only, handles may be driven from several host threads
+  // the descriptor-addressed kernel (k_cg1b): 8-wave, 16-row tiles (two blocks per CU out of step with each other) and
+  // 16-plane chunks (profiles/r02/k_cg1b_sweep.txt: 7.87 ms against 8.04 / 8.43 with 32 / 64 planes, 8.57 k_cg1)
+  const bool descr = lineoff && plane_first && g.tune.cg1_kernel == 0 && 8ll * g.plane < kBufMax;
   const int R = g.tune.cg1_auto ? 2 : g.tune.cg1_rows;
-  const int NW = g.tune.cg1_auto ? ((g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g.tune.cg1_waves;
+  const int NW = g.tune.cg1_auto ? ((!descr && g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g.tune.cg1_waves;
   const int by = NW * R;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
   int zchunk, nzc;
-  if (split && g.tune.zchunk <= 0) {
+  if (!split && g.tune.zchunk <= 0 && descr && cols * ((g.nzl + 15) / 16) >= 2048) {
+    Geom gs_ = g;
+    gs_.tune.zchunk = 16;
+    pick_chunks(gs_, cols, false, &zchunk, &nzc);
+  } else if (split && g.tune.zchunk <= 0) {
     Geom gs_ = g;
     gs_.tune.zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
     if (gs_.tune.zchunk > 64) gs_.tune.zchunk = 64;
@@ -2007,10 +2424,10 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
   do {                                                                                                             \
     if (p_f32) launch_cg1_r<RR, WW, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, \
                                            k, zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl,   \
-                                           lineoff, s);                                                            \
+                                           lineoff, plane_first, s);                                               \
     else launch_cg1_r<RR, WW, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,   \
                                       zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl, lineoff,  \
-                                      s);                                                                          \
+                                      plane_first, s);                                                             \
   } while (0)
   if (R == 4) OI_CG1(4, 8);
   else if (R == 2 && NW == 16) OI_CG1(2, 16);
@@ -2029,16 +2446,29 @@ __device__ __forceinline__ void cg1_scalars(double* rk, Ctrl* ctrl, int k) {
   rk[R1_BETA] = sc.beta;
 }
 
-// one wave per component: lane l adds partials l, l+64, ... in order, then a shuffle tree --
-// a fixed summation order, no block barriers until the five sums are in place
-__global__ void __launch_bounds__(320) k_finalize1(const double* __restrict__ partials, int nblocks, double* rk,
+// three waves per component (15 waves): lane L = 0 .. 191 of a component adds partials L, L + 192, ... with four
+// independent running sums (the loads of a round are in flight together: the descriptor-addressed CG kernel launches
+// 32768 blocks at 1024^3 and one wave per component took 0.2 ms over them), then a fixed tree -- the order of
+// summation depends on the number of blocks only, never on timing
+__global__ void __launch_bounds__(960) k_finalize1(const double* __restrict__ partials, int nblocks, double* rk,
                                                     Ctrl* ctrl, int k, int with_scalars) {
   if (ctrl->done) return;
-  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double v = 0.0;
-  for (int b = lane; b < nblocks; b += 64) v += partials[(long long)b * 5 + c];
-  v = wave_sum(v);
-  if (lane == 0) rk[c] = v;
+  __shared__ double part[15];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = wv % 5, L = (wv / 5) * 64 + lane;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = L;
+  for (; b + 576 < nblocks; b += 768) {
+    a0 += partials[(long long)b * 5 + c];
+    a1 += partials[(long long)(b + 192) * 5 + c];
+    a2 += partials[(long long)(b + 384) * 5 + c];
+    a3 += partials[(long long)(b + 576) * 5 + c];
+  }
+  for (; b < nblocks; b += 192) a0 += partials[(long long)b * 5 + c];
+  const double v = wave_sum((a0 + a1) + (a2 + a3));
+  if (lane == 0) part[wv] = v;
+  __syncthreads();
+  if (threadIdx.x < 5) rk[threadIdx.x] = (part[threadIdx.x] + part[threadIdx.x + 5]) + part[threadIdx.x + 10];
   __syncthreads();
   if (threadIdx.x == 0 && with_scalars) cg1_scalars(rk, ctrl, k);
 }
@@ -2049,7 +2479,7 @@ __global__ void k_scalars1(double* rk, Ctrl* ctrl, int k) {
 
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(320), 0, s, partials, nblocks, rec_k, ctrl, k, with_scalars);
+  hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(960), 0, s, partials, nblocks, rec_k, ctrl, k, with_scalars);
 }
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s) {
   hipLaunchKernelGGL(k_scalars1, dim3(1), dim3(1), 0, s, rec_k, ctrl, k);

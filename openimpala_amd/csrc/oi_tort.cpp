@@ -880,7 +880,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       {
         PROF(K_CG1);
         nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                        h->partials, h->ctrl, 0, 0, 0, h->lineoff, s);
+                        h->partials, h->ctrl, 0, 0, 0, h->lineoff, h->plane_first_dev, s);
       }
       if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       // (alpha_k, beta_{k+1} and the stop test are formed in the prologue of kernel k + 1; cg_iterate closes the last record)
@@ -896,10 +896,10 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
         HIPC(hipEventRecord(h->ev_start, s));
         HIPC(hipStreamWaitEvent(h->aux_stream, h->ev_start, 0));
         nb_b = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 1, 0, h->lineoff, s);
+                          h->partials, h->ctrl, 1, 1, 0, h->lineoff, h->plane_first_dev, s);
         HIPC(hipEventRecord(h->ev_boundary, s));
         nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 2, nb_b < 0 ? 0 : nb_b, h->lineoff, h->aux_stream);
+                          h->partials, h->ctrl, 1, 2, nb_b < 0 ? 0 : nb_b, h->lineoff, h->plane_first_dev, h->aux_stream);
         HIPC(hipEventRecord(h->ev_interior, h->aux_stream));
         // (a transport whose exchange may not overlap its own collectives keeps everything on the solver stream)
         hipStream_t xs = h->comm->exchange_overlaps ? h->comm_stream : s;
@@ -1738,6 +1738,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "force_comm") t.force_comm = iv != 0;
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;
+  else if (k == "cg1_kernel") t.cg1_kernel = iv;
   else { oi::set_error("%s: unknown key '%s'", __func__, key); return OI_BAD_ARG; }
   oi::set_default_tune(t);
   return OI_OK;

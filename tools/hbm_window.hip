@@ -50,6 +50,31 @@ __global__ __launch_bounds__(256) void k_rw(char* base, const long long* off, in
   }
 }
 
+// half-empty wave instructions: every lane group of 4 (one 64-byte line) takes part or not by `pattern` (bit g of the
+// 16-bit pattern, rotated per wave-row so that memory is still covered evenly); useful bytes only are counted.
+// mode 0: the inactive lanes are switched off by a branch; 1: they get an out-of-range buffer offset
+__global__ __launch_bounds__(256) void k_read_sparse(const char* base, long long units, unsigned pattern, int mode, unsigned* sink) {
+  const int lane = threadIdx.x & 63;
+  const long long stride = (long long)gridDim.x * 256;
+  u4 acc = {0, 0, 0, 0};
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fff0000, 0x00020000);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < units; i += stride) {
+    const unsigned rot = (unsigned)((i >> 6) * 5) & 15;
+    const unsigned pat = ((pattern >> rot) | (pattern << (16 - rot))) & 0xffffu;
+    const bool on = (pat >> (lane >> 2)) & 1;
+    u4 v = {0, 0, 0, 0};
+    if (mode == 0) {
+      if (on) v = __builtin_nontemporal_load((const u4*)base + i);
+    } else {
+      const char* wbase = base + ((i >> 6) << 10);  // this wave-row's 1 KiB (uniform), lane offset below
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)__builtin_amdgcn_readfirstlane((unsigned long long)wbase & 0xffffffffu) == 0 ? (void*)wbase : (void*)wbase, 0, 1024, 0x00020000);
+      v = __builtin_amdgcn_raw_buffer_load_b128(rs, on ? lane * 16 : 0x7ffff000, 0, 0);
+    }
+    acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *sink = 1;
+}
+
 static char* big;
 static long long* d_off;
 static unsigned* sink;
@@ -90,6 +115,25 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&big, total)); CK(hipMalloc(&d_off, 64 * 8)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(big, 1, total)); CK(hipDeviceSynchronize());
   printf("arena of %lld GiB at %p\n", total / GiB, (void*)big);
+  if (argc > 2 && argv[2][0] == 's') {  // sparse wave instructions
+    printf("-- read of a 16 GiB window, 64-byte lines taking part by pattern: useful TB/s (lines fetched / all lines)\n");
+    for (unsigned pattern : {0xffffu, 0xfff0u, 0xff00u, 0xf0f0u, 0xaaaau, 0xccccu, 0x8888u, 0x0101u}) {
+      const int live = __builtin_popcount(pattern);
+      for (int mode = 0; mode < 1; ++mode) {
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        const long long units = 16 * GiB / 16;
+        auto go = [&] { hipLaunchKernelGGL(k_read_sparse, dim3(2048), dim3(256), 0, 0, big, units, pattern, mode, sink); };
+        go();
+        CK(hipEventRecord(a));
+        for (int r = 0; r < 4; ++r) go();
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("  pattern %04x (%2d of 16 lines)  %s  %7.3f ms  useful %.3f TB/s\n", pattern, live, mode ? "range-checked" : "branch       ",
+               ms / 4, 16.0 * GiB * live / 16 * 4 / (ms * 1e-3) / 1e12);
+      }
+    }
+    return 0;
+  }
   if (argc > 2 && argv[2][0] == 'b') {  // which address bits matter between a read and a written stream?
     printf("-- copy of a 512 MiB window at O to O + 2^k (+ 512 MiB when they would overlap), TB/s\n        ");
     const long long Os[4] = {0, 5 * GiB, 77 * GiB + 300 * MiB, 130 * GiB};
