@@ -244,6 +244,8 @@ int oi_tort_line_voxels(void);
  *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
  *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 32; 0 = separate
  *                   allocations in order, no spare slots; see oi_tort_placement)
+ *   "cg1_kernel"    single-kernel CG, compacted layout: 0 = k_cg1b (descriptor-addressed accesses, default), 1 = k_cg1
+ *                   (branches around plain global accesses; same iterates bit for bit, kept as the cross-check)
  *   "place_slots"   slots of the vector arena (default 12, 6 to 16: six are used, spare ones widen the choice; fewer are
  *                   taken when less than a quarter of the card would stay free)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,

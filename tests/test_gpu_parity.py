@@ -590,6 +590,32 @@ def test_single_kernel_layouts_compacted_and_dense(sample, goldens):
     assert out[1][3] < out[0][3]   # (the 100^3 sample is fine-grained: most lines hold a free voxel)
 
 
+@pytest.mark.parametrize("rows,pf32,jacobi,zchunk,xskip", [(8, 0, False, 0, 1), (16, 0, True, 5, 1), (16, 1, False, 0, 1), (32, 1, True, 0, 0),
+                                                            (32, 0, False, 7, 0)])
+def test_single_kernel_iteration_two_kernels_are_bit_identical(sample, oi_option, rows, pf32, jacobi, zchunk, xskip):
+    """The single-kernel iteration exists twice for the compacted layout: k_cg1b (default: every access through a buffer
+    descriptor with range-check predication, all loads of a plane issued in one burst, p_k of three planes in an LDS ring)
+    and k_cg1 (branches around plain global accesses).  Same arithmetic in the same order: the residual after K launches
+    and the iterate x are identical bit for bit, over tile shapes, fp32-stored p (the build in which a scalar instruction
+    offset once let x be read from a wrong row), Jacobi, odd chunk lengths and x touched every iteration."""
+    out = {}
+    try:
+        for kern in (1, 0):
+            oi_option("cg1_kernel", kern, reset=0)
+            oia.set_tuning(16, zchunk, 32, rows, xskip)
+            t = oia.TortuosityMI355(sample, 1, 2, 0.0, 1.0, kernel=oia.KERNEL_FUSED1, p_storage=pf32, eps=1e-300, maxiter=500,
+                                    precond=oia.PRECOND_JACOBI if jacobi else oia.PRECOND_NONE)
+            t.cg_begin(); t.cg_iterate(36); t.sync()
+            its, rel, conv = t.cg_state()
+            t.cg_finish()
+            out[kern] = (its, rel, t.solution().copy())
+            t.destroy()
+    finally:
+        oia.set_tuning()
+    assert out[0][0] == out[1][0] == 35 and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2])
+
+
 @pytest.mark.parametrize("p_storage", [oia.STORE_F64, oia.STORE_F32])
 def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_storage):
     """r, q, z, p of the multigrid-preconditioned two-kernel iteration as compacted lines (default) or dense:
