@@ -2411,7 +2411,7 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
     Geom gs_ = g;
     gs_.tune.zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
     if (gs_.tune.zchunk > 64) gs_.tune.zchunk = 64;
-    if (gs_.tune.zchunk < 16) gs_.tune.zchunk = 16;
+    if (gs_.tune.zchunk < 16 || descr) gs_.tune.zchunk = 16;  // (k_cg1b: 16-plane chunks, and the planes leave sooner)
     pick_chunks(gs_, cols, false, &zchunk, &nzc);
   } else {
     pick_chunks(g, cols, false, &zchunk, &nzc);

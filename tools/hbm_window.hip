@@ -115,6 +115,17 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&big, total)); CK(hipMalloc(&d_off, 64 * 8)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(big, 1, total)); CK(hipDeviceSynchronize());
   printf("arena of %lld GiB at %p\n", total / GiB, (void*)big);
+  if (argc > 2 && argv[2][0] == 'd') {  // copy bandwidth against the distance, finely
+    const long long step = (argc > 3 ? atoll(argv[3]) : 256) * MiB, w = 512 * MiB;
+    printf("-- copy of a 512 MiB window at 0 to the window at distance D = m x %lld MiB: TB/s, 16 values per line\n", step / MiB);
+    for (long long m = (w + step - 1) / step; (m * step + w) <= total; ++m) {
+      if ((m % 16) == 0 || m == (w + step - 1) / step) printf("\n  D %7.2f GiB:", (double)(m * step) / GiB);
+      printf(" %.2f", bw_rw(0, 1, {0, m * step}, w, 6));
+      fflush(stdout);
+    }
+    printf("\n");
+    return 0;
+  }
   if (argc > 2 && argv[2][0] == 's') {  // sparse wave instructions
     printf("-- read of a 16 GiB window, 64-byte lines taking part by pattern: useful TB/s (lines fetched / all lines)\n");
     for (unsigned pattern : {0xffffu, 0xfff0u, 0xff00u, 0xf0f0u, 0xaaaau, 0xccccu, 0x8888u, 0x0101u}) {
