@@ -68,7 +68,7 @@ typedef struct oi_tort_opts {
   int maxiter;
   int precond;        /* OI_PRECOND_* */
   int remspot_passes; /* tortuosity.remspot_passes (TortuosityHypre.cpp:254-256), default 0 */
-  int remspot_box_size; /* the inputs file's box_size (default 32): the filter runs per box, see oi_remspot; works on z-slabs */
+  int remspot_box_size; /* the inputs file's box_size (default 48): the filter runs per box, see oi_remspot; works on z-slabs */
   int verbose;        /* 0 silent .. 3 */
   int check_every;    /* host looks at the device convergence flag every this many iterations (<=0: auto) */
   int kernel;         /* OI_KERNEL_* */
@@ -200,7 +200,7 @@ oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
 oi_status oi_tort_true_residual(oi_tort* h, double* relres);
 /* Where the vectors of the single-kernel iteration were put.  When a vector is larger than the 256 MB Infinity Cache,
  * x and the six double-buffered vectors are slots of ONE arena, with spare slots ("place_slots", memory permitting), and
- * `place_trials` placements (oi_tort_set_option, default 32) are timed with the real kernel when the handle is built,
+ * `place_trials` placements (oi_tort_set_option, default 48) are timed with the real kernel when the handle is built,
  * the fastest kept: on MI355X the iteration time depends on the distances between the arrays read and the arrays
  * written (HBM address mapping).  nslots = 0: no arena.  slots7[0..5] = slots of r, q, p[0], r2,
  * q2, p[1]; slots7[6] = number of slots in front of x.  ms_first / ms_best = ms per iteration of the in-order layout
@@ -242,7 +242,7 @@ int oi_tort_line_voxels(void);
  *   "mg_plain" "mg_novec4" "mg_debug"   multigrid cross-check kernels / per-level norms
  *   "mg_replicate_cells" "mg_wmask" "mg_scale"   multigrid level distribution and cycle shape
  *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
- *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 32; 0 = separate
+ *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 48; 0 = separate
  *                   allocations in order, no spare slots; see oi_tort_placement)
  *   "cg1_kernel"    single-kernel CG, compacted layout: 0 = k_cg1b (descriptor-addressed accesses, default), 1 = k_cg1
  *                   (branches around plain global accesses; same iterates bit for bit, kept as the cross-check)

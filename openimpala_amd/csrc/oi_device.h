@@ -34,7 +34,7 @@ struct Tune {
   long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
-  int place_trials = 32; // single-kernel CG: vector placements (slots of one arena) timed when the handle is built, the
+  int place_trials = 48; // single-kernel CG: vector placements (slots of one arena) timed when the handle is built, the
                          // fastest kept; 0 = separate allocations in order, no spare slots (env OI_PLACE_TRIALS)
   int place_slots = 12;  // slots of that arena (6 are used; the spare ones widen the choice), memory permitting
                          // (env OI_PLACE_SLOTS)

@@ -388,7 +388,9 @@ static oi_status place_vectors(oi_tort* h) {
   unsigned rng = 20260001u;
   auto rnd = [&](int m) { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % (unsigned)m); };
   oi_status rc = OI_OK;
-  const int nrandom = trials - trials / 3;
+  // a tenth of all placements are in the fastest class (profiles/r02/k_cg1b_sweep.txt): 40 random ones miss it once in 70
+  // handles, 21 missed it once in 9; the last eight trials are small changes of the best
+  const int nrandom = trials > 12 ? trials - 8 : trials - trials / 3;
   for (int t = 0; t < trials && rc == OI_OK; ++t) {
     int pl[7];
     if (t < nrandom) {  // the in-order layout, then random ones

@@ -132,7 +132,7 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
     buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
     out = {}
     for name, trials, slots in (("off", 0, 12), ("six", 6, 6), ("spare", 10, 12)):
-        oi_option("place_trials", trials, reset=32)
+        oi_option("place_trials", trials, reset=48)
         oi_option("place_slots", slots, reset=12)
         t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
         pl = t.placement()
@@ -151,7 +151,7 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
     assert out["off"][1] == out["six"][1] == out["spare"][1]       # and iterate (its true residual)
     assert out["spare"][2] > out["six"][2] >= out["off"][2]
     # a nearly full card: a handle that fits without spare slots is still built, with six slots
-    oi_option("place_trials", 4, reset=32)
+    oi_option("place_trials", 4, reset=48)
     free, total = oia.device_memory()
     hog = oia.DeviceBuffer(int(free - 0.26 * total))  # leaves 26 % of the card: spare slots would cut into the last quarter
     t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
