@@ -49,6 +49,25 @@ def main(out):
             print("%-64s calls %6s  avg %10.1f us  total %8.2f ms  %5.1f%%" % (
                 short(r["Name"])[:64], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
                 float(r["Percentage"])))
+    # the CG kernel's launches in order: the first ones belong to the placement search (two per placement tried, at
+    # placements of every speed), the LAST `steps` ones are bench.py's timed region -- the figure its line reports
+    trace = find(os.path.join(out, "trace"), "*kernel_trace.csv")
+    line = os.path.join(out, "bench_trace.json")
+    if trace and os.path.exists(line):
+        import json
+        try:
+            bl = json.loads(open(line).read().strip().splitlines()[-1])
+            steps = int(bl["steps"])
+            d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace))
+                 if short(r["Kernel_Name"]).startswith("k_cg1")]
+            d.sort()
+            last = [x[1] for x in d[-steps:]]
+            if last:
+                print("== CG kernel, the last %d launches (the timed region): rocprofv3 avg %.1f us; bench.py's HIP events of the same run "
+                      "%.1f us; all %d launches avg %.1f us ==" % (len(last), sum(last) / len(last) / 1e3, bl["roofline"]["ms_per_launch"] * 1e3,
+                                                                  len(d), sum(x[1] for x in d) / len(d) / 1e3))
+        except (KeyError, ValueError, IndexError):
+            pass
     traffic = defaultdict(float)
     for tag, counter, scale in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
         f = find(os.path.join(out, tag), "*counter_collection.csv")
