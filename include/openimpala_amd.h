@@ -198,6 +198,11 @@ oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes);
  * which no solver variant uses inside its iteration; one dense scratch vector, 8 bytes per voxel; collective on slabs).
  * Same normalisation as stats.final_relres. */
 oi_status oi_tort_true_residual(oi_tort* h, double* relres);
+/* Launch shape the single-kernel CG iteration would take for a slab of nx x ny x nz_local voxels under the current process
+ * defaults -- tile rows, planes per block, blocks (-1: would not fit) -- and the capacity (blocks) of a handle's
+ * partial-sum array for that slab.  Host arithmetic only: no device is touched. */
+oi_status oi_debug_cg1_grid(int nx, int ny, int nz_local, int descr, int split, int part, int* tile_rows, int* zchunk,
+                            int* blocks, int* capacity);
 /* Where the vectors of the single-kernel iteration were put.  When a vector is larger than the 256 MB Infinity Cache,
  * x and the six double-buffered vectors are slots of ONE arena, with spare slots ("place_slots", memory permitting), and
  * `place_trials` placements (oi_tort_set_option, default 48) are timed with the real kernel when the handle is built,

@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
-    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_tort_placement oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
+    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
@@ -147,6 +147,7 @@ def lib():
     L.oi_tort_set_option.argtypes = [C.c_char_p, C.c_double]
     L.oi_tort_retune.argtypes = [vp]
     L.oi_tort_true_residual.argtypes = [vp, C.POINTER(C.c_double)]
+    L.oi_debug_cg1_grid.argtypes = [i, i, i, i, i, i] + [C.POINTER(C.c_int)] * 4
     L.oi_tort_bench_stream.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oi_tort_placement.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oi_tort_line_voxels.argtypes = []
@@ -351,6 +352,13 @@ def stream_copy_bench(nbytes, reps=10):
 def set_option(key, value):
     """Named switch of the process defaults (see include/openimpala_amd.h); new handles only."""
     _check(lib().oi_tort_set_option(key.encode(), float(value)))
+
+
+def cg1_grid(nx, ny, nz_local, descr=1, split=0, part=0):
+    """(tile rows, planes per block, blocks, capacity of the partial-sum array) of the single-kernel iteration: host arithmetic."""
+    v = [C.c_int(0) for _ in range(4)]
+    _check(lib().oi_debug_cg1_grid(nx, ny, nz_local, descr, split, part, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
 
 
 def device_memory():

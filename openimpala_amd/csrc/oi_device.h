@@ -169,6 +169,8 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
                    double* out, float* bcoarse, double* partials, const Ctrl* ctrl, const int* lineoff /* b, out compacted */,
                    hipStream_t s);
 // single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
+struct Cg1Grid { int R, NW, tiles_x, tiles_y, zchunk, nzc, blocks; };
+Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part);
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
                double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff, const long long* plane_first,

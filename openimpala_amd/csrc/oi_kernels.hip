@@ -2384,6 +2384,38 @@ static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double*
 #undef OI_CG1K
 }
 
+// Launch shape of the single-kernel iteration (host arithmetic only; oi_debug_cg1_grid exposes it to the CPU tests).
+// blocks = -1: the grid would not fit the handle's partial-sum array (Tune::max_blocks).
+Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part) {
+  Cg1Grid o{};
+  // automatic tile shape: the descriptor-addressed kernel (k_cg1b) takes 8-wave, 16-row tiles (two blocks per CU out of
+  // step with each other) and 16-plane chunks (profiles/r02/k_cg1b_sweep.txt: 7.87 ms against 8.04 / 8.43 with 32 / 64
+  // planes, 8.57 k_cg1); k_cg1 16-wave, 32-row tiles on large planes (profiles/r01/cg1_sweep.txt)
+  o.R = g.tune.cg1_auto ? 2 : g.tune.cg1_rows;
+  o.NW = g.tune.cg1_auto ? ((!descr && g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g.tune.cg1_waves;
+  const int by = o.NW * o.R;
+  o.tiles_x = (g.pitch + kBX - 1) / kBX;
+  o.tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)o.tiles_x * o.tiles_y;
+  if (!split && g.tune.zchunk <= 0 && descr && cols * ((g.nzl + 15) / 16) >= 2048) {
+    Geom gs_ = g;
+    gs_.tune.zchunk = 16;
+    pick_chunks(gs_, cols, false, &o.zchunk, &o.nzc);
+  } else if (split && g.tune.zchunk <= 0) {
+    Geom gs_ = g;
+    gs_.tune.zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
+    if (gs_.tune.zchunk > 64) gs_.tune.zchunk = 64;
+    if (gs_.tune.zchunk < 16 || descr) gs_.tune.zchunk = 16;  // (k_cg1b: 16-plane chunks, and the planes leave sooner)
+    pick_chunks(gs_, cols, false, &o.zchunk, &o.nzc);
+  } else {
+    pick_chunks(g, cols, false, &o.zchunk, &o.nzc);
+  }
+  if (!grid_fits(g, cols, o.nzc)) { o.blocks = -1; return o; }
+  const int nsel = part == 0 ? o.nzc : (part == 1 ? (o.nzc < 2 ? o.nzc : 2) : o.nzc - 2);
+  o.blocks = nsel <= 0 ? 0 : (int)(cols * nsel);
+  return o;
+}
+
 // part: 0 = whole slab, 1 = boundary chunks, 2 = interior chunks (0 blocks when there are none).
 // `split` selects the chunking of a slab with neighbours: >= 4 chunks so that the interior
 // launch can hide the plane exchange.  Returns the number of blocks launched; they write
@@ -2394,32 +2426,10 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
                const long long* plane_first, hipStream_t s) {
   // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
   // off on large planes; locals only, handles may be driven from several host threads
-  // the descriptor-addressed kernel (k_cg1b): 8-wave, 16-row tiles (two blocks per CU out of step with each other) and
-  // 16-plane chunks (profiles/r02/k_cg1b_sweep.txt: 7.87 ms against 8.04 / 8.43 with 32 / 64 planes, 8.57 k_cg1)
   const bool descr = lineoff && plane_first && g.tune.cg1_kernel == 0 && 8ll * g.plane < kBufMax;
-  const int R = g.tune.cg1_auto ? 2 : g.tune.cg1_rows;
-  const int NW = g.tune.cg1_auto ? ((!descr && g.ny >= 256 && g.pitch >= 256) ? 16 : 8) : g.tune.cg1_waves;
-  const int by = NW * R;
-  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
-  const long long cols = (long long)tiles_x * tiles_y;
-  int zchunk, nzc;
-  if (!split && g.tune.zchunk <= 0 && descr && cols * ((g.nzl + 15) / 16) >= 2048) {
-    Geom gs_ = g;
-    gs_.tune.zchunk = 16;
-    pick_chunks(gs_, cols, false, &zchunk, &nzc);
-  } else if (split && g.tune.zchunk <= 0) {
-    Geom gs_ = g;
-    gs_.tune.zchunk = g.nzl / 4;  // two boundary chunks + at least two interior ones
-    if (gs_.tune.zchunk > 64) gs_.tune.zchunk = 64;
-    if (gs_.tune.zchunk < 16 || descr) gs_.tune.zchunk = 16;  // (k_cg1b: 16-plane chunks, and the planes leave sooner)
-    pick_chunks(gs_, cols, false, &zchunk, &nzc);
-  } else {
-    pick_chunks(g, cols, false, &zchunk, &nzc);
-  }
-  if (!grid_fits(g, cols, nzc)) return -1;
-  const int nsel = part == 0 ? nzc : (part == 1 ? (nzc < 2 ? nzc : 2) : nzc - 2);
-  if (nsel <= 0) return 0;
-  const int blocks = (int)(cols * nsel);
+  const Cg1Grid gr = cg1_grid(g, descr, split, part);
+  if (gr.blocks <= 0) return gr.blocks;
+  const int R = gr.R, NW = gr.NW, tiles_x = gr.tiles_x, tiles_y = gr.tiles_y, zchunk = gr.zchunk, nzc = gr.nzc, blocks = gr.blocks;
 #define OI_CG1(RR, WW)                                                                                             \
   do {                                                                                                             \
     if (p_f32) launch_cg1_r<RR, WW, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, \

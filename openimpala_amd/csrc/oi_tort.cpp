@@ -1371,6 +1371,27 @@ extern "C" oi_status oi_tort_bench_stream(oi_tort* h, int reps, double* ms_per_p
   return OI_OK;
 }
 
+// Launch shape the single-kernel iteration would take for a slab of nx x ny x nz_local voxels under the CURRENT process
+// defaults: host arithmetic only, no device needed (the CPU tests check wide and thin planes against the capacity of the
+// handle's partial-sum array).  descr = 1: the descriptor-addressed kernel of the compacted layout.
+extern "C" oi_status oi_debug_cg1_grid(int nx, int ny, int nz_local, int descr, int split, int part, int* tile_rows, int* zchunk,
+                                       int* blocks, int* capacity) {
+  if (nx < 1 || ny < 1 || nz_local < 1) { oi::set_error("%s: argument out of range", __func__); return OI_BAD_ARG; }
+  Geom g{};
+  g.nx = nx; g.ny = ny; g.nz = nz_local; g.z0 = 0; g.nzl = nz_local;
+  g.pitch = (nx + 1) & ~1;
+  g.W = (nx + 63) / 64;
+  g.plane = (long long)g.pitch * ny;
+  g.tune = oi::default_tune();
+  g.tune.max_blocks = oi::partial_blocks_bound(g.pitch, ny, nz_local);
+  const oi::Cg1Grid gr = oi::cg1_grid(g, descr != 0, split, part);
+  if (tile_rows) *tile_rows = gr.R * gr.NW;
+  if (zchunk) *zchunk = gr.zchunk;
+  if (blocks) *blocks = gr.blocks;
+  if (capacity) *capacity = g.tune.max_blocks;
+  return OI_OK;
+}
+
 extern "C" oi_status oi_tort_placement(oi_tort* h, int* nslots, int* slots7, int* tried, double* ms_first, double* ms_best) {
   if (!h) { oi::set_error("%s: null handle", __func__); return OI_BAD_ARG; }
   if (nslots) *nslots = h->nslots;

@@ -242,3 +242,24 @@ def test_readers_load_a_z_slab_only(tmp_path):
         assert np.array_equal(hr.threshold(2000.0), (hv > 2000).astype(np.uint8))
         with pytest.raises(oia.OpenImpalaError):
             hr.threshold(1.0, z0=10, nz_local=2)
+
+
+@pytest.mark.parametrize("descr", [1, 0])
+def test_launch_geometry_never_exceeds_the_partial_sum_array(descr):
+    """Host arithmetic of the single-kernel iteration's launch shape (no device): for wide planes, long thin planes, short slabs
+    and the BASELINE shares, every launch -- whole slab, boundary chunks, interior chunks -- stays within the capacity of the
+    partial-sum array a handle of that slab allocates (round 1: an 8192 x 4096 cross-section wrote past it)."""
+    shapes = [(1024, 1024, 1024), (8192, 4096, 64), (4096, 4096, 512), (2048, 2048, 256), (16384, 100, 300), (100, 16384, 9),
+              (100, 100, 100), (130, 7, 3), (1, 1, 1), (5000, 5000, 8), (2, 70000, 40)]
+    for nx, ny, nzl in shapes:
+        for split, parts in ((0, (0,)), (1, (1, 2))):
+            total = 0
+            for part in parts:
+                rows, zchunk, blocks, cap = oia.cg1_grid(nx, ny, nzl, descr=descr, split=split, part=part)
+                assert rows in (8, 16, 32) and 1 <= zchunk <= max(nzl, 1) and cap >= 4096
+                assert 0 <= blocks <= cap, (nx, ny, nzl, split, part, blocks, cap)
+                total += blocks
+            assert total <= cap and total >= 1
+    # the default of the descriptor-addressed kernel at the bench size: 16-row tiles, 16-plane chunks
+    assert oia.cg1_grid(1024, 1024, 1024, descr=1)[:3] == (16, 16, 8 * 64 * 64)
+    assert oia.cg1_grid(1024, 1024, 1024, descr=0)[0] == 32
