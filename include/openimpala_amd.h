@@ -204,7 +204,8 @@ oi_status oi_tort_true_residual(oi_tort* h, double* relres);
 oi_status oi_debug_cg1_grid(int nx, int ny, int nz_local, int descr, int split, int part, int* tile_rows, int* zchunk,
                             int* blocks, int* capacity);
 /* Where the vectors of the single-kernel iteration were put.  When a vector is larger than the 256 MB Infinity Cache,
- * x and the six double-buffered vectors are slots of ONE arena, with spare slots ("place_slots", memory permitting), and
+ * x and the six double-buffered vectors are slots of an arena (two allocations some 50 GB apart, "place_spacer_gb") with
+ * spare slots ("place_slots", memory permitting), and
  * `place_trials` placements (oi_tort_set_option, default 48) are timed with the real kernel when the handle is built,
  * the fastest kept: on MI355X the iteration time depends on the distances between the arrays read and the arrays
  * written (HBM address mapping).  nslots = 0: no arena.  slots7[0..5] = slots of r, q, p[0], r2,
@@ -251,10 +252,13 @@ int oi_tort_line_voxels(void);
  *                   allocations in order, no spare slots; see oi_tort_placement)
  *   "cg1_kernel"    single-kernel CG, compacted layout: 0 = k_cg1b (descriptor-addressed accesses, default), 1 = k_cg1
  *                   (branches around plain global accesses; same iterates bit for bit, kept as the cross-check)
+ *   "place_spacer_gb" the slots lie in two allocations with a spacer of this size (default 48 GB) allocated between them
+ *                   and freed again, so that the halves are far apart in HBM (needs that much free memory at set-up only;
+ *                   0 = one allocation)
  *   "place_slots"   slots of the vector arena (default 12, 6 to 16: six are used, spare ones widen the choice; fewer are
  *                   taken when less than a quarter of the card would stay free)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
- * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM seed the same defaults, read ONCE per process.
+ * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM, OI_PLACE_TRIALS, OI_PLACE_SLOTS, OI_PLACE_SPACER_GB seed the same defaults, read ONCE per process.
  * OI_BAD_ARG for an unknown key. */
 oi_status oi_tort_set_option(const char* key, double value);
 /* copy the current process defaults of the launch shapes into a live handle (layout, multigrid hierarchy and the

@@ -38,6 +38,8 @@ struct Tune {
                          // fastest kept; 0 = separate allocations in order, no spare slots (env OI_PLACE_TRIALS)
   int place_slots = 12;  // slots of that arena (6 are used; the spare ones widen the choice), memory permitting
                          // (env OI_PLACE_SLOTS)
+  float place_spacer_gb = 48.f;  // the slots lie in two allocations with a spacer of this size allocated between them and freed
+                         // again (memory permitting; 0 = one allocation; env OI_PLACE_SPACER_GB)
   int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
   int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
 };

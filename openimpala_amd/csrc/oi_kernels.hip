@@ -87,6 +87,7 @@ Tune default_tune() {
     if (getenv("OI_FORCE_COMM")) g_tune_defaults.force_comm = 1;
     if (const char* e = getenv("OI_PLACE_TRIALS")) g_tune_defaults.place_trials = atoi(e);
     if (const char* e = getenv("OI_PLACE_SLOTS")) g_tune_defaults.place_slots = atoi(e);
+    if (const char* e = getenv("OI_PLACE_SPACER_GB")) g_tune_defaults.place_spacer_gb = (float)atof(e);
   }
   return g_tune_defaults;
 }

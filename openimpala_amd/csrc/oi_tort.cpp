@@ -84,6 +84,8 @@ struct oi_tort {
   // chosen by timing (place_vectors): the HBM address mapping makes the iteration time depend on where the three
   // vectors read and the three written lie relative to each other
   char* slot_arena = nullptr;
+  char* slot_arena2 = nullptr;  // second half of the slots, allocated behind a spacer that is freed again (see alloc_vector_slots)
+  int nslots_a = 0;             // slots in the first arena (x lives there too)
   size_t x_bytes = 0;  // > 0: x lies in the arena too
   int nslots = 0;
   size_t slot_bytes = 0;
@@ -213,6 +215,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->slot_arena2) (void)hipFree(h->slot_arena2);
   if (h->slot_arena) { (void)hipFree(h->slot_arena); h->r = h->q = h->r2 = h->q2 = nullptr; h->p[0] = h->p[1] = nullptr; if (h->x_bytes) h->x = nullptr; }
   void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->plane_first_dev,
                  h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
@@ -331,10 +334,15 @@ static constexpr size_t kPlaceMinBytes = (size_t)256 << 20;  // below this a vec
 
 // pl[0..5] = slots of r, q, p[0], r2, q2, p[1]; pl[6] = number of slots in FRONT of x (x lies in the same arena)
 static void assign_slots(oi_tort* h, const int* pl) {
-  auto slot = [&](int k) { return h->slot_arena + (size_t)pl[k] * h->slot_bytes + (pl[k] >= pl[6] ? h->x_bytes : 0); };
+  const int xa = std::min(pl[6], h->nslots_a);  // x lies in the first arena, behind this many of its slots
+  auto slot = [&](int k) {
+    const int v = pl[k];
+    if (v >= h->nslots_a) return h->slot_arena2 + (size_t)(v - h->nslots_a) * h->slot_bytes;
+    return h->slot_arena + (size_t)v * h->slot_bytes + (v >= xa ? h->x_bytes : 0);
+  };
   h->r = (double*)slot(0); h->q = (double*)slot(1); h->p[0] = slot(2);
   h->r2 = (double*)slot(3); h->q2 = (double*)slot(4); h->p[1] = slot(5);
-  if (h->x_bytes) h->x = (double*)(h->slot_arena + (size_t)pl[6] * h->slot_bytes);
+  if (h->x_bytes) h->x = (double*)(h->slot_arena + (size_t)xa * h->slot_bytes);
   for (int k = 0; k < 7; ++k) h->placement[k] = pl[k];
 }
 
@@ -352,11 +360,33 @@ static oi_status alloc_vector_slots(oi_tort* h) {
     const int most = std::min(kMaxSlots, std::max(6, h->g.tune.place_slots));
     for (want = most; want > 6 && (size_t)want * h->slot_bytes + h->x_bytes + total_b / 4 > free_b; --want) {}
   }
-  for (;; want = 6) {
-    if (hipMalloc((void**)&h->slot_arena, (size_t)want * h->slot_bytes + h->x_bytes) == hipSuccess) break;
+  // The slots are split over TWO allocations with a spacer allocated between them and freed again: the two halves then lie
+  // some 50 GB apart in HBM while the room between them goes back to the caller.  A read stream and a written stream that
+  // far apart fall into different bank groups (a copy runs at 6.05 instead of 5.4-5.7 TB/s from 40 GiB of distance on:
+  // profiles/r02/placement/hbm_window_dist256.txt); an arena of 15-30 GB cannot offer such distances, which is why 256-
+  // and 512-plane slabs stayed in the slow class without it (free_offset_search_discarded.txt).  Needs the spacer's size
+  // free at set-up only.
+  double spacer_gb = search ? (double)h->g.tune.place_spacer_gb : 0.0;
+  if (spacer_gb > 0.0) {
+    size_t free_b = 0, total_b = 0;
+    HIPC(hipMemGetInfo(&free_b, &total_b));
+    if ((size_t)want * h->slot_bytes + h->x_bytes + (size_t)(spacer_gb * 1e9) + total_b / 8 > free_b) spacer_gb = 0.0;
+  }
+  for (;; want = 6, spacer_gb = 0.0) {
+    const int na = spacer_gb > 0.0 ? (want + 1) / 2 : want;
+    char* spacer = nullptr;
+    bool ok = hipMalloc((void**)&h->slot_arena, (size_t)na * h->slot_bytes + h->x_bytes) == hipSuccess;
+    if (ok && na < want) {
+      ok = hipMalloc((void**)&spacer, (size_t)(spacer_gb * 1e9)) == hipSuccess &&
+           hipMalloc((void**)&h->slot_arena2, (size_t)(want - na) * h->slot_bytes) == hipSuccess;
+      if (spacer) (void)hipFree(spacer);
+    }
+    if (ok) { h->nslots_a = na; break; }
     (void)hipGetLastError();
-    h->slot_arena = nullptr;
-    if (want == 6) { oi::set_error("out of device memory for the CG vectors (%zu bytes)", 6 * h->slot_bytes + h->x_bytes); return OI_HIP_ERROR; }
+    if (h->slot_arena) (void)hipFree(h->slot_arena);
+    if (h->slot_arena2) (void)hipFree(h->slot_arena2);
+    h->slot_arena = h->slot_arena2 = nullptr;
+    if (want == 6 && spacer_gb == 0.0) { oi::set_error("out of device memory for the CG vectors (%zu bytes)", 6 * h->slot_bytes + h->x_bytes); return OI_HIP_ERROR; }
   }
   h->nslots = want;
   h->bytes_device += (size_t)want * h->slot_bytes + h->x_bytes;
@@ -373,7 +403,8 @@ static oi_status place_vectors(oi_tort* h) {
   const int trials = h->g.tune.place_trials;
   if (!h->slot_arena || !h->x_bytes || trials <= 0 || h->hist_cap < 4) return OI_OK;
   hipStream_t s = h->stream;
-  HIPC(hipMemsetAsync(h->slot_arena, 0, (size_t)h->nslots * h->slot_bytes + h->x_bytes, s));
+  HIPC(hipMemsetAsync(h->slot_arena, 0, (size_t)h->nslots_a * h->slot_bytes + h->x_bytes, s));
+  if (h->slot_arena2) HIPC(hipMemsetAsync(h->slot_arena2, 0, (size_t)(h->nslots - h->nslots_a) * h->slot_bytes, s));
   HIPC(hipMemsetAsync(h->rec, 0, sizeof(double) * kRec1Stride * h->hist_cap, s));
   Ctrl c;
   c.done = 0; c.pad = 0; c.tol2 = -1.0;
@@ -1761,6 +1792,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "force_comm") t.force_comm = iv != 0;
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;
+  else if (k == "place_spacer_gb") t.place_spacer_gb = (float)value;
   else if (k == "cg1_kernel") t.cg1_kernel = iv;
   else { oi::set_error("%s: unknown key '%s'", __func__, key); return OI_BAD_ARG; }
   oi::set_default_tune(t);
@@ -1778,7 +1810,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
   t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale;
   t.force_comm = old.force_comm;
-  t.place_trials = old.place_trials; t.place_slots = old.place_slots;
+  t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   h->g.tune = t;
   return OI_OK;
 }

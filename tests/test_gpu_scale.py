@@ -131,9 +131,10 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
     K = 30
     buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
     out = {}
-    for name, trials, slots in (("off", 0, 12), ("six", 6, 6), ("spare", 10, 12)):
+    for name, trials, slots, spacer in (("off", 0, 12, 48.0), ("six", 6, 6, 0.0), ("spare", 10, 12, 48.0)):
         oi_option("place_trials", trials, reset=48)
         oi_option("place_slots", slots, reset=12)
+        oi_option("place_spacer_gb", spacer, reset=48.0)   # ("spare": two allocations, a freed spacer between them)
         t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
         pl = t.placement()
         if name == "off":
