@@ -1369,11 +1369,6 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
   return OI_OK;
 }
 
-// ||b - A x|| / ||b|| of the CURRENT solution, recomputed from scratch: A x by the stand-alone apply (k_apply7 -- a kernel no
-// solver variant uses inside its iteration), squared norm over the owned planes by a fixed-order reduction.  x carries
-// the Dirichlet values, so on the free rows b - A x = -(A x); identity rows have no residual.  The convergence test and
-// stats.final_relres use the RECURRENCE residual r_k = r_{k-1} - alpha q (as HYPRE's Krylov solvers do); this entry point
-// is the independent check that the two agree.  Needs one dense scratch vector (8 bytes per voxel).
 // ms per pass of a kernel that only moves the handle's six double-buffered CG vectors (r2, q2, p[1] -> r, q, p[0]) where
 // they lie: the in-situ ceiling of a 3-read / 3-write stream, reported by bench.py beside the CG kernel's own rate.
 // Only between CG runs (the vectors are scratch then; cg_begin initialises them).
@@ -1433,6 +1428,11 @@ extern "C" oi_status oi_tort_placement(oi_tort* h, int* nslots, int* slots7, int
   return OI_OK;
 }
 
+// ||b - A x|| / ||b|| of the CURRENT solution, recomputed from scratch: A x by the stand-alone apply (k_apply7 -- a kernel no
+// solver variant uses inside its iteration), squared norm over the owned planes by a fixed-order reduction.  x carries
+// the Dirichlet values, so on the free rows b - A x = -(A x); identity rows have no residual.  The convergence test and
+// stats.final_relres use the RECURRENCE residual r_k = r_{k-1} - alpha q (as HYPRE's Krylov solvers do); this entry point
+// is the independent check that the two agree.  Needs one dense scratch vector (8 bytes per voxel).
 extern "C" oi_status oi_tort_true_residual(oi_tort* h, double* relres) {
   if (!h || !relres) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   *relres = std::numeric_limits<double>::quiet_NaN();
