@@ -13,21 +13,27 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU G
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAVES_EQ_64 TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
   n=$((n+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$n -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-variants --no-apply-bench --steps 20 --warmup 4 "$@" > $out/bench_$n.json 2> $out/p$n.err || { tail -5 $out/p$n.err; continue; }
+  if [ -n "$OI_SQ_SCRIPT" ]; then  # another workload (e.g. tools/mg_bench.py) and another kernel (OI_SQ_KERNEL)
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$n -- python3 $R/$OI_SQ_SCRIPT "$@" > $out/bench_$n.json 2> $out/p$n.err || { tail -5 $out/p$n.err; continue; }
+  else
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$n -- python3 $R/bench.py --no-solve --no-cpu-baseline --no-variants --no-apply-bench --steps 20 --warmup 4 "$@" > $out/bench_$n.json 2> $out/p$n.err || { tail -5 $out/p$n.err; continue; }
+  fi
   echo pass-$n-done
 done
 python3 - $out <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, os
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "k_cg1" not in k: continue
-        acc["k_cg1"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        want = os.environ.get("OI_SQ_KERNEL", "k_cg1").split(",")
+        hit = [w for w in want if w in k]
+        if not hit: continue
+        acc[hit[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
     for c, v in sorted(d.items()):
         v = v[len(v)//4:]  # drop the placement-search / warm-up launches' share
-        print(f"{k:8s} {c:34s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
+        print(f"{k:24s} {c:34s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
 PY
 find $out -name "*.db" -delete; find $out -name "*agent_info*" -delete; find $out -name "*kernel_trace*" -delete
