@@ -58,8 +58,19 @@ OpenImpala::TortuosityMI355::SolverType solver_from_string(const std::string& s)
   throw std::runtime_error("Invalid solver string: '" + s + "'.");
 }
 
+// the phase bytes stay in the reader's own buffer: page-locked when a device is present (oi_read_set_pinned), so that the
+// upload of the volume -- or of one z-slab per GPU -- is a single DMA transfer instead of a staged pageable copy
+struct PhaseBytes {
+  std::unique_ptr<std::uint8_t, void (*)(void*)> buf{nullptr, oi_free_host};
+  std::size_t n = 0;
+  const std::uint8_t* data() const { return buf.get(); }
+  std::size_t size() const { return n; }
+  const std::uint8_t& operator[](std::size_t k) const { return buf.get()[k]; }
+  const std::uint8_t* begin() const { return buf.get(); }
+  const std::uint8_t* end() const { return buf.get() + n; }
+};
 struct Volume {
-  std::vector<std::uint8_t> phase;
+  PhaseBytes phase;
   int nx = 0, ny = 0, nz = 0;
 };
 
@@ -97,8 +108,8 @@ Volume load_volume(const std::filesystem::path& path, double threshold, const oi
     throw std::runtime_error("Unsupported file extension for full domain load: " + ext);  // Diffusion.cpp:298-300
   }
   if (st != OI_OK) throw std::runtime_error(std::string(oi_status_string(st)) + ": " + oi_last_error());
-  v.phase.assign(data, data + static_cast<std::size_t>(v.nx) * v.ny * v.nz);
-  oi_free_host(data);
+  v.phase.buf.reset(data);
+  v.phase.n = static_cast<std::size_t>(v.nx) * v.ny * v.nz;
   return v;
 }
 
@@ -142,6 +153,7 @@ int main(int argc, char* argv[]) {
     if (verbose >= 1) std::cout << "Reading full domain data from: " << input_path.string() << std::endl;
     Volume vol;
     try {
+      oi_read_set_pinned(1);  // (pageable memory when no device is visible: the error is reported where a device is needed)
       vol = load_volume(input_path, threshold, in);
     } catch (const std::exception& e) {
       std::cout << "Error loading full domain data: " << e.what() << std::endl;

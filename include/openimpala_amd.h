@@ -328,6 +328,10 @@ int oi_abi_version(void);
  * oi_read_*: *phase is malloc'ed by the library (release with oi_free_host).
  * TiffReader::threshold (TiffReader.cpp:289-444,449-455), RawReader::threshold
  * (RawReader.cpp:379-491), HDF5Reader::threshold (HDF5Reader.cpp:333-402). */
+/* on != 0: the readers return PAGE-LOCKED buffers from now on (hipHostMalloc), so that the upload of a volume or of a
+ * z-slab is one DMA transfer; oi_free_host releases either kind.  Without a device the readers keep returning malloc'ed
+ * memory. */
+void oi_read_set_pinned(int on);
 oi_status oi_read_tiff(const char* path, double threshold, uint8_t** phase, int* nx, int* ny, int* nz,
                        int* bits_per_sample);
 /* planes [z0, z0 + nz_local) only (nz_local < 0: all from z0); *nz = depth of the FILE.  The file is

@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host"
+    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host oi_read_set_pinned"
 ).split()
 
 
@@ -147,6 +147,8 @@ def lib():
     L.oi_tort_set_option.argtypes = [C.c_char_p, C.c_double]
     L.oi_tort_retune.argtypes = [vp]
     L.oi_tort_true_residual.argtypes = [vp, C.POINTER(C.c_double)]
+    L.oi_read_set_pinned.argtypes = [i]
+    L.oi_read_set_pinned.restype = None
     L.oi_debug_cg1_grid.argtypes = [i, i, i, i, i, i] + [C.POINTER(C.c_int)] * 4
     L.oi_tort_bench_stream.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oi_tort_placement.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -359,6 +361,11 @@ def cg1_grid(nx, ny, nz_local, descr=1, split=0, part=0):
     v = [C.c_int(0) for _ in range(4)]
     _check(lib().oi_debug_cg1_grid(nx, ny, nz_local, descr, split, part, *[C.byref(x) for x in v]))
     return tuple(x.value for x in v)
+
+
+def read_set_pinned(on=True):
+    """Readers return page-locked buffers from now on (oi_read_set_pinned): one DMA transfer per upload."""
+    lib().oi_read_set_pinned(1 if on else 0)
 
 
 def device_memory():

@@ -28,6 +28,7 @@
 
 namespace oi {
 void set_error(const char* fmt, ...);
+void* host_alloc(size_t n, bool zero);  // oi_io.cpp: malloc, or page-locked memory after oi_read_set_pinned(1)
 }
 
 namespace {
@@ -613,9 +614,9 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
   }
   const uint64_t za = (uint64_t)z0, zb = za + (uint64_t)nz_local;  // planes [za, zb)
   const uint64_t n = X * Y * (zb - za), es = (uint64_t)d.type_size;
-  uint8_t* out = (uint8_t*)calloc(n, 1);  // unallocated storage reads as fill value 0
+  uint8_t* out = (uint8_t*)oi::host_alloc(n, true);  // unallocated storage reads as fill value 0
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
-  auto fail = [&](const char* msg) { free(out); oi::set_error("'%s' [%s]: %s", path, dataset, msg); return OI_IO_ERROR; };
+  auto fail = [&](const char* msg) { oi_free_host(out); oi::set_error("'%s' [%s]: %s", path, dataset, msg); return OI_IO_ERROR; };
 
   if (d.layout == 1 || d.layout == 0) {
     const uint64_t src = d.layout == 1 ? h.base + d.data_addr : d.compact_off;

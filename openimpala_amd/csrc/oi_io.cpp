@@ -37,6 +37,20 @@ namespace oi {
 void set_error(const char* fmt, ...);
 const char* last_error();
 }
+// Output buffers of the readers: plain malloc, or -- after oi_read_set_pinned(1) (oi_tort.cpp, the part of the library that
+// knows HIP) -- page-locked host memory, so that the upload of a slab is one DMA transfer (the reference stages through
+// pageable std::vectors).  The hooks keep this file free of any device API (it is also built alone, by g++, for ASan).
+extern "C" void oi_free_host(void* p);
+namespace oi {
+void* (*g_host_alloc)(size_t) = nullptr;
+void (*g_host_free)(void*) = nullptr;
+void* host_alloc(size_t n, bool zero) {
+  void* p = g_host_alloc ? g_host_alloc(n) : malloc(n);
+  if (p && zero) memset(p, 0, n);
+  return p;
+}
+}  // namespace oi
+
 
 namespace {
 
@@ -470,7 +484,7 @@ extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int
     oi::set_error("'%s': %zu x %zu x %d voxels overflow the address space", path, W, H, nz_local);
     return OI_IO_ERROR;
   }
-  uint8_t* out = (uint8_t*)malloc(W * H * (size_t)nz_local);
+  uint8_t* out = (uint8_t*)oi::host_alloc(W * H * (size_t)nz_local, false);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   // pages are independent: decode them on the host cores this process may use
   std::string first_error;
@@ -495,7 +509,7 @@ extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int
   worker();
   for (auto& t : pool) t.join();
   if (failed.load()) {
-    free(out);
+    oi_free_host(out);
     oi::set_error("%s", first_error.c_str());
     return (oi_status)failed.load();
   }
@@ -538,12 +552,12 @@ extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_fil
         st = OI_IO_ERROR;
       }
       if (st == OI_OK) {
-        out = (uint8_t*)malloc((size_t)p0.w * p0.h * (size_t)num_files);
+        out = (uint8_t*)oi::host_alloc((size_t)p0.w * p0.h * (size_t)num_files, false);
         if (!out) { oi::set_error("out of memory"); st = OI_IO_ERROR; }
       }
     }
     if (st == OI_OK) st = decode_page(name.c_str(), f, pages[0], p0, (size_t)k, threshold, out + (size_t)k * p0.w * p0.h, buf);
-    if (st != OI_OK) { free(out); return st; }
+    if (st != OI_OK) { oi_free_host(out); return st; }
   }
   *phase = out;
   *nx = (int)p0.w; *ny = (int)p0.h; *nz = num_files;
@@ -576,7 +590,7 @@ extern "C" oi_status oi_read_raw_planes(const char* path, int nx, int ny, int nz
     return OI_IO_ERROR;
   }
   const size_t n = (size_t)nx * ny * (size_t)nz_local, first = (size_t)nx * ny * (size_t)z0;
-  uint8_t* out = (uint8_t*)malloc(n);
+  uint8_t* out = (uint8_t*)oi::host_alloc(n, false);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   const bool swap = bpv > 1 && le != host_is_le();
   for (size_t v = 0; v < n; ++v) {
@@ -617,7 +631,7 @@ extern "C" oi_status oi_read_dat(const char* path, double threshold, uint8_t** p
   if (w <= 0 || h <= 0 || dep <= 0) { oi::set_error("'%s': invalid DAT header", path); return OI_IO_ERROR; }
   const size_t n = (size_t)w * h * dep;
   if (d.size() - 12 < 2 * n) { oi::set_error("'%s': DAT payload shorter than the header says", path); return OI_IO_ERROR; }
-  uint8_t* out = (uint8_t*)malloc(n);
+  uint8_t* out = (uint8_t*)oi::host_alloc(n, false);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   const uint16_t thr = (uint16_t)threshold;  // DatReader::threshold takes the raw type (uint16)
   for (size_t v = 0; v < n; ++v) out[v] = load_swapped<uint16_t>(d.data() + 12 + 2 * v, swap) > thr ? 1 : 0;
@@ -625,4 +639,7 @@ extern "C" oi_status oi_read_dat(const char* path, double threshold, uint8_t** p
   return OI_OK;
 }
 
-extern "C" void oi_free_host(void* p) { free(p); }
+extern "C" void oi_free_host(void* p) {
+  if (oi::g_host_free) oi::g_host_free(p);
+  else free(p);
+}

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "oi_comm.h"
@@ -1698,6 +1699,46 @@ extern "C" oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
   return OI_OK;
 }
 // time `reps` launches of the library's reference copy stream (two scratch arrays of `bytes` each, allocated here)
+// ---- page-locked output buffers for the readers (oi_io.cpp's allocation hooks) ---------------------------------------------
+namespace oi {
+extern void* (*g_host_alloc)(size_t);
+extern void (*g_host_free)(void*);
+}
+namespace {
+std::mutex g_pinned_mutex;
+std::vector<void*> g_pinned;  // page-locked buffers handed out (few and large: a linear search is fine)
+void* pinned_alloc(size_t n) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return malloc(n);  // (no device, or the pinned pool is exhausted: pageable memory is still a correct buffer)
+  }
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  g_pinned.push_back(p);
+  return p;
+}
+void pinned_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (size_t k = 0; k < g_pinned.size(); ++k)
+      if (g_pinned[k] == p) {
+        g_pinned[k] = g_pinned.back();
+        g_pinned.pop_back();
+        (void)hipHostFree(p);
+        return;
+      }
+  }
+  free(p);
+}
+}  // namespace
+// on: the readers (oi_read_*) return page-locked buffers from now on (oi_free_host releases either kind)
+extern "C" void oi_read_set_pinned(int on) {
+  // (the free hook stays installed once set: buffers handed out earlier must still find their way back)
+  oi::g_host_free = pinned_free;
+  oi::g_host_alloc = on ? pinned_alloc : nullptr;
+}
+
 extern "C" oi_status oi_dev_stream_copy_bench(size_t bytes, int reps, double* ms_per_copy) {
   if (!ms_per_copy || reps < 1 || bytes < 4096) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;

@@ -680,3 +680,26 @@ def test_multigrid_on_tiny_and_odd_volumes(shape):
         else:
             assert math.isnan(tau) or t.status == ref["status"]
         t.destroy()
+
+
+def test_readers_hand_out_page_locked_buffers_on_request():
+    """oi_read_set_pinned(1): the readers' output buffers come from hipHostMalloc (one DMA transfer per upload, what the
+    multi-GPU front end asks for); same bytes as the pageable path, z-slab reads included, and oi_free_host releases either
+    kind (the Python reader classes copy out of the buffer and free it)."""
+    path = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_uint8.raw")
+    raw = np.fromfile(path, dtype=np.uint8).reshape(100, 100, 100)
+    out = {}
+    try:
+        for k, pinned in enumerate((False, True, False)):
+            oia.read_set_pinned(pinned)
+            out[k] = oia.RawReader(path, 100, 100, 100, "UINT8").threshold(0.5)
+            slab = oia.RawReader(path, 100, 100, 100, "UINT8").threshold(0.5, z0=37, nz_local=21)
+            assert np.array_equal(slab, out[k][37:58])
+            tif = oia.TiffReader(os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")).threshold(0.5)
+            assert tif.shape == (100, 100, 100)
+    finally:
+        oia.read_set_pinned(False)
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], out[2]) and np.array_equal(out[0], (raw > 0.5).astype(np.uint8))
+    t = oia.TortuosityMI355(out[1], 1, 0)   # (the reference's default tolerance: the 1e-6 flux gate needs it)
+    assert t.value() > 1.0 and t.status == oia.OI_OK
+    t.destroy()
