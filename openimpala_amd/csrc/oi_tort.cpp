@@ -326,9 +326,10 @@ static oi_status cg_one_iteration(oi_tort* h, int k);
 // MI355X: the time of a kernel that streams several arrays at the same offsets depends on the DISTANCES between the
 // arrays it reads and the arrays it writes (HBM address mapping: tools/hbm_window.hip, profiles/r02/hbm_window_*.txt --
 // a plain copy runs at 4.6 to 6.0 TB/s depending on which address bit separates source and destination).  The six
-// double-buffered vectors laid out one after the other are in the slowest class at 1024^3.  So the vectors are slots
-// of ONE arena with (memory permitting) three spare slots, and which slot holds which vector is decided by timing the
-// real kernel on a few placements when the handle is built.  The arithmetic does not see the choice.
+// double-buffered vectors laid out one after the other are in the slowest class at 1024^3.  So x and the vectors are
+// slots of an arena (two allocations some 50 GB apart, see alloc_vector_slots) with, memory permitting, spare slots, and
+// which slot holds which vector is decided by timing the real kernel on a few placements when the handle is built.  The
+// arithmetic does not see the choice.
 static constexpr int kMaxSlots = 16;  // array bound (Tune::place_slots)
 static constexpr size_t kSlotAlign = (size_t)2 << 20;
 static constexpr size_t kPlaceMinBytes = (size_t)256 << 20;  // below this a vector sits in the 256 MB Infinity Cache
@@ -344,7 +345,8 @@ static void assign_slots(oi_tort* h, const int* pl) {
   h->r = (double*)slot(0); h->q = (double*)slot(1); h->p[0] = slot(2);
   h->r2 = (double*)slot(3); h->q2 = (double*)slot(4); h->p[1] = slot(5);
   if (h->x_bytes) h->x = (double*)(h->slot_arena + (size_t)xa * h->slot_bytes);
-  for (int k = 0; k < 7; ++k) h->placement[k] = pl[k];
+  for (int k = 0; k < 6; ++k) h->placement[k] = pl[k];
+  h->placement[6] = xa;
 }
 
 static oi_status alloc_vector_slots(oi_tort* h) {
