@@ -403,7 +403,7 @@ static oi_status alloc_vector_slots(oi_tort* h) {
 // (tol2 < 0 so that they do not stop); cg_begin initialises everything afterwards.  Every rank runs the same number
 // of launches (the slab path has collectives inside), the choice itself is local.
 static oi_status place_vectors(oi_tort* h) {
-  const int trials = h->g.tune.place_trials;
+  int trials = h->g.tune.place_trials;
   if (!h->slot_arena || !h->x_bytes || trials <= 0 || h->hist_cap < 4) return OI_OK;
   hipStream_t s = h->stream;
   HIPC(hipMemsetAsync(h->slot_arena, 0, (size_t)h->nslots_a * h->slot_bytes + h->x_bytes, s));
@@ -424,7 +424,7 @@ static oi_status place_vectors(oi_tort* h) {
   oi_status rc = OI_OK;
   // a tenth of all placements are in the fastest class (profiles/r02/k_cg1b_sweep.txt): 40 random ones miss it once in 70
   // handles, 21 missed it once in 9; the last eight trials are small changes of the best
-  const int nrandom = trials > 12 ? trials - 8 : trials - trials / 3;
+  int nrandom = trials > 12 ? trials - 8 : trials - trials / 3;
   for (int t = 0; t < trials && rc == OI_OK; ++t) {
     int pl[7];
     if (t < nrandom) {  // the in-order layout, then random ones
@@ -467,7 +467,15 @@ static oi_status place_vectors(oi_tort* h) {
     if (h->opts.verbose > 2)
       fprintf(stderr, "[openimpala_amd]   placement %2d: x after %d slots, %d %d %d | %d %d %d  %.3f ms\n", t, pl[6], pl[0], pl[1], pl[2],
               pl[3], pl[4], pl[5], per_iter);
-    if (t == 0) h->placement_ms_first = per_iter;
+    if (t == 0) {
+      h->placement_ms_first = per_iter;
+      // the search may take about 1.5 s: very large slabs (config 5's share: 49 ms per iteration) get fewer trials.  Every
+      // rank must run the same number of launches, so the slowest rank's time decides
+      int tenth_ms = (int)std::min(1e8, per_iter * 10.0) + 1;
+      if (h->comm && h->comm->allreduce_max_i32_host(&tenth_ms, 1, s) != OI_OK) { rc = OI_RCCL_ERROR; break; }
+      const int afford = std::max(8, (int)(1500.0 / (2.0 * 0.1 * tenth_ms)));
+      if (afford < trials) { trials = afford; nrandom = trials > 12 ? trials - 8 : trials - trials / 3; }
+    }
     if (t == 0 || per_iter < best_ms) { best_ms = per_iter; for (int k = 0; k < 7; ++k) best[k] = pl[k]; }
     h->placement_tried = t + 1;
   }
