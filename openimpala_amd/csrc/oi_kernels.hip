@@ -2198,6 +2198,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       *reinterpret_cast<double2*>(&T[(wu + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
   };
   auto stage_halo = [&](double* T, const HRaw& hr) {
+    // (the LDS addresses of the halo are formed from an opaque copy of the lane index: hoisted out of the loop they were
+    // spilled to scratch at the 128-VGPR budget, and a scratch reload waits for every store the wave has in flight)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
     if (wu < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (hcode) {
