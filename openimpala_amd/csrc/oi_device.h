@@ -58,6 +58,7 @@ struct Geom {
   long long nvec;      // (nzl+2) * plane elements per vector incl. ghost planes
   long long nwords;    // (nzl+2) * wplane
   double vlo, vhi;
+  float live_lines = 0.f;  // compacted layout: stored lines / all lines of this slab (0: not known) -- launch shapes may depend on it
   int periodic;        // 1: x and y wrap by index in the tiled kernels (homogenization cell problem; z wraps through the ghost planes)
   Tune tune;
 };

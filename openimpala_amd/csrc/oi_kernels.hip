@@ -2404,7 +2404,10 @@ Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part) {
   const long long cols = (long long)o.tiles_x * o.tiles_y;
   if (!split && g.tune.zchunk <= 0 && descr && cols * ((g.nzl + 15) / 16) >= 2048) {
     Geom gs_ = g;
-    gs_.tune.zchunk = 16;
+    // sparse structures (a quarter of the lines stored: config 5's porosity 0.2) do better with long chunks -- little to
+    // overlap per plane, and the chunk-end planes cost the same (profiles/r02/k_cg1b_sweep.txt: 46.8 vs 49.0 ms on
+    // config 5's share, 4.94 vs 5.07 ms at 1024^3); the sphere pack (half of the lines) with 16 planes
+    gs_.tune.zchunk = (g.live_lines > 0.f && g.live_lines < 0.35f) ? 64 : 16;
     pick_chunks(gs_, cols, false, &o.zchunk, &o.nzc);
   } else if (split && g.tune.zchunk <= 0) {
     Geom gs_ = g;

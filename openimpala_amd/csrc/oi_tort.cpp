@@ -628,6 +628,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
       h->plane_first.resize((size_t)g.nzl + 3);
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
       h->nvec_cg = std::max<long long>(16, (long long)oi::kLV * h->plane_first[g.nzl + 2]);
+      g.live_lines = (float)((double)h->plane_first[g.nzl + 2] / (double)nlines);
       OIC(check_plane_message_lengths(h, s));
     }
   }
