@@ -375,7 +375,10 @@ static oi_status alloc_vector_slots(oi_tort* h) {
     HIPC(hipMemGetInfo(&free_b, &total_b));
     if ((size_t)want * h->slot_bytes + h->x_bytes + (size_t)(spacer_gb * 1e9) + total_b / 8 > free_b) spacer_gb = 0.0;
   }
-  for (;; want = 6, spacer_gb = 0.0) {
+  // attempts: with the spacer; the same slots in one allocation; the six slots that are needed
+  for (int attempt = 0;; ++attempt) {
+    if (attempt == 1) spacer_gb = 0.0;
+    if (attempt == 2) want = 6;
     const int na = spacer_gb > 0.0 ? (want + 1) / 2 : want;
     char* spacer = nullptr;
     bool ok = hipMalloc((void**)&h->slot_arena, (size_t)na * h->slot_bytes + h->x_bytes) == hipSuccess;
@@ -389,7 +392,7 @@ static oi_status alloc_vector_slots(oi_tort* h) {
     if (h->slot_arena) (void)hipFree(h->slot_arena);
     if (h->slot_arena2) (void)hipFree(h->slot_arena2);
     h->slot_arena = h->slot_arena2 = nullptr;
-    if (want == 6 && spacer_gb == 0.0) { oi::set_error("out of device memory for the CG vectors (%zu bytes)", 6 * h->slot_bytes + h->x_bytes); return OI_HIP_ERROR; }
+    if (attempt >= 2) { oi::set_error("out of device memory for the CG vectors (%zu bytes)", 6 * h->slot_bytes + h->x_bytes); return OI_HIP_ERROR; }
   }
   h->nslots = want;
   h->bytes_device += (size_t)want * h->slot_bytes + h->x_bytes;

@@ -140,7 +140,8 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
         if name == "off":
             assert pl["tried"] == 0 and pl["ms_kept"] == 0.0
         else:
-            assert pl["nslots"] == slots and pl["tried"] == trials and 0.0 < pl["ms_kept"] <= pl["ms_in_order"]
+            # (twice the trials when the first set of arenas turned out flat and slow and a second one was searched)
+            assert pl["nslots"] == slots and pl["tried"] in (trials, 2 * trials) and 0.0 < pl["ms_kept"] <= pl["ms_in_order"]
             assert len(set(pl["slots"])) == 6 and all(0 <= v < slots for v in pl["slots"]) and 0 <= pl["x_after_slots"] <= slots
         t.cg_begin(); t.cg_iterate(K + 1); t.sync()
         its, rel, conv = t.cg_state()
@@ -157,7 +158,7 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
     hog = oia.DeviceBuffer(int(free - 0.26 * total))  # leaves 26 % of the card: spare slots would cut into the last quarter
     t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
     pl = t.placement()
-    assert pl["nslots"] == 6 and pl["tried"] == 4
+    assert pl["nslots"] == 6 and pl["tried"] in (4, 8)
     t.cg_begin(); t.cg_iterate(K + 1); t.sync()
     assert t.cg_state()[1] == out["off"][0]
     t.cg_finish()
