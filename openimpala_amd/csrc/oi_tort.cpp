@@ -352,7 +352,10 @@ static void assign_slots(oi_tort* h, const int* pl) {
 static oi_status alloc_vector_slots(oi_tort* h) {
   const size_t vec = (size_t)h->nvec_cg * sizeof(double);
   h->slot_bytes = (vec + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
-  const bool search = h->g.tune.place_trials > 0 && vec >= kPlaceMinBytes;
+  // (on slabs every rank must take the same decision: the search runs iterations, and those have collectives inside)
+  int no_search = (h->g.tune.place_trials > 0 && vec >= kPlaceMinBytes) ? 0 : 1;
+  if (h->comm) OIC(h->comm->allreduce_max_i32_host(&no_search, 1, h->stream));
+  const bool search = !no_search;
   int want = 6;
   if (search) {
     // x joins the arena (where it lies between the other vectors matters as much as where they lie)
