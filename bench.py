@@ -524,15 +524,26 @@ def main():
         bufh, _ = make_structure(oia, args, shape, z0, nzl)
         ph = bufh.download(np.uint8, shape)
         bufh.free()
+        free_before = oia.device_memory()[0]
         h0 = time.perf_counter()
         eh = oia.EffectiveDiffusivityMI355(ph, 1, eps=1e-9, precond=oia.PRECOND_MG, device=local_rank)
-        res = [eh.solve(k) for k in range(3)]
+        hc = time.perf_counter()
+        res, hs = [], []
+        for k in range(3):
+            res.append(eh.solve(k))
+            hs.append(time.perf_counter())
         D = eh.tensor()
-        h1 = time.perf_counter() - h0
+        h1 = time.perf_counter()
         eh.destroy()
         del ph
+        # (GPUTEST_r02 showed 3.7 s here against 1.25 s in every run of the builder: the split says where such a run spends it
+        # -- `create` holds the 1 GB pageable upload of the phase bytes, the mask and the multigrid hierarchy)
         homog = {"what": "EffectiveDiffusivityHypre path: chi_x, chi_y, chi_z to relres 1e-9 (periodic multigrid PCG) + tensor",
-                 "seconds_incl_upload": h1, "iterations": [r[1] for r in res], "converged": [bool(r[0]) for r in res],
+                 "seconds_incl_upload": h1 - h0,
+                 "seconds_split": {"create_incl_pageable_upload": hc - h0, "solve_x": hs[0] - hc, "solve_y": hs[1] - hs[0],
+                                   "solve_z": hs[2] - hs[1], "tensor": h1 - hs[2]},
+                 "device_free_GB_before": free_before / 1e9,
+                 "iterations": [r[1] for r in res], "converged": [bool(r[0]) for r in res],
                  "D_diag": [float(D[i, i]) for i in range(3)]}
 
     extras["variants"] = variants

@@ -40,3 +40,12 @@ def oi_option():
     yield setter
     for key, reset in changed:
         oia.set_option(key, reset)
+
+
+def pytest_collection_modifyitems(config, items):
+    """Robustness tests (tests/test_zz_*: misuse, threads, out-of-memory, release) run after every parity test whatever the
+    order of the command line's arguments: under `-x` a failure there must not hide a parity row."""
+    last = [it for it in items if os.path.basename(str(it.fspath)).startswith("test_zz_")]
+    if last:
+        first = [it for it in items if it not in last]
+        items[:] = first + last

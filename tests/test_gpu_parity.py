@@ -429,106 +429,6 @@ def test_degenerate_thin_volumes(shape):
             t.destroy()
 
 
-def test_api_misuse_is_reported_not_fatal(sample):
-    """Calls out of order, bad arguments, use after destroy: OI_BAD_ARG with a message that names the call."""
-    sub = np.ascontiguousarray(sample[:24, :28, :32])
-    t = oia.TortuosityMI355(sub, 1, 0)
-    for call in (lambda: t.cg_iterate(3), t.cg_finish, lambda: t.set_eps(0.0), lambda: t.set_eps(float("nan"))):
-        with pytest.raises(oia.OpenImpalaError) as e:
-            call()
-        assert e.value.status == oia.OI_BAD_ARG and "oi_tort_" in str(e.value)
-    assert t.cg_state() == (0, 0.0, False) and t.solution().shape == sub.shape
-    tau = t.value()
-    assert tau > 1.0 and t.value() == tau and t.value(refresh=True) == pytest.approx(tau, rel=1e-12)
-    t.cg_begin()
-    with pytest.raises(oia.OpenImpalaError):   # the stand-alone apply is refused while a CG run is open
-        t.apply(np.zeros(sub.shape))
-    with pytest.raises(oia.OpenImpalaError):
-        t.cg_iterate(-5)
-    t.cg_iterate(0); t.cg_finish()
-    t.destroy(); t.destroy()
-    with pytest.raises(oia.OpenImpalaError):
-        t.value()
-    for kw in (dict(kernel=99), dict(eps=-1.0)):
-        with pytest.raises(oia.OpenImpalaError):
-            oia.TortuosityMI355(sub, 1, 0, **kw)
-    with pytest.raises(oia.OpenImpalaError):
-        oia.TortuosityMI355(np.zeros((0, 4, 4), np.uint8), 1, 0)
-    assert math.isnan(oia.TortuosityMI355(sub, 5, 0).value())            # phase id absent: no percolation
-    assert math.isnan(oia.TortuosityMI355(sub, 1, 0, maxiter=1).value())  # not converged
-    h = oia.EffectiveDiffusivityMI355(sub, 1)
-    with pytest.raises(oia.OpenImpalaError):
-        h.tensor()
-    with pytest.raises(oia.OpenImpalaError) as e:
-        h.solve(5)
-    assert "oi_effdiff_solve" in str(e.value)
-    h.destroy(); h.destroy()
-
-
-def test_independent_handles_in_concurrent_host_threads(sample, goldens):
-    """Distinct handles may be driven from distinct host threads at once (the reference runs one solver object per
-    MPI rank; the app's gpu.ngpus mode and a parallel REV study do this): three directions, two preconditioners."""
-    import threading
-    g = goldens["phases"]["1"]
-    out, err = {}, []
-
-    def work(d, precond):
-        try:
-            t = oia.TortuosityMI355(sample, 1, d, g["vlo"], g["vhi"], eps=1e-10, precond=precond)
-            out[(d, precond)] = (t.value(), t.stats().flux_in)
-            t.destroy()
-        except Exception as e:  # surface it in the main thread
-            err.append((d, precond, repr(e)))
-
-    th = [threading.Thread(target=work, args=(d, p)) for d in range(3) for p in (oia.PRECOND_MG, oia.PRECOND_JACOBI)]
-    [t.start() for t in th]
-    [t.join(timeout=300) for t in th]
-    assert not any(t.is_alive() for t in th) and not err, err
-    for (d, _), (tau, flux) in out.items():
-        assert tau == pytest.approx(g["tau"][d], rel=1e-7) and flux == pytest.approx(g["flux"][d], rel=1e-7)
-
-
-def test_out_of_memory_is_an_error_not_a_crash():
-    """A volume that cannot fit (34e9 voxels: x alone would take 275 GB next to 70 GB of phase and code bytes) fails
-    with OI_HIP_ERROR, gives back what it had allocated, and the library keeps working."""
-    free0, _ = oia.device_memory()
-    shape = (2048, 4096, 4096)
-    buf = oia.gen_bernoulli_device(shape, 3, 0.6)
-    with pytest.raises(oia.OpenImpalaError) as e:
-        oia.TortuosityMI355(buf, 1, 0, shape=shape)
-    assert e.value.status == oia.OI_HIP_ERROR and "out of memory" in str(e.value)
-    buf.free()
-    free1, _ = oia.device_memory()
-    assert free0 - free1 < (1 << 30)
-    ph = oia.gen_bernoulli_device((48, 48, 48), 3, 0.7)
-    t = oia.TortuosityMI355(ph, 1, 0, shape=(48, 48, 48))
-    assert t.value() > 1.0
-    t.destroy(); ph.free()
-
-
-def test_handles_release_their_device_memory(sample):
-    """A REV study creates and destroys hundreds of handles: every variant gives its device memory back."""
-    sub = np.ascontiguousarray(sample[:48, :52, :60])
-
-    def cycle():
-        for kw in (dict(), dict(precond=oia.PRECOND_MG), dict(kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_JACOBI),
-                   dict(kernel=oia.KERNEL_FUSED), dict(kernel=oia.KERNEL_UNFUSED, precond=oia.PRECOND_MG)):
-            t = oia.TortuosityMI355(sub, 1, 0, eps=1e-8, **kw)
-            assert t.value() > 1.0
-            t.destroy()
-        h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-8, precond=oia.PRECOND_MG)
-        assert h.solve(0)[0]
-        h.destroy()
-
-    for _ in range(3):  # first uses: streams, library workspaces, the allocator's own pools settle
-        cycle()
-    free = []
-    for _ in range(8):
-        cycle()
-        free.append(oia.device_memory()[0])
-    assert free[3] - free[-1] < (8 << 20), free   # no steady decline (the allocator's pool may grow by a granule once)
-
-
 def test_remspot_on_the_device_equals_the_sequential_pass():
     """tortuosity_remspot is defined by its x-fastest in-place order (a flip is seen by the voxels after it);
     the device relaxation must land on exactly that result: iid noise (many isolated voxels), a 3-D
