@@ -262,6 +262,12 @@ def main():
     t_create = time.time() - t_create
     buf.free()
     placement = t.placement()
+    per_rank = None
+    if dist is not None:  # N > 1: what every rank's handle cost and where its vectors went (rank order)
+        mine = {"rank": rank, "create_total_s": t_create, "planes": nzl,
+                "vector_placement": {k: placement[k] for k in ("nslots", "slots", "tried", "ms_in_order", "ms_kept", "alloc_s", "search_s", "cache_hit")}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     st = t.stats()
     if st.active_vf <= 0:
         raise RuntimeError("synthetic structure does not percolate")
@@ -369,6 +375,9 @@ def main():
             roofline["stream_3r3w_same_vectors"] = {
                 "ms": sms, "GBps": sbytes / sms / 1e6, "frac_of_peak": sbytes / sms / 1e6 / HBM_PEAK_GBS,
                 "cg_kernel_vs_this_stream": achieved / (sbytes / sms / 1e6),
+                # which class of allocations this process got (profiles/r02/placement/final_12_runs.txt: eleven of twelve
+                # processes stream their vectors at 6.09-6.41 TB/s and run the kernel at 6.39-6.58 ms; one at 5.80 / 7.24)
+                "placement_class": "fast" if sbytes / sms / 1e6 >= 6000.0 else "slow",
                 "what": "d_j = s_j over r2,q2,p[1] -> r,q,p[0] of this handle (whole vectors, same placement); the CG kernel also "
                         "streams x, the code bytes and the line table"}
         except oia.OpenImpalaError as e:
@@ -403,10 +412,12 @@ def main():
             "time_to_1e-6": extras["solve"], "time_to_1e-6_multigrid_pcg": extras["solve_mg"],
             "variants": extras["variants"], "homogenization": extras["homog"],
             "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
-                        "flood_sweeps": st.flood_sweeps},
+                        "flood_sweeps": st.flood_sweeps, "upload_pack": st.t_upload_s, "codes_vectors_placement": st.t_setup_s,
+                        "placement_alloc_s": placement["alloc_s"], "placement_s": placement["search_s"]},
             "device_bytes": st.bytes_device,
             # where the CG vectors were put (slots of one arena) and what the placement search measured, ms per iteration
             "vector_placement": placement,
+            "per_rank": per_rank,
         }
         if extras["note"]:
             out["note"] = extras["note"]

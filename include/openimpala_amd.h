@@ -203,15 +203,21 @@ oi_status oi_tort_true_residual(oi_tort* h, double* relres);
  * partial-sum array for that slab.  Host arithmetic only: no device is touched. */
 oi_status oi_debug_cg1_grid(int nx, int ny, int nz_local, int descr, int split, int part, int* tile_rows, int* zchunk,
                             int* blocks, int* capacity);
-/* Where the vectors of the single-kernel iteration were put.  When a vector is larger than the 256 MB Infinity Cache,
- * x and the six double-buffered vectors are slots of an arena (two allocations some 50 GB apart, "place_spacer_gb") with
- * spare slots ("place_slots", memory permitting), and
- * `place_trials` placements (oi_tort_set_option, default 48) are timed with the real kernel when the handle is built,
- * the fastest kept: on MI355X the iteration time depends on the distances between the arrays read and the arrays
- * written (HBM address mapping).  nslots = 0: no arena.  slots7[0..5] = slots of r, q, p[0], r2,
- * q2, p[1]; slots7[6] = number of slots in front of x.  ms_first / ms_best = ms per iteration of the in-order layout
- * and of the layout kept (0 when nothing was timed).  The results of the solve do not depend on the placement. */
+/* Where the vectors of the single-kernel iteration were put.  When a vector is larger than the 256 MB Infinity Cache
+ * ("place_min_mb"), x and "place_slots" vector-sized slots are allocated back to back when the handle is built (with a
+ * spacer between the two halves where the set would otherwise span less than "place_extent_gb"), `place_trials`
+ * placements of the six double-buffered vectors in those slots (oi_tort_set_option, default 48) are timed with the real
+ * kernel, the fastest kept and the slots it does not use FREED: on MI355X the iteration time depends on the distances
+ * between the arrays read and the arrays written (HBM address mapping).  nslots = 0: no search.
+ * slots7[0..5] = slots of r, q, p[0], r2, q2, p[1]; slots7[6] = 0 (x is the first allocation of the set).  ms_first /
+ * ms_best = ms per iteration of the in-order layout and of the layout kept (0 when nothing was timed).  The results of
+ * the solve do not depend on the placement. */
 oi_status oi_tort_placement(oi_tort* h, int* nslots, int* slots7, int* tried, double* ms_first, double* ms_best);
+/* What the placement cost when the handle was built: seconds spent allocating the set (the driver clears memory another
+ * process has used: seconds for tens of GB) and searching, device bytes held by the handle at the peak of the search,
+ * bytes of x and the six vectors kept afterwards, and whether the process's placement cache answered (a handle of the
+ * same shape built earlier: one verification cycle instead of a search; "place_cache"). */
+oi_status oi_tort_placement_cost(oi_tort* h, double* alloc_s, double* search_s, double* peak_bytes, double* kept_bytes, int* cache_hit);
 /* ms per pass of a kernel that only MOVES the six double-buffered vectors of the single-kernel iteration where they lie
  * (three read, three written, 16-byte nontemporal accesses): the in-situ ceiling of that traffic mix on this card at
  * this placement.  Only between CG runs (the vectors are scratch then). */
@@ -248,17 +254,20 @@ int oi_tort_line_voxels(void);
  *   "mg_plain" "mg_novec4" "mg_debug"   multigrid cross-check kernels / per-level norms
  *   "mg_replicate_cells" "mg_wmask" "mg_scale"   multigrid level distribution and cycle shape
  *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
- *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 48; 0 = separate
- *                   allocations in order, no spare slots; see oi_tort_placement)
+ *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 48; 0 = six slots in
+ *                   order, no search; see oi_tort_placement)
  *   "cg1_kernel"    single-kernel CG, compacted layout: 0 = k_cg1b (descriptor-addressed accesses, default), 1 = k_cg1
  *                   (branches around plain global accesses; same iterates bit for bit, kept as the cross-check)
- *   "place_spacer_gb" the slots lie in two allocations with a spacer of this size (default 48 GB) allocated between them
- *                   and freed again, so that the halves are far apart in HBM (needs that much free memory at set-up only;
- *                   0 = one allocation)
- *   "place_slots"   slots of the vector arena (default 12, 6 to 16: six are used, spare ones widen the choice; fewer are
- *                   taken when less than a quarter of the card would stay free)
+ *   "place_slots"   slots allocated for the search (default 12, 6 to 16: six are kept, the others freed after the search;
+ *                   fewer are taken when less than a quarter of the card would stay free)
+ *   "place_extent_gb" extent the set of allocations should span in HBM (default 60): smaller sets get a spacer between
+ *                   the halves of the slots, allocated and freed again at set-up, of at most "place_spacer_gb" (default 48;
+ *                   0 = never a spacer)
+ *   "place_min_mb"  vectors below this size are not searched for (default 256: they sit in the Infinity Cache)
+ *   "place_cache"   1 (default): a handle reuses the placement an earlier handle of this process found for the same set of
+ *                   allocations after verifying it with one timed cycle
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
- * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM, OI_PLACE_TRIALS, OI_PLACE_SLOTS, OI_PLACE_SPACER_GB seed the same defaults, read ONCE per process.
+ * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM, OI_PLACE_TRIALS, OI_PLACE_SLOTS, OI_PLACE_SPACER_GB, OI_PLACE_EXTENT_GB, OI_PLACE_MIN_MB, OI_PLACE_CACHE seed the same defaults, read ONCE per process.
  * OI_BAD_ARG for an unknown key. */
 oi_status oi_tort_set_option(const char* key, double value);
 /* copy the current process defaults of the launch shapes into a live handle (layout, multigrid hierarchy and the

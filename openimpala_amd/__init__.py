@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
     "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
-    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
+    "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_placement_cost oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
@@ -152,6 +152,7 @@ def lib():
     L.oi_debug_cg1_grid.argtypes = [i, i, i, i, i, i] + [C.POINTER(C.c_int)] * 4
     L.oi_tort_bench_stream.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oi_tort_placement.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.oi_tort_placement_cost.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.oi_tort_line_voxels.argtypes = []
     L.oi_tort_line_voxels.restype = i
     L.oi_comm_unique_id.argtypes = [vp]
@@ -529,7 +530,12 @@ class TortuosityMI355:
         slots = (C.c_int * 7)()
         first, best = C.c_double(0.0), C.c_double(0.0)
         _check(lib().oi_tort_placement(self._h, C.byref(n), slots, C.byref(tried), C.byref(first), C.byref(best)))
-        return {"nslots": n.value, "slots": list(slots)[:6], "x_after_slots": slots[6], "tried": tried.value, "ms_in_order": first.value, "ms_kept": best.value}
+        a, b, pk, kp, hit = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        _check(lib().oi_tort_placement_cost(self._h, C.byref(a), C.byref(b), C.byref(pk), C.byref(kp), C.byref(hit)))
+        return {"nslots": n.value, "slots": list(slots)[:6], "x_after_slots": slots[6], "tried": tried.value, "ms_in_order": first.value, "ms_kept": best.value,
+                # what it cost: seconds allocating the set (with a spacer, the driver clears what it hands out) and searching,
+                # device bytes of the whole handle at the peak of the search, bytes of x + the six vectors kept
+                "alloc_s": a.value, "search_s": b.value, "peak_device_bytes": pk.value, "kept_vector_bytes": kp.value, "cache_hit": bool(hit.value)}
 
     def true_residual(self):
         """||b - A x|| / ||b|| of the current solution, recomputed on the device with the stand-alone apply kernel."""

@@ -34,12 +34,16 @@ struct Tune {
   long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
-  int place_trials = 48; // single-kernel CG: vector placements (slots of one arena) timed when the handle is built, the
-                         // fastest kept; 0 = separate allocations in order, no spare slots (env OI_PLACE_TRIALS)
-  int place_slots = 12;  // slots of that arena (6 are used; the spare ones widen the choice), memory permitting
+  int place_trials = 48; // single-kernel CG: vector placements (six of place_slots allocations made back to back) timed when
+                         // the handle is built, the fastest kept; 0 = six slots in order, no search (env OI_PLACE_TRIALS)
+  int place_slots = 12;  // slots allocated for the search (6 are kept, the others freed after it), memory permitting
                          // (env OI_PLACE_SLOTS)
-  float place_spacer_gb = 48.f;  // the slots lie in two allocations with a spacer of this size allocated between them and freed
-                         // again (memory permitting; 0 = one allocation; env OI_PLACE_SPACER_GB)
+  float place_spacer_gb = 48.f;  // LARGEST spacer allocated between the two halves of the slots and freed again (memory
+                         // permitting; 0 = none; env OI_PLACE_SPACER_GB): it fills the set up to place_extent_gb
+  float place_extent_gb = 60.f;  // extent (x + slots + spacer) the set of allocations should span in HBM: a 1024^3 set
+                         // spans it by itself, the set of a 256-plane slab gets a spacer (env OI_PLACE_EXTENT_GB)
+  int place_min_mb = 256;  // vectors below this size (they sit in the 256 MB Infinity Cache) are not searched for
+  int place_cache = 1;   // reuse the placement an earlier handle of this process found for the same set of allocations
   int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
   int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
 };

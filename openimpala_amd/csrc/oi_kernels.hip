@@ -88,6 +88,9 @@ Tune default_tune() {
     if (const char* e = getenv("OI_PLACE_TRIALS")) g_tune_defaults.place_trials = atoi(e);
     if (const char* e = getenv("OI_PLACE_SLOTS")) g_tune_defaults.place_slots = atoi(e);
     if (const char* e = getenv("OI_PLACE_SPACER_GB")) g_tune_defaults.place_spacer_gb = (float)atof(e);
+    if (const char* e = getenv("OI_PLACE_EXTENT_GB")) g_tune_defaults.place_extent_gb = (float)atof(e);
+    if (const char* e = getenv("OI_PLACE_MIN_MB")) g_tune_defaults.place_min_mb = atoi(e);
+    if (const char* e = getenv("OI_PLACE_CACHE")) g_tune_defaults.place_cache = atoi(e) != 0;
   }
   return g_tune_defaults;
 }

@@ -210,3 +210,49 @@ def test_remspot_on_slabs_equals_the_single_domain(nranks, box):
     assert np.array_equal(mask, ref["mask"])
     assert all(r["status"] == oia.OI_OK for r in outs)
     assert outs[0]["tau"] == pytest.approx(ref["tau"], rel=1e-8)
+
+
+def test_placement_search_on_slabs_with_neighbours(oi_option):
+    """The placement search of the single-kernel iteration on z-slabs WITH neighbours: the decision to search, the number of
+    trials, the second-set decision and the cache verdict are all-reduced (each of them guards launches that have
+    collectives inside).  `place_min_mb` = 0 makes these small slabs search; two handles per rank, so that the second one
+    goes through the cache path with its all-reduces too.  Same answer as the single domain."""
+    oi_option("place_min_mb", 0, reset=256)
+    oi_option("place_trials", 6, reset=48)
+    oi_option("place_slots", 8, reset=12)
+    oi_option("place_spacer_gb", 0.0, reset=48.0)
+    phase = o.gen_spheres((48, 40, 44), 21, 5, 0.45)
+    ref = o.tortuosity(phase, 1, 2, -1.0, 1.0, eps=1e-10)
+    nranks, nz = 3, phase.shape[0]
+    comms = oia.Comm.create_local(nranks)
+    out, err = [None] * nranks, []
+
+    def work(r):
+        try:
+            z0, z1 = oia.slab_range(nz, nranks, r)
+            res = []
+            for rep in range(2):
+                t = oia.TortuosityMI355(np.ascontiguousarray(phase[z0:z1]), 1, 2, -1.0, 1.0, comm=comms[r], z0=z0, nz_global=nz,
+                                        eps=1e-10, kernel=oia.KERNEL_FUSED1, precond=oia.PRECOND_NONE)
+                pl = t.placement()
+                res.append((t.value(), pl, t.stats().bytes_device))
+                t.destroy()
+            out[r] = res
+        except Exception as e:
+            err.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "slab threads hung"
+    assert not err, err
+    for c in comms:
+        c.destroy()
+    for r in range(nranks):
+        (tau0, pl0, b0), (tau1, pl1, b1) = out[r]
+        assert tau0 == pytest.approx(ref["tau"], rel=1e-7) and tau1 == tau0
+        assert pl0["nslots"] == 8 and pl0["tried"] in (6, 12) and not pl0["cache_hit"]
+        assert pl1["tried"] in (1, 6, 12) and (pl1["tried"] == 1) == pl1["cache_hit"]
+        assert b0 == b1
+    # every rank took the same decisions
+    assert len({out[r][1][1]["cache_hit"] for r in range(nranks)}) == 1
