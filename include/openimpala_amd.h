@@ -263,6 +263,9 @@ int oi_tort_line_voxels(void);
  *   "place_extent_gb" extent the set of allocations should span in HBM (default 60): smaller sets get a spacer between
  *                   the halves of the slots, allocated and freed again at set-up, of at most "place_spacer_gb" (default 48;
  *                   0 = never a spacer)
+ *   "place_alloc_budget_s" spare slots and the spacer are allocated only while the allocations of the set have taken less
+ *                   than this (default 0.5 s): the driver clears memory another process has used when it is allocated, and
+ *                   the x + six slots a handle needs anyway may already have cost seconds on a card that was full before
  *   "place_min_mb"  vectors below this size are not searched for (default 256: they sit in the Infinity Cache)
  *   "place_cache"   1 (default): a handle reuses the placement an earlier handle of this process found for the same set of
  *                   allocations after verifying it with one timed cycle

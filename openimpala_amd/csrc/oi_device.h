@@ -28,12 +28,14 @@ struct Tune {
   int cg1_xskip = 1;     // k_cg1: x touched every second iteration
   int cg1_fullline = 1;  // compacted layout: stored lines read and written whole
   int cg1_compact = 1;   // single-kernel variant: r, q, p stored as compacted live lines
+  int cg1_seg = 1;       // k_cg1b: line slots from per-row segment records (scalar loads) instead of the per-line table
   int cg1_kernel = 0;    // compacted layout: 0 = k_cg1b (descriptor-addressed, all loads of a plane in one burst), 1 = k_cg1
   int apply_kernel = 0;  // stand-alone apply: 0 = wave-autonomous k_apply7, 1 = LDS-tiled k_fused_a<PURE>
   int mg_plain = 0, mg_novec4 = 0, mg_debug = 0;  // multigrid cross-check switches (env OI_MG_PLAIN / _NOVEC4 / _DEBUG)
   long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
+  int mg_nu_coarse = 1;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (1 or 2; the fine level: 1)
   int place_trials = 48; // single-kernel CG: vector placements (six of place_slots allocations made back to back) timed when
                          // the handle is built, the fastest kept; 0 = six slots in order, no search (env OI_PLACE_TRIALS)
   int place_slots = 12;  // slots allocated for the search (6 are kept, the others freed after it), memory permitting
@@ -43,6 +45,8 @@ struct Tune {
   float place_extent_gb = 60.f;  // extent (x + slots + spacer) the set of allocations should span in HBM: a 1024^3 set
                          // spans it by itself, the set of a 256-plane slab gets a spacer (env OI_PLACE_EXTENT_GB)
   int place_min_mb = 256;  // vectors below this size (they sit in the 256 MB Infinity Cache) are not searched for
+  float place_alloc_budget_s = 0.5f;  // spare slots (and the spacer) are allocated only while the set's allocations have
+                         // taken less than this (the driver clears memory other processes have used: seconds for tens of GB)
   int place_cache = 1;   // reuse the placement an earlier handle of this process found for the same set of allocations
   int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
   int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
@@ -128,7 +132,8 @@ int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double
 // Compacted line layout of the single-kernel iteration: only the aligned kLV-voxel lines (owned and ghost
 // planes) that hold a free voxel are stored, in (plane, row, line) order.  lineoff[(gz * ny + j) * LW + line],
 // LW = ceil(pitch / 16), is a line's slot or -1; plane_first_dev[gz] (gz = 0 .. nzl + 2) the first slot of a plane.
-hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, hipStream_t s);
+// seg (optional): (nzl + 2) * ny * ceil(pitch / 128) segment records of 8 bytes (see k_line_finalize)
+hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, void* seg, hipStream_t s);
 // q = A v, partials {v.q}; returns number of partial blocks
 int launch_apply(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                  const Ctrl* ctrl, hipStream_t s);
@@ -181,7 +186,7 @@ Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part);
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
                double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff, const long long* plane_first,
-               hipStream_t s);
+               const void* seg, hipStream_t s);
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
                       hipStream_t s);
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);

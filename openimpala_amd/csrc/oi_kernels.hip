@@ -85,6 +85,7 @@ Tune default_tune() {
     if (const char* e = getenv("OI_MG_WMASK")) g_tune_defaults.mg_wmask = atoi(e);
     if (const char* e = getenv("OI_MG_SCALE")) g_tune_defaults.mg_scale = (float)atof(e);
     if (getenv("OI_FORCE_COMM")) g_tune_defaults.force_comm = 1;
+    if (const char* e = getenv("OI_MG_NU_COARSE")) g_tune_defaults.mg_nu_coarse = atoi(e) >= 2 ? 2 : 1;
     if (const char* e = getenv("OI_PLACE_TRIALS")) g_tune_defaults.place_trials = atoi(e);
     if (const char* e = getenv("OI_PLACE_SLOTS")) g_tune_defaults.place_slots = atoi(e);
     if (const char* e = getenv("OI_PLACE_SPACER_GB")) g_tune_defaults.place_spacer_gb = (float)atof(e);
@@ -454,6 +455,7 @@ int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double
   return blocks;
 }
 
+constexpr int kBX_lines = 128 / kLV;  // stored lines per row of a 128-voxel tile column (segment records)
 // ---- compacted line layout: which aligned kLV-voxel lines (owned AND ghost planes) hold a free voxel ----
 __global__ void __launch_bounds__(256) k_line_flags(Geom g, const uint8_t* __restrict__ code, int LW, int* __restrict__ flags) {
   const long long n = (long long)(g.nzl + 2) * g.ny * LW;
@@ -467,19 +469,34 @@ __global__ void __launch_bounds__(256) k_line_flags(Geom g, const uint8_t* __res
     flags[t] = any;
   }
 }
-// slot (exclusive scan of the flags) or -1; slot of the first line of every plane into plane_first[0 .. nzl+2]
-__global__ void __launch_bounds__(256) k_line_finalize(long long n, long long per_plane, const int* __restrict__ flags,
-                                                        int* __restrict__ slots, long long* __restrict__ plane_first) {
+// slot (exclusive scan of the flags) or -1; slot of the first line of every plane into plane_first[0 .. nzl+2].
+// seg (optional): one SEGMENT RECORD per row and 128-voxel tile column -- { slot of the segment's first stored line, bit
+// mask of its stored lines } -- from which a wave derives the slots of its whole row segment with one SCALAR load
+// (slot of line l = base + popcount(mask below l)) instead of a 4-byte table entry fetched by every lane.
+__global__ void __launch_bounds__(256) k_line_finalize(long long n, long long per_plane, int LW, int TX, const int* __restrict__ flags,
+                                                        int* __restrict__ slots, long long* __restrict__ plane_first,
+                                                        uint2* __restrict__ seg) {
+  constexpr int LPT = kBX_lines;  // lines per tile column
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     const int sl = slots[t];
     if (t % per_plane == 0) plane_first[t / per_plane] = sl;
     if (t == n - 1) plane_first[n / per_plane] = sl + flags[t];
-    slots[t] = flags[t] ? sl : -1;
+    const int li = (int)(t % LW);
+    if (seg && (li % LPT) == 0) {
+      unsigned m = 0;
+      for (int b = 0; b < LPT && li + b < LW; ++b) m |= flags[t + b] ? (1u << b) : 0u;
+      seg[(t / LW) * TX + li / LPT] = make_uint2((unsigned)sl, m);
+    }
   }
+  // (second pass over the same elements: the records read the flags of up to LPT - 1 later lines, which the slot
+  // rewrite does not touch -- flags stay as they are, only `slots` changes, and every thread rewrites its own entries)
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+    if (!flags[t]) slots[t] = -1;
 }
 // lineoff: (nzl + 2) * ny * LW ints; plane_first_dev: nzl + 3 long longs.  Returns hipSuccess or the failing call's error.
-hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, hipStream_t s) {
+hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, void* seg, hipStream_t s) {
   const int LW = (g.pitch + kLV - 1) / kLV;
+  const int TX = (g.pitch + 127) / 128;
   const long long n = (long long)(g.nzl + 2) * g.ny * LW;
   if (n >= (1ll << 31)) return hipErrorInvalidValue;
   int* flags = nullptr;
@@ -492,8 +509,8 @@ hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, 
   if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
   if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, lineoff, (int)n, s);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_line_finalize, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, n, (long long)g.ny * LW, flags, lineoff,
-                       plane_first_dev);
+    hipLaunchKernelGGL(k_line_finalize, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, n, (long long)g.ny * LW, LW, TX, flags, lineoff,
+                       plane_first_dev, (uint2*)seg);
     e = hipStreamSynchronize(s);
   }
   if (tmp) (void)hipFree(tmp);
@@ -2005,7 +2022,7 @@ template <> struct PBuf<float> {
   }
 };
 
-template <int R, int NW, typename PT, bool JACOBI>
+template <int R, int NW, typename PT, bool JACOBI, bool SEG>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     const double* __restrict__ r_in, double* __restrict__ r_out,
                                                     const double* __restrict__ q_in, double* __restrict__ q_out,
@@ -2014,7 +2031,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
                                                     int tiles_x, int tiles_y, int nzc, int part, int partial_base,
                                                     double* __restrict__ partials, Ctrl* ctrl,
                                                     const int* __restrict__ lineoff, const long long* __restrict__ plane_first,
-                                                    int LW, int fullline) {
+                                                    const uint2* __restrict__ seg, int LW, int fullline) {
   constexpr int BY = NW * R;
   constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
@@ -2066,15 +2083,30 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   const bool is_halo = yhalo || xhalo;
 
   const long long plane_lines4 = 4ll * g.ny * LW;
+  // SEG: the slots of a row segment come from its segment record (k_line_finalize) -- one scalar load per row instead of a
+  // table entry fetched by every lane.  `lsel` = this lane's line inside the 128-voxel segment
+  // (the bit masks are re-formed from an opaque copy of the lane index where they are used: two VGPRs held across the loop
+  // were two spills at the 128-register budget, see stage_halo)
+  auto slot_from = [&](uint2 rec, unsigned bit, unsigned below) { return (rec.y & bit) ? (int)rec.x + __builtin_popcount(rec.y & below) : -1; };
+  auto slot_own = [&](uint2 rec) {
+    int l_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(l_));
+    const unsigned bit = 1u << (l_ >> (kLVs - 1));
+    return slot_from(rec, bit, bit - 1u);
+  };
+  const long long seg_plane = (long long)g.ny * tiles_x;
   auto code_buf = [&](int p) { return buf_of(code + (long long)p * g.plane, g.plane); };
   auto slot_buf = [&](int p) { return buf_of(reinterpret_cast<const char*>(lineoff) + (long long)p * plane_lines4, plane_lines4); };
   auto x_buf = [&](int p) { return buf_of(x + (long long)p * g.plane, 8ll * g.plane); };
   auto row_of = [&](int rr_) { return j0 + wu + rr_ * NW; };  // scalar
 
   // ---- code bytes and line slots of plane p (they arrive one iteration before they are used) ----
-  auto codes_issue = [&](int p, unsigned short (&cn)[R], int (&ln)[R]) {
+  // SEG, main loop: the records are only REQUESTED here (scalar loads, `recs`); their slots are formed at the end of the
+  // iteration (slots_of) -- forming them here would wait for the scalar loads in the middle of the issue phase
+  uint2 rec_nn[R];
+  auto codes_issue = [&](int p, unsigned short (&cn)[R], int (&ln)[R], bool defer) {
 #pragma unroll
-    for (int rr_ = 0; rr_ < R; ++rr_) { cn[rr_] = 0; ln[rr_] = -1; }
+    for (int rr_ = 0; rr_ < R; ++rr_) { cn[rr_] = 0; ln[rr_] = -1; rec_nn[rr_] = make_uint2(0u, 0u); }
     if (p <= g.nzl + 1) {
       const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
 #pragma unroll
@@ -2087,20 +2119,35 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           cn[rr_] = __builtin_amdgcn_raw_buffer_load_b16(cb, ivox + j * g.pitch, 0, 0);
           // a lane outside the row reads 0 from the range check, which would be slot 0: such lanes have code 0 and the
           // slot is only looked at together with in_x
-          ln[rr_] = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, ilin + j * LW * 4, 0, 0);
+          if (SEG) {
+            rec_nn[rr_] = seg[(long long)p * seg_plane + (long long)j * tiles_x + tx];  // (uniform address: a scalar load)
+            if (!defer) ln[rr_] = slot_own(rec_nn[rr_]);
+          } else {
+            ln[rr_] = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, ilin + j * LW * 4, 0, 0);
+          }
         }
       }
     }
   };
   unsigned hcode = 0;  // halo lanes: code byte(s) and slot of their halo voxel (pair) in the plane staged next
   int hslot = 0;
-  auto halo_codes_issue = [&](int p) {
+  uint2 hrec_s = make_uint2(0u, 0u);  // SEG: the record of the row above / below the tile as requested (waves 0, 1)
+  auto halo_codes_issue = [&](int p, bool defer) {
     hcode = 0; hslot = 0;
+    hrec_s = make_uint2(0u, 0u);
     if (p <= g.nzl + 1 && wu < 3) {
       const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
       if (wu < 2) hcode = __builtin_amdgcn_raw_buffer_load_b16(cb, hvox, 0, 0);
       else hcode = __builtin_amdgcn_raw_buffer_load_b8(cb, hvox, 0, 0);
-      hslot = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, hlin, 0, 0);
+      // SEG: the row above / below the tile has a record, read by the whole wave (the slot only matters where hcode != 0); the
+      // lanes of wave 2 (columns left / right of the tile, a different row each) keep their 4-byte table entries
+      if (!SEG || wu == 2) {
+        hslot = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, hlin, 0, 0);
+      } else {
+        const int hr_ = min(max(hrow, 0), g.ny - 1);
+        hrec_s = seg[(long long)p * seg_plane + (long long)hr_ * tiles_x + tx];
+        if (!defer) hslot = slot_own(hrec_s);
+      }
     }
   };
   typedef typename PBuf<PT>::Pair PPair;
@@ -2238,10 +2285,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   {
     Raw raw;
     HRaw hr;
-    halo_codes_issue(gs);
-    codes_issue(gs - 1, cc_nn, lo_nn);
-    codes_issue(gs, cc_cur, lo_cur);
-    codes_issue(gs + 1, cc_nxt, lo_nxt);
+    halo_codes_issue(gs, false);
+    codes_issue(gs - 1, cc_nn, lo_nn, false);
+    codes_issue(gs, cc_cur, lo_cur, false);
+    codes_issue(gs + 1, cc_nxt, lo_nxt, false);
     plane_issue(gs - 1, cc_nn, lo_nn, pfm, pf0, raw, gs == 1 ? 2 : 0);
     plane_finish(gs - 1, cc_nn, pfm, pf0, raw, pn_nxt, rn_nxt, gs == 1 ? 2 : 0);
     stage_rows(tile + b_prev, pn_nxt);
@@ -2251,7 +2298,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     plane_finish(gs, cc_cur, pf0, pf1, raw, pn_nxt, rn_cur, 1);
     stage_rows(tile + b_cur, pn_nxt);
     stage_halo(tile + b_cur, hr);
-    halo_codes_issue(gs + 1);
+    halo_codes_issue(gs + 1, false);
   }
   __syncthreads();
 
@@ -2269,8 +2316,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
     if (more) halo_issue(pf1, pf2, hoff, hr);
     const unsigned hcode_now = hcode;
-    codes_issue(gz + 2, cc_nn, lo_nn);
-    if (more) halo_codes_issue(gz + 2);
+    codes_issue(gz + 2, cc_nn, lo_nn, true);
+    if (more) halo_codes_issue(gz + 2, true);
     const unsigned hcode_next = hcode;
     const int hslot_next = hslot;
     __builtin_amdgcn_sched_barrier(0);
@@ -2318,6 +2365,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         s_qdq += q0 * d0; s_qdq += q1 * d1;
       }
     }
+    if (SEG) {  // the records requested at the top of this iteration have long arrived: their slots
+#pragma unroll
+      for (int rr_ = 0; rr_ < R; ++rr_) lo_nn[rr_] = slot_own(rec_nn[rr_]);
+      if (more && wu < 2) hslot = slot_own(hrec_s);
+    }
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       rn_cur[rr_] = rn_nxt[rr_];
@@ -2362,26 +2414,31 @@ template <int R, int NW, typename PT, bool JAC>
 static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                           const double* q_in, double* q_out, const void* p_in, void* p_out, double* rec, int k,
                           int zchunk, int tiles_x, int tiles_y, int nzc, int part, int partial_base, double* partials,
-                          Ctrl* ctrl, const int* lineoff, const long long* plane_first, hipStream_t s) {
-  hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
-                     (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
-                     partials, ctrl, lineoff, plane_first, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
+                          Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+  if (seg && g.tune.cg1_seg)
+    hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
+                       (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
+                       partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
+  else
+    hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, false>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
+                       (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
+                       partials, ctrl, lineoff, plane_first, (const uint2*)nullptr, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
 }
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
                          const double* q_in, double* q_out, const void* p_in, void* p_out, int jacobi,
                          double* rec, int k, int zchunk, int tiles_x, int tiles_y, int nzc, int part,
                          int partial_base, double* partials, Ctrl* ctrl, const int* lineoff, const long long* plane_first,
-                         hipStream_t s) {
+                         const void* seg, hipStream_t s) {
   // compacted layout: the descriptor-addressed kernel, unless a plane is too large for a 31-bit range or the tuning
   // asks for the first form (cross-checks)
   if (lineoff && plane_first && g.tune.cg1_kernel == 0 && 8ll * g.plane < kBufMax) {
     if (jacobi)
       launch_cg1b_k<R, NW, PT, true>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, tiles_y,
-                                     nzc, part, partial_base, partials, ctrl, lineoff, plane_first, s);
+                                     nzc, part, partial_base, partials, ctrl, lineoff, plane_first, seg, s);
     else
       launch_cg1b_k<R, NW, PT, false>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, rec, k, zchunk, tiles_x, tiles_y,
-                                      nzc, part, partial_base, partials, ctrl, lineoff, plane_first, s);
+                                      nzc, part, partial_base, partials, ctrl, lineoff, plane_first, seg, s);
     return;
   }
 #define OI_CG1K(JAC, CMP)                                                                                              \
@@ -2434,7 +2491,7 @@ Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part) {
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
                double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff,
-               const long long* plane_first, hipStream_t s) {
+               const long long* plane_first, const void* seg, hipStream_t s) {
   // automatic tile shape (1024^3 sweep, profiles/r01/cg1_sweep.txt): 16-wave, 32-row tiles pay
   // off on large planes; locals only, handles may be driven from several host threads
   const bool descr = lineoff && plane_first && g.tune.cg1_kernel == 0 && 8ll * g.plane < kBufMax;
@@ -2445,10 +2502,10 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
   do {                                                                                                             \
     if (p_f32) launch_cg1_r<RR, WW, float>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, \
                                            k, zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl,   \
-                                           lineoff, plane_first, s);                                               \
+                                           lineoff, plane_first, seg, s);                                          \
     else launch_cg1_r<RR, WW, double>(blocks, g, code, x, r_in, r_out, q_in, q_out, p_in, p_out, jacobi, rec, k,   \
                                       zchunk, tiles_x, tiles_y, nzc, part, partial_base, partials, ctrl, lineoff,  \
-                                      plane_first, s);                                                             \
+                                      plane_first, seg, s);                                                        \
   } while (0)
   if (R == 4) OI_CG1(4, 8);
   else if (R == 2 && NW == 16) OI_CG1(2, 16);

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const uint8_t*
 template <class W, class D>
 __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, const float* __restrict__ b,
                                                   const float* __restrict__ xc, const float* __restrict__ xc2, Dims C,
-                                                  float scale, float* __restrict__ out) {
+                                                  float scale, const float* __restrict__ xpre, float* __restrict__ out) {
   OI_MG_CELL(L)
   auto x2 = [&](long long mm, int ii, int jj, int kk) -> float {
     const float dd = (float)L.diag[mm];
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, con
     const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
     float c = xc[cm];
     if (xc2) c += xc2[cm];
-    return kOmega * b[mm] * rcp(dd) + scale * c;
+    return xpre ? xpre[mm] + scale * c : kOmega * b[mm] * rcp(dd) + scale * c;
   };
   float o = 0.f;
   const float d = (float)L.diag[m];
@@ -327,27 +327,38 @@ __device__ __forceinline__ void ld4(const uint8_t* p, float (&v)[4]) {
   v[0] = (float)(t & 0xffu); v[1] = (float)((t >> 8) & 0xffu); v[2] = (float)((t >> 16) & 0xffu); v[3] = (float)(t >> 24);
 }
 
-template <class W, class D>
-__global__ void __launch_bounds__(256) k_mg_pre4(LevelT<W, D> L, int kfirst, int nplanes, const float* __restrict__ b,
-                                                  float* __restrict__ r) {
+// k_mg_lin4<SRC, OUT>: one linear step on a level, four cells per thread.  u = the first Jacobi iterate w b / D formed on the
+// fly (SRC 0) or a stored vector x (SRC 1); res = b - A u; the result is res (OUT 0) or the smoothed u + w res / D (OUT 1):
+//   <0, 0> pre-smoothing residual (one sweep from zero)          <1, 0> residual of a stored iterate
+//   <0, 1> second Jacobi iterate (two sweeps from zero)          <1, 1> one Jacobi sweep on a stored iterate
+// Same arithmetic in the same order as the one-cell kernels k_mg_pre / k_mg_resid / k_mg_jacobi (bit-identical results).
+template <class W, class D, int SRC, int OUT>
+__global__ void __launch_bounds__(256) k_mg_lin4(LevelT<W, D> L, int kfirst, int nplanes, const float* __restrict__ b,
+                                                  const float* __restrict__ x, float* __restrict__ r) {
   OI_MG_CELL4(L)
   auto xs1 = [&](float bb, float dd) -> float { return dd > 0.f ? kOmega * bb * rcp(dd) : 0.f; };
-  auto xs4 = [&](long long mm, float (&o)[4]) {
+  auto u4 = [&](long long mm, float (&o)[4]) {
+    if (SRC == 1) { ld4(x + mm, o); return; }
     float bb[4], dd[4];
     ld4(b + mm, bb); ld4(L.diag + mm, dd);
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = xs1(bb[c], dd[c]);
   };
+  auto u1 = [&](long long mm) -> float { return SRC == 1 ? x[mm] : xs1(b[mm], (float)L.diag[mm]); };
   const long long mxm = (L.periodic && i == 0) ? m + (L.nx - 1) : m - 1;                 // left of cell i
   const long long mxp = (L.periodic && i + 3 == L.nx - 1) ? m + 3 - (L.nx - 1) : m + 4;  // right of cell i + 3
   const long long mym = (L.periodic && j == 0) ? m + sy * (L.ny - 1) : m - sy;
   const long long myp = (L.periodic && j == L.ny - 1) ? m - sy * (L.ny - 1) : m + sy;
   float bc[4], dc[4], xc_[4], xym[4], xyp[4], xzm[4], xzp[4], wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
   ld4(b + m, bc); ld4(L.diag + m, dc);
+  if (SRC == 1) {
+    ld4(x + m, xc_);
+  } else {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) xc_[c] = xs1(bc[c], dc[c]);
-  const float xl = xs1(b[mxm], (float)L.diag[mxm]), xr = xs1(b[mxp], (float)L.diag[mxp]);
-  xs4(mym, xym); xs4(myp, xyp); xs4(m - sz, xzm); xs4(m + sz, xzp);
+    for (int c = 0; c < 4; ++c) xc_[c] = xs1(bc[c], dc[c]);
+  }
+  const float xl = u1(mxm), xr = u1(mxp);
+  u4(mym, xym); u4(myp, xyp); u4(m - sz, xzm); u4(m + sz, xzp);
   ld4(L.wx + m, wxc); ld4(L.wy + m, wyc); ld4(L.wy + mym, wym); ld4(L.wz + m, wzc); ld4(L.wz + (m - sz), wzm);
   const float wxl = (float)L.wx[mxm];
   float res[4];
@@ -361,7 +372,8 @@ __global__ void __launch_bounds__(256) k_mg_pre4(LevelT<W, D> L, int kfirst, int
       s += wyc[c] * xyp[c];
       s += wzm[c] * xzm[c];
       s += wzc[c] * xzp[c];
-      res[c] = bc[c] - (dc[c] * xc_[c] - s);
+      const float rr = bc[c] - (dc[c] * xc_[c] - s);
+      res[c] = OUT == 0 ? rr : xc_[c] + kOmega * rr * rcp(dc[c]);
     }
   }
   *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
@@ -370,10 +382,12 @@ __global__ void __launch_bounds__(256) k_mg_pre4(LevelT<W, D> L, int kfirst, int
 template <class W, class D>
 __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, int nplanes, const float* __restrict__ b,
                                                    const float* __restrict__ xc, const float* __restrict__ xc2, Dims C,
-                                                   float scale, float* __restrict__ out) {
+                                                   float scale, const float* __restrict__ xpre, float* __restrict__ out) {
   OI_MG_CELL4(L)
   const bool per = L.periodic != 0;
+  // xpre != null: the iterate before the coarse correction is a stored vector (two pre-smoothing sweeps), not w b / D
   auto x21 = [&](float bb, float dd, float cc) -> float { return dd > 0.f ? kOmega * bb * rcp(dd) + scale * cc : 0.f; };
+  auto x21p = [&](float xp, float dd, float cc) -> float { return dd > 0.f ? xp + scale * cc : 0.f; };
   auto par = [&](long long cm) -> float {
     float c = xc[cm];
     if (xc2) c += xc2[cm];
@@ -382,12 +396,12 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
   // x2 of the four cells i .. i + 3 of row jj in plane kk (array offset mm); their parents are (i >> 1) and (i >> 1) + 1
   auto x24 = [&](long long mm, int jj, int kk, float (&o)[4]) {
     float bb[4], dd[4];
-    ld4(b + mm, bb); ld4(L.diag + mm, dd);
+    ld4((xpre ? xpre : b) + mm, bb); ld4(L.diag + mm, dd);
     const long long cm = (long long)(i >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
     float2 p = *reinterpret_cast<const float2*>(xc + cm);
     if (xc2) { const float2 q = *reinterpret_cast<const float2*>(xc2 + cm); p.x += q.x; p.y += q.y; }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = x21(bb[c], dd[c], c < 2 ? p.x : p.y);
+    for (int c = 0; c < 4; ++c) o[c] = xpre ? x21p(bb[c], dd[c], c < 2 ? p.x : p.y) : x21(bb[c], dd[c], c < 2 ? p.x : p.y);
   };
   auto zero4 = [](float (&o)[4]) { o[0] = o[1] = o[2] = o[3] = 0.f; };
   const long long mxm = (L.periodic && i == 0) ? m + (L.nx - 1) : m - 1;
@@ -400,8 +414,11 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
   ld4(L.diag + m, dc); ld4(b + m, bc);
   x24(m, j, k, cc);
   const long long prow = (long long)C.nx * (j >> 1) + C.sz * parent_plane(L, C, k);
-  const float xl = (per || i > 0) ? x21(b[mxm], (float)L.diag[mxm], par((long long)(ixm >> 1) + prow)) : 0.f;
-  const float xr = (per || i + 3 < L.nx - 1) ? x21(b[mxp], (float)L.diag[mxp], par((long long)(ixp >> 1) + prow)) : 0.f;
+  auto x2e = [&](long long mm, long long cm) -> float {
+    return xpre ? x21p(xpre[mm], (float)L.diag[mm], par(cm)) : x21(b[mm], (float)L.diag[mm], par(cm));
+  };
+  const float xl = (per || i > 0) ? x2e(mxm, (long long)(ixm >> 1) + prow) : 0.f;
+  const float xr = (per || i + 3 < L.nx - 1) ? x2e(mxp, (long long)(ixp >> 1) + prow) : 0.f;
   if (per || j > 0) x24(mym, jym, k, xym); else zero4(xym);
   if (per || j < L.ny - 1) x24(myp, jyp, k, xyp); else zero4(xyp);
   x24(m - sz, j, k - 1, xzm); x24(m + sz, j, k + 1, xzp);
@@ -547,6 +564,7 @@ struct MgLevelHost {
   long long n = 0;          // cells incl. the two ghost planes
   void *wx = nullptr, *wy = nullptr, *wz = nullptr, *diag = nullptr;
   float *b = nullptr, *b2 = nullptr, *r = nullptr, *x2 = nullptr, *xs = nullptr;
+  float *t = nullptr, *t2 = nullptr;  // two smoothing sweeps (MgHierarchy::nu_coarse = 2): the pre-smoothed iterate, a scratch
   template <class W, class D>
   LevelT<W, D> dev() const {
     LevelT<W, D> L;
@@ -566,13 +584,14 @@ struct MgHierarchy {
   unsigned wmask = kWCycleMask;
   float scale = kScale;
   bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
+  int nu_coarse = 1;    // damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (1 or 2)
   bool failed = false;
 };
 
 void mg_destroy(MgHierarchy* mg) {
   if (!mg) return;
   for (auto& L : mg->levels) {
-    void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.b2, L.r, L.x2, L.xs};
+    void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.b2, L.r, L.x2, L.xs, L.t, L.t2};
     for (void* q : p)
       if (q) (void)hipFree(q);
   }
@@ -657,6 +676,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   if (g.tune.mg_wmask >= 0) mg->wmask = (unsigned)g.tune.mg_wmask;                   // experiments with the cycle shape
   if (g.tune.mg_scale > 0.f) mg->scale = g.tune.mg_scale;
   mg->novec4 = g.tune.mg_novec4 != 0;
+  mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
     L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
@@ -689,6 +709,14 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
       MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
     }
     mg->bytes += (size_t)L.n * (3 * wb + db + 5 * sizeof(float));
+    if (mg->nu_coarse > 1) {
+      float** more[] = {&L.t, &L.t2};
+      for (float** v : more) {
+        MGC(hipMalloc((void**)v, sizeof(float) * L.n));
+        MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
+      }
+      mg->bytes += (size_t)L.n * 2 * sizeof(float);
+    }
     // operator: owned contributions into float arrays, summed / exchanged, then (compact levels) narrowed
     float* t[4] = {nullptr, nullptr, nullptr, nullptr};
     if (L.compact) {
@@ -774,10 +802,26 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   // byte / 16-bit levels whose rows split into groups of four cells take the four-cells-per-thread kernels
   const bool vec4 = L.compact && (L.d.nx & 3) == 0 && L.d.nx >= 64 && !mg->novec4;
   const int blocks4 = (int)((((long long)(L.d.nx >> 2) * L.d.ny * L.d.nzl) + 255) / 256);
-  if (vec4 && blocks4 > 0)
-    hipLaunchKernelGGL((k_mg_pre4<uint8_t, uint16_t>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), kfirst, L.d.nzl, rhs, L.r);
-  else
-    OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
+  const bool two = mg->nu_coarse > 1;  // two sweeps before and two after the correction
+#define OI_MG_LIN4(SRC, OUT, B, X, DST)                                                                                      \
+  hipLaunchKernelGGL((k_mg_lin4<uint8_t, uint16_t, SRC, OUT>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), \
+                     kfirst, L.d.nzl, B, X, DST)
+  if (!two) {
+    if (vec4 && blocks4 > 0) OI_MG_LIN4(0, 0, rhs, (const float*)nullptr, L.r);
+    else OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
+  } else {
+    // x2 = two damped-Jacobi sweeps from zero (kept in L.t for the post-smoother), r = rhs - A x2
+    if (vec4 && blocks4 > 0) {
+      OI_MG_LIN4(0, 1, rhs, (const float*)nullptr, L.t);
+    } else {
+      OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)nullptr, L.t2, 1);
+      if (!ghost_exchange(mg, L, L.t2, sizeof(float), s)) return false;
+      OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t2, L.t, 0);
+    }
+    if (!ghost_exchange(mg, L, L.t, sizeof(float), s)) return false;
+    if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 0, rhs, (const float*)L.t, L.r);
+    else OI_MG_LAUNCH(k_mg_resid, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t, L.r);
+  }
   if (!restrict_to(mg, nullptr, nullptr, nullptr, &L, C, C.b, s)) return false;
   if (!coarse_cycle(mg, l + 1, C.b, C.x2, s)) return false;
   const float* second = nullptr;
@@ -787,11 +831,20 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
     if (!coarse_cycle(mg, l + 1, C.b2, C.xs, s)) return false;
     second = C.xs;
   }
+  // correction + post-smoothing: one sweep fused with the prolongation; with two sweeps a plain one follows
+  const float* xpre = two ? L.t : nullptr;
+  float* dst = two ? L.t2 : out;
   if (vec4 && blocks4 > 0)
     hipLaunchKernelGGL((k_mg_post4<uint8_t, uint16_t>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), kfirst, L.d.nzl, rhs,
-                       C.x2, second, C.d, mg->scale, out);
+                       C.x2, second, C.d, mg->scale, xpre, dst);
   else
-    OI_MG_LAUNCH(k_mg_post, L, L.d.nzl, s, kfirst, rhs, C.x2, second, C.d, mg->scale, out);
+    OI_MG_LAUNCH(k_mg_post, L, L.d.nzl, s, kfirst, rhs, C.x2, second, C.d, mg->scale, xpre, dst);
+  if (two) {
+    if (!ghost_exchange(mg, L, L.t2, sizeof(float), s)) return false;
+    if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 1, rhs, (const float*)L.t2, out);
+    else OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t2, out, 0);
+  }
+#undef OI_MG_LIN4
   return ghost_exchange(mg, L, out, sizeof(float), s);
 }
 

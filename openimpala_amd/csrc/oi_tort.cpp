@@ -90,6 +90,7 @@ struct oi_tort {
   double* rec = nullptr;                // its per-iteration scalar records
   // compacted line layout of r, q, p in the single-kernel variant (see launch_build_lines)
   int* lineoff = nullptr;
+  unsigned long long* seg = nullptr;  // one record per row and 128-voxel tile column: first slot + mask of the stored lines
   long long* plane_first_dev = nullptr;
   std::vector<long long> plane_first;   // first slot of every plane, gz = 0 .. nzl + 2
   long long nvec_cg = 0;                // elements of r / q / p (= g.nvec in the dense layout)
@@ -234,7 +235,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
     h->r = h->q = h->r2 = h->q2 = nullptr; h->p[0] = h->p[1] = nullptr;
     vecset_free(h->vs);
   }
-  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->plane_first_dev,
+  void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->seg, h->plane_first_dev,
                  h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
   for (void* d : dev)
     if (d) (void)hipFree(d);
@@ -438,17 +439,22 @@ static oi_status vecset_alloc(oi_tort* h, bool search) {
   for (int attempt = 0;; ++attempt) {
     if (attempt == 1) spacer_gb = 0.0;
     if (attempt == 2) want = 6;
-    const int na = spacer_gb > 0.0 ? (want + 1) / 2 : want;
+    const int na = spacer_gb > 0.0 ? std::max(6, (want + 1) / 2) : want;  // (the six needed slots lie in front of the spacer)
     char* spacer = nullptr;
     bool ok = hipMalloc((void**)&v.x, h->x_bytes) == hipSuccess;
     for (int k = 0; ok && k < want; ++k) {
-      if (k == na) ok = hipMalloc((void**)&spacer, (size_t)(spacer_gb * 1e9)) == hipSuccess;
+      // SPARE slots (and the spacer) only while the driver hands memory out quickly: memory another process has used is
+      // cleared when it is allocated, at ~10 GB/s on this pool (a 60 GB set: 0.01 s on a clean card, 5.6 s on a dirty one,
+      // profiles/r03/place_runs_a.txt).  x and six slots are needed whatever they cost; what the search adds is bounded
+      if (k >= 6 && now_s() - t0 > (double)h->g.tune.place_alloc_budget_s) { want = k; break; }
+      if (k == na && k >= 6) ok = hipMalloc((void**)&spacer, (size_t)(spacer_gb * 1e9)) == hipSuccess;
       ok = ok && hipMalloc((void**)&v.slot[k], h->slot_bytes) == hipSuccess;
       if (ok) v.nslots = k + 1;
     }
     if (spacer) (void)hipFree(spacer);
     if (ok) {
-      v.nfront = na; v.bytes = set_bytes;
+      const size_t set_bytes = (size_t)v.nslots * h->slot_bytes + h->x_bytes;
+      v.nfront = std::min(na, v.nslots); v.bytes = set_bytes;
       h->place_spacer_bytes = (size_t)(spacer_gb * 1e9);
       break;
     }
@@ -791,7 +797,8 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     if (!dense) {
       OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
       OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));
-      HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, s));
+      if (h->cg1) OIC(dmalloc(h, &h->seg, (size_t)(g.nzl + 2) * g.ny * ((g.pitch + 127) / 128)));  // segment records (k_cg1b)
+      HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, h->seg, s));
       h->plane_first.resize((size_t)g.nzl + 3);
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
       h->nvec_cg = std::max<long long>(16, (long long)oi::kLV * h->plane_first[g.nzl + 2]);
@@ -1101,7 +1108,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       {
         PROF(K_CG1);
         nb = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                        h->partials, h->ctrl, 0, 0, 0, h->lineoff, h->plane_first_dev, s);
+                        h->partials, h->ctrl, 0, 0, 0, h->lineoff, h->plane_first_dev, h->seg, s);
       }
       if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       // (alpha_k, beta_{k+1} and the stop test are formed in the prologue of kernel k + 1; cg_iterate closes the last record)
@@ -1117,10 +1124,10 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
         HIPC(hipEventRecord(h->ev_start, s));
         HIPC(hipStreamWaitEvent(h->aux_stream, h->ev_start, 0));
         nb_b = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 1, 0, h->lineoff, h->plane_first_dev, s);
+                          h->partials, h->ctrl, 1, 1, 0, h->lineoff, h->plane_first_dev, h->seg, s);
         HIPC(hipEventRecord(h->ev_boundary, s));
         nb_i = launch_cg1(g, h->code, h->x, rb[in], rb[out], qb[in], qb[out], h->p[in], h->p[out], pf, jac, h->rec, k,
-                          h->partials, h->ctrl, 1, 2, nb_b < 0 ? 0 : nb_b, h->lineoff, h->plane_first_dev, h->aux_stream);
+                          h->partials, h->ctrl, 1, 2, nb_b < 0 ? 0 : nb_b, h->lineoff, h->plane_first_dev, h->seg, h->aux_stream);
         HIPC(hipEventRecord(h->ev_interior, h->aux_stream));
         // (a transport whose exchange may not overlap its own collectives keeps everything on the solver stream)
         hipStream_t xs = h->comm->exchange_overlaps ? h->comm_stream : s;
@@ -2027,14 +2034,17 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_replicate_cells") t.mg_replicate_cells = (long long)value;
   else if (k == "mg_wmask") t.mg_wmask = iv;
   else if (k == "mg_scale") t.mg_scale = (float)value;
+  else if (k == "mg_nu_coarse") t.mg_nu_coarse = iv >= 2 ? 2 : 1;
   else if (k == "force_comm") t.force_comm = iv != 0;
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;
   else if (k == "place_spacer_gb") t.place_spacer_gb = (float)value;
   else if (k == "cg1_kernel") t.cg1_kernel = iv;
+  else if (k == "cg1_seg") t.cg1_seg = iv != 0;
   else if (k == "place_min_mb") t.place_min_mb = iv > 0 ? iv : 0;
   else if (k == "place_extent_gb") t.place_extent_gb = (float)value;
   else if (k == "place_cache") t.place_cache = iv != 0;
+  else if (k == "place_alloc_budget_s") t.place_alloc_budget_s = (float)value;
   else { oi::set_error("%s: unknown key '%s'", __func__, key); return OI_BAD_ARG; }
   oi::set_default_tune(t);
   return OI_OK;
@@ -2049,10 +2059,11 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_compact = old.cg1_compact;
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
-  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse;
   t.force_comm = old.force_comm;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;
+  t.place_alloc_budget_s = old.place_alloc_budget_s;
   h->g.tune = t;
   return OI_OK;
 }

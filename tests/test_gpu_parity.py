@@ -277,6 +277,36 @@ def test_multigrid_preconditioned_cg(sample, goldens, pid, direction):
     t.destroy()
 
 
+def test_multigrid_two_coarse_sweeps(sample, goldens, oi_option):
+    """`mg_nu_coarse` = 2: two damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (the fine level
+    keeps one).  Still a fixed symmetric cycle, so plain PCG applies: same answers as the goldens with fewer iterations than
+    the one-sweep cycle; the four-cells-per-thread kernels and the one-cell kernels give bit-identical iterates; odd shapes
+    (truncated aggregates, levels that fall back to the one-cell kernels) against the oracle."""
+    g = goldens["phases"]["1"]
+    its, hist = {}, {}
+    for nu, novec4 in ((1, 0), (2, 0), (2, 1)):
+        oi_option("mg_nu_coarse", nu, reset=1)
+        oi_option("mg_novec4", novec4, reset=0)
+        t = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG)
+        tau = t.value()
+        st = t.stats()
+        assert t.status == oia.OI_OK and st.converged and tau == pytest.approx(g["tau"][0], rel=1e-7)
+        assert st.flux_in == pytest.approx(g["flux"][0], rel=1e-7)
+        its[(nu, novec4)] = st.iterations
+        hist[(nu, novec4)] = (tau, st.final_relres)
+        t.destroy()
+    assert its[(2, 0)] < its[(1, 0)] and its[(2, 0)] == its[(2, 1)]
+    assert hist[(2, 0)] == hist[(2, 1)]      # bit-identical solves
+    oi_option("mg_nu_coarse", 2, reset=1)
+    oi_option("mg_novec4", 0, reset=0)
+    phase = o.gen_spheres((37, 45, 51), 6, 5, 0.5)
+    for d in range(3):
+        ref = o.tortuosity(phase, 1, d, -1.0, 1.0, eps=1e-10)
+        t = oia.TortuosityMI355(phase, 1, d, -1.0, 1.0, eps=1e-10, precond=oia.PRECOND_MG)
+        assert t.value() == pytest.approx(ref["tau"], rel=1e-8) and t.getSolverIterations() < ref["iterations"] / 4
+        t.destroy()
+
+
 def test_multigrid_ragged_shapes_and_refusals():
     phase = o.gen_spheres((37, 45, 51), 6, 5, 0.5)       # odd sizes: truncated aggregates on every level
     for d in range(3):

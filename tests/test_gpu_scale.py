@@ -133,6 +133,7 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
     buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
     out = {}
     oi_option("place_cache", 0, reset=1)
+    oi_option("place_alloc_budget_s", 1e9, reset=0.5)   # (spare slots whatever the driver's clearing costs: their number is asserted)
     for name, trials, slots, spacer in (("off", 0, 12, 48.0), ("six", 6, 6, 0.0), ("spare", 10, 12, 48.0)):
         oi_option("place_trials", trials, reset=48)
         oi_option("place_slots", slots, reset=12)

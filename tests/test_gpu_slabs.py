@@ -221,6 +221,7 @@ def test_placement_search_on_slabs_with_neighbours(oi_option):
     oi_option("place_trials", 6, reset=48)
     oi_option("place_slots", 8, reset=12)
     oi_option("place_spacer_gb", 0.0, reset=48.0)
+    oi_option("place_alloc_budget_s", 1e9, reset=0.5)
     phase = o.gen_spheres((48, 40, 44), 21, 5, 0.45)
     ref = o.tortuosity(phase, 1, 2, -1.0, 1.0, eps=1e-10)
     nranks, nz = 3, phase.shape[0]

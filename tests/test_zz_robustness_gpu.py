@@ -156,14 +156,19 @@ def test_searching_single_kernel_handles_release_their_arenas():
     ph = oia.gen_bernoulli_device(shape, 7, 0.75)
     free = []
     held = []
-    for _ in range(5):
+    oia.set_option("place_alloc_budget_s", 1e9)   # (spare slots whatever the driver's clearing of them costs)
+    for n in range(5):
         t = oia.TortuosityMI355(ph, 1, 0, shape=shape, kernel=oia.KERNEL_FUSED1, eps=1e-3, maxiter=50)
         pl = t.placement()
-        assert pl["tried"] > 1, pl   # the search did run
+        # the search did run: in full for the first handle; the later ones may take its placement from the process cache
+        # (one verification cycle) -- they allocate and free the same spare slots either way
+        assert pl["nslots"] > 6 and (pl["tried"] > 1 or (n > 0 and pl["cache_hit"])), pl
+        assert pl["peak_device_bytes"] > t.stats().bytes_device + 2 * 400e6, pl
         t.cg_begin(); t.cg_iterate(4); t.cg_finish()
         held.append((oia.device_memory()[0], t.stats().bytes_device))
         t.destroy()
         free.append(oia.device_memory()[0])
+    oia.set_option("place_alloc_budget_s", 0.5)
     ph.free()
     assert max(free[1:]) - min(free[1:]) < (64 << 20), [f >> 20 for f in free]
     # while alive a handle holds what it accounts for -- the spare slots of the search have been released (the driver may

@@ -7,10 +7,15 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--structure", default="spheres")
+ap.add_argument("--nu", default="1", help="comma-separated mg_nu_coarse values, alternated")
+ap.add_argument("--wmask", default="-1", help="comma-separated mg_wmask values (-1 = default)")
 a = ap.parse_args()
 n = a.size
 buf, desc = bench.make_structure(oia, a, (n, n, n), 0, n)
-for rep in range(3):
+for rep in range(3 * len(a.nu.split(",")) * len(a.wmask.split(","))):
+    nu = int(a.nu.split(",")[rep % len(a.nu.split(","))])
+    wm = int(a.wmask.split(",")[(rep // len(a.nu.split(","))) % len(a.wmask.split(","))])
+    oia.set_option("mg_nu_coarse", nu); oia.set_option("mg_wmask", wm)
     tm = oia.TortuosityMI355(buf, 1, oia.Direction.X, 0.0, 1.0, shape=(n, n, n), eps=1e-6, precond=oia.PRECOND_MG, profile=1, maxiter=1000)
     t0 = time.perf_counter()
     tm.cg_begin()
@@ -21,6 +26,6 @@ for rep in range(3):
     tm.cg_finish()
     dt = time.perf_counter() - t0
     mk = tm.kernel_times()
-    print(f"solve {rep}: {its} iterations, relres {rel:.3e}, {dt:.3f} s,",
+    print(f"nu_coarse {nu} wmask {wm} solve {rep}: {its} iterations, relres {rel:.3e}, {dt:.3f} s,",
           {k: round(v[0] / max(1, v[1]), 3) for k, v in mk.items() if v[1]}, flush=True)
     tm.destroy()
