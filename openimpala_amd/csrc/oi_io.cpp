@@ -8,7 +8,7 @@
 //               planar config; 1-bit data honours FILLORDER and ignores PHOTOMETRIC;
 //               voxel > threshold -> 1 else 0.
 //               Encodings decoded here (what libtiff decodes for the reference): none, LZW (5),
-//               Deflate (8 / 32946, zlib), PackBits (32773), horizontal predictor (317 = 2);
+//               Deflate (8 / 32946, zlib), PackBits (32773), horizontal predictor (317 = 2), floating-point predictor (317 = 3);
 //               classic TIFF and BigTIFF, both byte orders.  Anything else is reported, never guessed.
 //   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
 #include <fcntl.h>
@@ -280,6 +280,22 @@ void unpredict_rows(uint8_t* buf, size_t rows, size_t cols, bool swap) {
   }
 }
 
+// undo the floating-point predictor (tag 317 = 3, TIFF Technical Note 3; one sample per pixel) row by row, in place: the
+// writer split every row of IEEE samples into byte planes -- all most significant bytes first, whatever the byte order of the
+// file -- and differenced the resulting row of BYTES horizontally.  On return the samples are back in the file's byte order.
+void unpredict_float_rows(uint8_t* buf, size_t rows, size_t cols, size_t bytes_ps, bool file_le, std::vector<uint8_t>& tmp) {
+  const size_t rb = cols * bytes_ps;
+  tmp.resize(rb);
+  for (size_t r = 0; r < rows; ++r) {
+    uint8_t* row = buf + r * rb;
+    for (size_t i = 1; i < rb; ++i) row[i] = (uint8_t)(row[i] + row[i - 1]);
+    memcpy(tmp.data(), row, rb);
+    for (size_t c = 0; c < cols; ++c)
+      for (size_t b = 0; b < bytes_ps; ++b)  // plane b holds byte b counted from the most significant one
+        row[c * bytes_ps + (file_le ? bytes_ps - 1 - b : b)] = tmp[b * cols + c];
+  }
+}
+
 // interpretBytesAsDouble of the reference (TiffReader.cpp, used at :385,:430)
 double sample_as_double(const uint8_t* p, uint32_t bps, uint32_t fmt, bool swap) {
   switch (bps) {
@@ -368,11 +384,13 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
     oi::set_error("'%s': TIFF compression %u is not supported (none, LZW, Deflate and PackBits are)", path, pg.comp);
     return OI_IO_ERROR;
   }
-  if (pg.predictor != 1 && !(pg.predictor == 2 && pg.bps >= 8 && pg.fmt != 3)) {
+  const bool float_pred = pg.predictor == 3 && pg.fmt == 3 && (pg.bps == 32 || pg.bps == 64) && pg.spp == 1;
+  if (pg.predictor != 1 && !(pg.predictor == 2 && pg.bps >= 8 && pg.fmt != 3) && !float_pred) {
     oi::set_error("'%s': TIFF predictor %u with %u-bit format %u is not supported", path, pg.predictor, pg.bps, pg.fmt);
     return OI_IO_ERROR;
   }
   const bool swap = f.le != host_is_le();
+  std::vector<uint8_t> ptmp;
   const size_t bytes_ps = p0.bps >= 8 ? p0.bps / 8 : 1;
   // geometry of one chunk (strip or tile)
   const size_t cw = pg.tiled ? pg.tile_w : W;
@@ -394,7 +412,7 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
       if (n > f.d.size() || o > f.d.size() - n) { oi::set_error("'%s': chunk outside file", path); return OI_IO_ERROR; }  // (o + n may wrap)
       const uint8_t* src = f.d.data() + o;
       size_t avail = n;
-      if (pg.comp != 1 || pg.predictor == 2) {
+      if (pg.comp != 1 || pg.predictor != 1) {
         bool ok = true;
         if (pg.comp == 32773) ok = unpackbits(src, n, buf, expect);
         else if (pg.comp == 5) ok = unlzw(src, n, buf, expect);
@@ -407,6 +425,8 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
           else if (bytes_ps == 2) unpredict_rows<uint16_t>(buf.data(), rows_ok, cw, swap);
           else if (bytes_ps == 4) unpredict_rows<uint32_t>(buf.data(), rows_ok, cw, swap);
           else unpredict_rows<uint64_t>(buf.data(), rows_ok, cw, swap);
+        } else if (float_pred) {
+          unpredict_float_rows(buf.data(), buf.size() / row_bytes, cw, bytes_ps, f.le, ptmp);
         }
         src = buf.data();
         avail = buf.size();

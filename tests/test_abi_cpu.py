@@ -199,6 +199,27 @@ def test_tiff_reader_predictor_bigtiff_and_sequences(tmp_path, big):
         oia.TiffReader(str(tmp_path / "slice_"), num_files=nz + 1, start_index=3, digits=4).threshold(thr)
 
 
+@pytest.mark.parametrize("compression", ["tiff_lzw", "tiff_adobe_deflate"])
+def test_tiff_reader_floating_point_predictor(tmp_path, compression):
+    """Predictor 3 (TIFF Technical Note 3: byte planes of the IEEE samples, differenced as bytes) on float32 stacks written
+    by libtiff; expected voxels = libtiff's own decode of the same file."""
+    Image = _pil()
+    rng = np.random.default_rng(5)
+    nz, ny, nx = 3, 31, 67
+    vol = (np.cumsum(rng.normal(0.0, 0.3, size=(nz, ny, nx)), axis=2) + 5.0).astype(np.float32)
+    pages = [Image.fromarray(v) for v in vol]
+    p = tmp_path / "fpred.tif"
+    pages[0].save(p, format="TIFF", compression=compression, tiffinfo={317: 3}, save_all=True, append_images=pages[1:])
+    with Image.open(p) as im:
+        if im.tag_v2.get(317) != 3:
+            pytest.skip("this libtiff build did not apply the floating-point predictor")
+    expect = np.stack([_page(Image, p, k) for k in range(nz)])
+    assert np.array_equal(expect, vol)   # libtiff round-trips the samples
+    thr = float(np.median(vol))
+    got = oia.TiffReader(str(p)).threshold(thr)
+    assert np.array_equal(got, (vol.astype(np.float64) > thr).astype(np.uint8)) and 0 < got.mean() < 1
+
+
 def test_tiff_reader_rejects_what_it_cannot_decode(tmp_path):
     Image = _pil()
     a = (np.arange(64 * 64) % 256).astype(np.uint8).reshape(64, 64)

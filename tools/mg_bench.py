@@ -9,13 +9,17 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--structure", default="spheres")
 ap.add_argument("--nu", default="1", help="comma-separated mg_nu_coarse values, alternated")
 ap.add_argument("--wmask", default="-1", help="comma-separated mg_wmask values (-1 = default)")
+ap.add_argument("--zchunk", default="0", help="comma-separated z-chunk lengths of the marching kernels (0 = automatic)")
+ap.add_argument("--scale", default="0", help="comma-separated mg_scale values (0 = default 1.5)")
 a = ap.parse_args()
 n = a.size
 buf, desc = bench.make_structure(oia, a, (n, n, n), 0, n)
-for rep in range(3 * len(a.nu.split(",")) * len(a.wmask.split(","))):
-    nu = int(a.nu.split(",")[rep % len(a.nu.split(","))])
-    wm = int(a.wmask.split(",")[(rep // len(a.nu.split(","))) % len(a.wmask.split(","))])
-    oia.set_option("mg_nu_coarse", nu); oia.set_option("mg_wmask", wm)
+import itertools
+combos = list(itertools.product(a.nu.split(","), a.wmask.split(","), a.zchunk.split(","), a.scale.split(",")))
+for rep in range(2 * len(combos)):
+    nu, wm, zc, sc = combos[rep % len(combos)]
+    nu, wm, zc, sc = int(nu), int(wm), int(zc), float(sc)
+    oia.set_option("mg_nu_coarse", nu); oia.set_option("mg_wmask", wm); oia.set_option("zchunk", zc); oia.set_option("mg_scale", sc)
     tm = oia.TortuosityMI355(buf, 1, oia.Direction.X, 0.0, 1.0, shape=(n, n, n), eps=1e-6, precond=oia.PRECOND_MG, profile=1, maxiter=1000)
     t0 = time.perf_counter()
     tm.cg_begin()
@@ -26,6 +30,6 @@ for rep in range(3 * len(a.nu.split(",")) * len(a.wmask.split(","))):
     tm.cg_finish()
     dt = time.perf_counter() - t0
     mk = tm.kernel_times()
-    print(f"nu_coarse {nu} wmask {wm} solve {rep}: {its} iterations, relres {rel:.3e}, {dt:.3f} s,",
+    print(f"nu_coarse {nu} wmask {wm} zchunk {zc} scale {sc} solve {rep}: {its} iterations, relres {rel:.3e}, {dt:.3f} s,",
           {k: round(v[0] / max(1, v[1]), 3) for k, v in mk.items() if v[1]}, flush=True)
     tm.destroy()
