@@ -8,9 +8,10 @@
 // B-tree + local heap) and new-style groups with compact link messages, contiguous, compact and chunked layouts --
 // layout message v3 (v1 chunk B-tree) and v4 (what libver = latest writes since HDF5 1.10: single-chunk, implicit,
 // fixed-array and extensible-array chunk indexes, plain and filtered entries, paged data blocks) --, optional deflate /
-// shuffle filters (zlib).  Reported as unsupported, never guessed: groups with dense link storage (fractal heap: more
-// than eight links unless the writer changed the threshold), version-2 B-tree chunk indexes (datasets with two or
-// more unlimited dimensions), virtual datasets, other filters.  Metadata checksums are not verified.
+// shuffle filters (zlib); groups with dense link storage (fractal heap + version-2 B-tree name index) and the version-2
+// B-tree chunk index of datasets with two or more unlimited dimensions.  Reported as unsupported, never guessed: virtual
+// datasets, other filters, filtered fractal heaps, link names stored as tiny / huge heap objects.  Metadata checksums are
+// not verified.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -56,7 +57,9 @@ struct Mapped {
     return true;
   }
   size_t size() const { return n; }
-  const uint8_t& operator[](size_t i) const { return p[i]; }
+  // every byte access is bounded by the mapping: a truncated or crafted header near the end of the file reads zeros, not
+  // the pages behind the map (the callers' own range checks then reject what the zeros decode to)
+  const uint8_t& operator[](size_t i) const { static const uint8_t zero = 0; return i < n ? p[i] : zero; }
 };
 
 struct H5 {
@@ -181,39 +184,223 @@ bool group_lookup(const H5& h, uint64_t btree, uint64_t heap, const std::string&
   return false;
 }
 
+// ---- version-2 B-tree ("BTHD" / "BTIN" / "BTLF", format specification III.A.2): every record of the tree, in order ----
+// Used for the name index of a group with dense link storage (record type 5) and for the chunk index of a dataset with two
+// or more unlimited dimensions (record types 10 and 11).  fn(record offset in the file) returns false to stop early.
+int limit_enc_size(uint64_t limit) {  // bytes that hold any value up to `limit` (H5VM_limit_enc_size)
+  int bits = 0;
+  while (limit >>= 1) ++bits;
+  return bits / 8 + 1;
+}
+struct BTree2 {
+  int type = 0, depth = 0;
+  uint64_t node_size = 0, rec_size = 0, root = kUndef, root_nrec = 0, total = 0;
+  int max_nrec_size = 0;
+  std::vector<uint64_t> cum_max_nrec;  // per level (0 = leaf): most records a subtree rooted there can hold
+};
+bool btree2_open(const H5& h, uint64_t hdr, BTree2& t, std::string& why) {
+  if (!h.ok(hdr, 16 + (uint64_t)h.so + 2 + h.sl + 4) || memcmp(&h.f[hdr], "BTHD", 4) != 0 || h.f[hdr + 4] != 0) { why = "bad version-2 B-tree header"; return false; }
+  t.type = h.f[hdr + 5];
+  t.node_size = h.le(hdr + 6, 4);
+  t.rec_size = h.le(hdr + 10, 2);
+  t.depth = (int)h.le(hdr + 12, 2);
+  t.root = h.le(hdr + 16, h.so);
+  t.root_nrec = h.le(hdr + 16 + h.so, 2);
+  t.total = h.le(hdr + 18 + h.so, h.sl);
+  if (t.rec_size == 0 || t.node_size < 16 || t.node_size > (1u << 26) || t.depth > 16) { why = "version-2 B-tree header out of range"; return false; }
+  const uint64_t leaf_max = (t.node_size - 10) / t.rec_size;
+  t.max_nrec_size = limit_enc_size(leaf_max);
+  t.cum_max_nrec.assign(1, leaf_max);
+  for (int u = 1; u <= t.depth; ++u) {
+    const uint64_t ptr = (uint64_t)h.so + t.max_nrec_size + (u > 1 ? limit_enc_size(t.cum_max_nrec[u - 1]) : 0);
+    if (t.node_size < 10 + ptr) { why = "version-2 B-tree node too small"; return false; }
+    const uint64_t mx = (t.node_size - (10 + ptr)) / (t.rec_size + ptr);
+    t.cum_max_nrec.push_back((mx + 1) * t.cum_max_nrec[u - 1] + mx);
+  }
+  return true;
+}
+template <typename F>
+bool btree2_walk(const H5& h, const BTree2& t, uint64_t node, uint64_t nrec, int level, F&& fn, std::string& why, uint64_t& budget) {
+  if (node == kUndef || nrec == 0) return true;
+  const uint64_t a = h.base + node;
+  if (budget-- == 0 || !h.ok(a, t.node_size) || h.f[a + 4] != 0 || h.f[a + 5] != t.type || nrec * t.rec_size + 10 > t.node_size) { why = "corrupt version-2 B-tree node"; return false; }
+  if (level == 0) {
+    if (memcmp(&h.f[a], "BTLF", 4) != 0) { why = "corrupt version-2 B-tree leaf"; return false; }
+    for (uint64_t r = 0; r < nrec; ++r)
+      if (!fn(a + 6 + r * t.rec_size)) return false;
+    return true;
+  }
+  if (memcmp(&h.f[a], "BTIN", 4) != 0) { why = "corrupt version-2 B-tree internal node"; return false; }
+  const int tot_size = level > 1 ? limit_enc_size(t.cum_max_nrec[level - 1]) : 0;
+  const uint64_t ptr = (uint64_t)h.so + t.max_nrec_size + tot_size;
+  uint64_t q = a + 6 + nrec * t.rec_size;  // child pointers follow the records
+  if (q + (nrec + 1) * ptr + 4 > a + t.node_size) { why = "corrupt version-2 B-tree internal node"; return false; }
+  for (uint64_t c = 0; c <= nrec; ++c, q += ptr) {  // in-order: child c, record c, child c + 1, ...
+    if (!btree2_walk(h, t, h.le(q, h.so), h.le(q + h.so, t.max_nrec_size), level - 1, fn, why, budget)) return false;
+    if (c < nrec && !fn(a + 6 + c * t.rec_size)) return false;
+  }
+  return true;
+}
+template <typename F>
+bool btree2_for_each(const H5& h, uint64_t hdr, int want_type_a, int want_type_b, F&& fn, std::string& why) {
+  BTree2 t;
+  if (!btree2_open(h, hdr, t, why)) return false;
+  if (t.type != want_type_a && t.type != want_type_b) { why = "version-2 B-tree of type " + std::to_string(t.type) + " where another was expected"; return false; }
+  uint64_t budget = 1u << 22;  // nodes
+  return btree2_walk(h, t, t.root, t.root_nrec, t.depth, fn, why, budget);
+}
+
+// ---- fractal heap ("FRHP" / "FHIB" / "FHDB", format specification III.G): the bytes of a MANAGED object by its heap ID ----
+// (the link messages of a group with dense storage; tiny and huge objects -- link names beyond the managed-object limit --
+// and filtered heaps are reported, not read)
+struct FHeap {
+  uint64_t hdr = 0;
+  int id_len = 0, off_bytes = 0, len_bytes = 0;
+  unsigned flags = 0;
+  uint64_t width = 0, start_size = 0, max_direct = 0, root = kUndef;
+  int max_heap_bits = 0, root_rows = 0;
+  uint64_t dblock_hdr = 0;  // bytes in front of a direct block's data
+};
+int log2u(uint64_t v) { int b = 0; while (v >>= 1) ++b; return b; }
+bool fheap_open(const H5& h, uint64_t hdr, FHeap& fh, std::string& why) {
+  const uint64_t need = 4 + 1 + 2 + 2 + 1 + 4 + 12ULL * h.sl + 3ULL * h.so + 2 + 2 + 2 + 2 + 4;
+  if (!h.ok(hdr, need) || memcmp(&h.f[hdr], "FRHP", 4) != 0 || h.f[hdr + 4] != 0) { why = "bad fractal heap header"; return false; }
+  fh.hdr = hdr;
+  fh.id_len = (int)h.le(hdr + 5, 2);
+  const uint64_t filt_len = h.le(hdr + 7, 2);
+  fh.flags = h.f[hdr + 9];
+  const uint64_t max_managed = h.le(hdr + 10, 4);
+  uint64_t q = hdr + 14;
+  q += h.sl;            // next huge object ID
+  q += h.so;            // v2 B-tree of huge objects
+  q += h.sl;            // free space in managed blocks
+  q += h.so;            // managed block free-space manager
+  q += 4ULL * h.sl;     // managed space, allocated managed space, iterator offset, number of managed objects
+  q += 4ULL * h.sl;     // huge size / number, tiny size / number
+  fh.width = h.le(q, 2); q += 2;
+  fh.start_size = h.le(q, h.sl); q += h.sl;
+  fh.max_direct = h.le(q, h.sl); q += h.sl;
+  fh.max_heap_bits = (int)h.le(q, 2); q += 2;
+  q += 2;               // starting rows of the root indirect block
+  fh.root = h.le(q, h.so); q += h.so;
+  fh.root_rows = (int)h.le(q, 2);
+  if (filt_len) { why = "filtered fractal heap (a group with compressed link storage)"; return false; }
+  if (fh.width == 0 || fh.start_size == 0 || (fh.start_size & (fh.start_size - 1)) || (fh.max_direct & (fh.max_direct - 1)) || fh.max_heap_bits < 8 ||
+      fh.max_heap_bits > 64 || fh.max_direct < fh.start_size) { why = "fractal heap header out of range"; return false; }
+  fh.off_bytes = (fh.max_heap_bits + 7) / 8;
+  fh.len_bytes = std::min(limit_enc_size(fh.max_direct), limit_enc_size(max_managed));  // (H5HF_hdr_finish_init: the smaller encoding)
+  fh.dblock_hdr = 5 + (uint64_t)h.so + fh.off_bytes + ((fh.flags & 0x02) ? 4 : 0);
+  return true;
+}
+// size of the blocks of row r of a doubling table, and the heap offset its first block starts at
+uint64_t fh_row_size(const FHeap& fh, int r) { return r < 2 ? fh.start_size : fh.start_size << (r - 1); }
+// file address of the direct block that holds heap offset `off` (kUndef: not allocated), walking indirect blocks
+bool fheap_locate(const H5& h, const FHeap& fh, uint64_t iblock, int nrows, uint64_t iblock_off, uint64_t off, uint64_t& dblock, uint64_t& dblock_off,
+                  uint64_t& dblock_size, std::string& why, int depth = 0) {
+  const uint64_t a = h.base + iblock;
+  if (depth > 8 || !h.ok(a, 5 + (uint64_t)h.so + fh.off_bytes) || memcmp(&h.f[a], "FHIB", 4) != 0) { why = "corrupt fractal heap indirect block"; return false; }
+  const int max_direct_rows = log2u(fh.max_direct) - log2u(fh.start_size) + 2;
+  uint64_t q = a + 5 + h.so + fh.off_bytes, cur = iblock_off;
+  for (int r = 0; r < nrows; ++r) {
+    const uint64_t bs = fh_row_size(fh, r);
+    for (uint64_t c = 0; c < fh.width; ++c, cur += bs, q += h.so) {
+      if (!h.ok(q, h.so)) { why = "corrupt fractal heap indirect block"; return false; }
+      if (off < cur || off >= cur + bs) continue;
+      const uint64_t child = h.le(q, h.so);
+      if (child == kUndef || (h.so < 8 && child == (1ULL << (8 * h.so)) - 1)) { dblock = kUndef; return true; }
+      if (r < max_direct_rows) { dblock = child; dblock_off = cur; dblock_size = bs; return true; }
+      const int child_rows = log2u(bs) - (log2u(fh.start_size) + log2u(fh.width)) + 1;
+      return fheap_locate(h, fh, child, child_rows, cur, off, dblock, dblock_off, dblock_size, why, depth + 1);
+    }
+  }
+  dblock = kUndef;
+  return true;
+}
+// file offset and length of the managed object `id` (id_len bytes at file offset idp); false + why when it cannot be read
+bool fheap_object(const H5& h, const FHeap& fh, uint64_t idp, uint64_t& obj_off, uint64_t& obj_len, std::string& why) {
+  if (!h.ok(idp, (uint64_t)fh.id_len) || fh.id_len < 1 + fh.off_bytes + fh.len_bytes) { why = "fractal heap ID too short"; return false; }
+  const unsigned b0 = h.f[idp];
+  if ((b0 & 0xC0) != 0) { why = "fractal heap ID of an unknown version"; return false; }
+  if ((b0 & 0x30) != 0) { why = "tiny or huge fractal heap object (a link name beyond the managed-object limit)"; return false; }
+  const uint64_t off = h.le(idp + 1, fh.off_bytes), len = h.le(idp + 1 + fh.off_bytes, fh.len_bytes);
+  uint64_t dblock = kUndef, dboff = 0, dbsize = 0;
+  if (fh.root_rows == 0) { dblock = fh.root; dboff = 0; dbsize = fh.start_size; }
+  else if (!fheap_locate(h, fh, fh.root, fh.root_rows, 0, off, dblock, dboff, dbsize, why)) return false;
+  if (dblock == kUndef) { why = "fractal heap object in an unallocated block"; return false; }
+  const uint64_t a = h.base + dblock;
+  if (!h.ok(a, dbsize) || memcmp(&h.f[a], "FHDB", 4) != 0 || off < dboff + fh.dblock_hdr || off - dboff > dbsize || len > dbsize - (off - dboff)) {
+    why = "corrupt fractal heap direct block";
+    return false;
+  }
+  obj_off = a + (off - dboff);
+  obj_len = len;
+  return true;
+}
+
+// one Link message body at [o, o + n): does it name `name`?  1 = hard link found (obj_addr set), 0 = another name, -1 = `name` but not a
+// hard link (soft / external links are not followed)
+int link_message_matches(const H5& h, uint64_t o, uint64_t n, const std::string& name, uint64_t& obj_addr) {
+  if (n < 4 || h.f[o] != 1) return 0;
+  const uint64_t end = o + n;
+  const unsigned fl = h.f[o + 1];
+  uint64_t p = o + 2;
+  unsigned ltype = 0;
+  if (fl & 0x08) ltype = h.f[p++];
+  if (fl & 0x04) p += 8;  // creation order
+  if (fl & 0x10) p += 1;  // character set
+  const int lb = 1 << (fl & 3);
+  if (p + (uint64_t)lb > end) return 0;
+  const uint64_t nlen = h.le(p, lb);
+  p += lb;
+  if (nlen > end - p) return 0;
+  const bool match = nlen == name.size() && memcmp(&h.f[p], name.data(), (size_t)nlen) == 0;
+  p += nlen;
+  if (!match) return 0;
+  if (ltype == 0 && p + (uint64_t)h.so <= end) { obj_addr = h.base + h.le(p, h.so); return 1; }
+  return -1;
+}
+
+// a group with DENSE link storage (more than 8 links under libver = latest): the Link Info message names a fractal heap
+// that holds the link messages and a version-2 B-tree (type 5: hash of the name + heap ID) that indexes them by name.
+// Every record is visited (the name hash -- Jenkins lookup3 -- is not recomputed: the names themselves are compared).
+// 1 found, 0 not found, -1 cannot be read (why)
+int dense_link_lookup(const H5& h, uint64_t heap_addr, uint64_t btree_addr, const std::string& name, uint64_t& obj_addr, std::string& why) {
+  FHeap fh;
+  if (!fheap_open(h, h.base + heap_addr, fh, why)) return -1;
+  int found = 0;
+  bool bad = false;
+  const bool ok = btree2_for_each(h, h.base + btree_addr, 5, 5, [&](uint64_t rec) {
+    uint64_t o = 0, n = 0;
+    if (!fheap_object(h, fh, rec + 4, o, n, why)) { bad = true; return false; }
+    const int r = link_message_matches(h, o, n, name, obj_addr);
+    if (r != 0) { found = r > 0 ? 1 : 0; return false; }
+    return true;
+  }, why);
+  if (bad) return -1;
+  if (!ok && found == 0 && !why.empty()) return -1;
+  return found;
+}
+
 // new-style group: a hard link called `name` among the compact Link messages (type 6) of the group's object header.
-// returns 1 found, 0 not found, -1 the group keeps its links in a fractal heap (dense storage: not read)
-int link_lookup(const H5& h, const std::vector<Msg>& msgs, const std::string& name, uint64_t& obj_addr) {
-  bool dense = false;
+// returns 1 found, 0 not found, -1 the group's links cannot be read (why)
+int link_lookup(const H5& h, const std::vector<Msg>& msgs, const std::string& name, uint64_t& obj_addr, std::string& why) {
+  const uint64_t undef_so = h.so == 8 ? kUndef : ((1ULL << (8 * h.so)) - 1);
   for (const Msg& m : msgs) {
-    if (m.type == 0x0002 && m.size >= 2) {  // Link Info: is there a fractal heap?
+    if (m.type == 0x0002 && m.size >= 2) {  // Link Info: a fractal heap = dense storage (the links are NOT in the header then)
       const unsigned fl = h.f[m.off + 1];
       const uint64_t p = m.off + 2 + ((fl & 1) ? 8 : 0);
-      if (p + (uint64_t)h.so <= m.off + m.size && h.le(p, h.so) != (h.so == 8 ? kUndef : ((1ULL << (8 * h.so)) - 1))) dense = true;
+      if (p + 2ULL * h.so <= m.off + m.size && h.le(p, h.so) != undef_so) {
+        const uint64_t heap = h.le(p, h.so), bt = h.le(p + h.so, h.so);
+        if (bt == undef_so) { why = "dense link storage without a name index"; return -1; }
+        return dense_link_lookup(h, heap, bt, name, obj_addr, why);
+      }
     }
-    if (m.type != 0x0006 || m.size < 4) continue;
-    const uint64_t end = m.off + m.size;
-    if (h.f[m.off] != 1) continue;
-    const unsigned fl = h.f[m.off + 1];
-    uint64_t p = m.off + 2;
-    unsigned ltype = 0;
-    if (fl & 0x08) ltype = h.f[p++];
-    if (fl & 0x04) p += 8;  // creation order
-    if (fl & 0x10) p += 1;  // character set
-    const int lb = 1 << (fl & 3);
-    if (p + (uint64_t)lb > end) continue;
-    const uint64_t nlen = h.le(p, lb);
-    p += lb;
-    if (nlen > end - p) continue;
-    const bool match = nlen == name.size() && memcmp(&h.f[p], name.data(), (size_t)nlen) == 0;
-    p += nlen;
-    if (match && ltype == 0 && p + (uint64_t)h.so <= end) {
-      obj_addr = h.base + h.le(p, h.so);
-      return 1;
-    }
-    if (match) return 0;  // soft / external link: not followed
+    if (m.type != 0x0006) continue;
+    const int r = link_message_matches(h, m.off, m.size, name, obj_addr);
+    if (r > 0) return 1;
+    if (r < 0) return 0;  // soft / external link: not followed
   }
-  return dense ? -1 : 0;
+  return 0;
 }
 
 struct Dataset {
@@ -494,8 +681,29 @@ bool for_each_chunk_v4(const H5& h, const Dataset& d, uint64_t za, uint64_t zb, 
   }
   uint64_t plain = 1;
   for (int i = 0; i < d.chunk_rank; ++i) plain *= d.chunk_dims[i];
-  if (d.chunk_index == 5) { why = "version-2 B-tree chunk index (two or more unlimited dimensions) is not supported"; return false; }
   if (d.index_addr == kUndef) return true;  // nothing written yet
+  if (d.chunk_index == 5) {
+    // two or more unlimited dimensions: a version-2 B-tree whose records are the chunks themselves -- type 10: address +
+    // scaled offsets (8 bytes per dimension); type 11 (filtered): address, stored size, filter mask, scaled offsets
+    const bool filtered = d.f_deflate || d.f_shuffle || d.f_other;
+    int csl = 1 + (log2u(plain) + 8) / 8;  // bytes of the stored-size field (H5D_BT2_COMPUTE_CHUNK_SIZE_LEN)
+    if (csl > 8) csl = 8;
+    bool bad = false;
+    const bool ok = btree2_for_each(h, h.base + d.index_addr, 10, 11, [&](uint64_t rec) {
+      uint64_t q = rec;
+      ChunkEntry e;
+      e.addr = h.le(q, h.so); q += h.so;
+      e.nbytes = plain;
+      if (filtered) { e.nbytes = h.le(q, csl); q += csl + 4; }
+      uint64_t offs[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < nd; ++i, q += 8) offs[i] = h.le(q, 8) * d.chunk_dims[i];
+      if (e.addr == kUndef || (h.so < 8 && e.addr == (1ULL << (8 * h.so)) - 1)) return true;
+      if (offs[0] >= zb || offs[0] + d.chunk_dims[0] <= za) return true;  // no plane of [za, zb) in this chunk
+      if (!fn(offs, h.base + e.addr, e.nbytes)) { bad = true; return false; }
+      return true;
+    }, why);
+    return ok && !bad ? true : (bad ? false : (why.empty() ? true : false));
+  }
   EArray ea;
   if (d.chunk_index == 4 && !earray_open(h, h.base + d.index_addr, ea, why)) return false;
   // linear chunk index = row-major offset over the MAXIMAL chunk grid (H5VM_array_offset_pre with max_down_chunks); an
@@ -581,8 +789,9 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
     if (bt != kUndef) {
       if (!group_lookup(h, bt, hp, part, next)) { oi::set_error("'%s': no object '%s' (dataset '%s')", path, part.c_str(), dataset); return OI_IO_ERROR; }
     } else {
-      const int r = link_lookup(h, msgs, part, next);
-      if (r < 0) { oi::set_error("'%s': the group holding '%s' keeps its links in a fractal heap (dense storage), which this reader does not parse", path, part.c_str()); return OI_IO_ERROR; }
+      std::string lwhy;
+      const int r = link_lookup(h, msgs, part, next, lwhy);
+      if (r < 0) { oi::set_error("'%s': the group holding '%s' keeps its links in a fractal heap (dense storage) that cannot be read: %s", path, part.c_str(), lwhy.c_str()); return OI_IO_ERROR; }
       if (r == 0) { oi::set_error("'%s': no object '%s' (dataset '%s')", path, part.c_str(), dataset); return OI_IO_ERROR; }
     }
     obj = next;

@@ -54,18 +54,31 @@ int main(int argc, char** argv) {
   if (strstr(var, "tiny")) { chunk[0] = 1; chunk[1] = 4; chunk[2] = 5; H5Pset_chunk(dcpl, 3, chunk); }  /* many chunks: deep index structures */
   if (strstr(var, "shuf")) H5Pset_shuffle(dcpl);
   if (strstr(var, "gz")) H5Pset_deflate(dcpl, 4);
+  if (strstr(var, "unlim2tiny")) { chunk[0] = 1; chunk[1] = 2; chunk[2] = 5; H5Pset_chunk(dcpl, 3, chunk); }  /* thousands of B-tree records: internal nodes */
   if (strstr(var, "nested")) {
     hid_t g1 = H5Gcreate2(f, "g1", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     loc = H5Gcreate2(g1, "g2", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
   }
   if (strstr(var, "dense")) {  /* more links than the compact limit (8): the root group switches to a fractal heap */
-    for (int i = 0; i < 12; ++i) {
+    /* "densebig": enough links for a root indirect block and internal B-tree nodes; "dense_in_group": the dataset's own
+     * group (not the root) is the dense one */
+    const int nlinks = strstr(var, "densebig") ? 3000 : 12;
+    if (strstr(var, "dense_in_group")) {
+      hid_t g1 = H5Gcreate2(f, "g1", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+      loc = H5Gcreate2(g1, "g2", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    }
+    for (int i = 0; i < nlinks; ++i) {
       char nm[32];
-      snprintf(nm, sizeof nm, "other%02d", i);
-      hsize_t one = 1;
-      hid_t sp = H5Screate_simple(1, &one, NULL);
-      hid_t ds = H5Dcreate2(f, nm, H5T_NATIVE_INT, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-      H5Dclose(ds); H5Sclose(sp);
+      snprintf(nm, sizeof nm, i % 3 ? "other%02d" : "a_rather_longer_name_of_another_object_%05d", i);
+      if (nlinks > 100) {  /* groups: cheaper than datasets */
+        hid_t gg = H5Gcreate2(loc, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        H5Gclose(gg);
+      } else {
+        hsize_t one = 1;
+        hid_t sp = H5Screate_simple(1, &one, NULL);
+        hid_t ds = H5Dcreate2(loc, nm, H5T_NATIVE_INT, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        H5Dclose(ds); H5Sclose(sp);
+      }
     }
   }
   hid_t ftype = H5T_STD_U8LE, mtype = H5T_NATIVE_DOUBLE;

@@ -85,17 +85,27 @@ def test_corrupted_and_crafted_files_under_sanitizers(drivers, tmp_path):
         if subprocess.run(["gcc", "-O1", os.path.join(ROOT, "tests", "h5_libhdf5_writer.c"), "-I" + inc, "-L" + lib, "-lhdf5",
                            "-Wl,-rpath," + lib, "-o", w], capture_output=True).returncode == 0:
             srcs, good = [], []
-            for k, v in enumerate(("chunk_gz_shuf", "paged", "unlimz_tiny", "unlimx", "single_gz", "implicit", "nested_chunk")):
+            # (round 3: + the version-2 B-tree chunk index, dense groups: fractal heap, name index)
+            for k, v in enumerate(("chunk_gz_shuf", "paged", "unlimz_tiny", "unlimx", "single_gz", "implicit", "nested_chunk", "unlim2tiny_gz",
+                                   "unlim2", "dense_chunk", "densebig_chunk_gz")):
                 f = tmp_path / f"latest{k}.h5"
                 subprocess.run([w, str(f), v, "40", "40", "40", "u8"], check=True, timeout=120)
                 srcs.append(f.read_bytes())
                 if "nested" not in v:
                     good.append(str(f))
             lp = []
-            for t in range(140):
+            for t in range(220):
                 q = tmp_path / f"l{t}.h5"
                 q.write_bytes(bytes(corrupt(srcs[t % len(srcs)], t, rng)))
                 lp.append(str(q))
+            # files cut INSIDE the dataset's object header, message by message: the dataspace, datatype, layout and filter
+            # messages end at the end of the file (fixed-offset reads of a message body must stay inside the map)
+            for k, src in enumerate(srcs[:4]):
+                at = src.find(b"OHDR", src.find(b"OHDR") + 4)   # (the root group's header comes first)
+                for cut in range(at + 6, min(len(src), at + 200), 7):
+                    q = tmp_path / f"cut{k}_{cut}.h5"
+                    q.write_bytes(src[:cut])
+                    lp.append(str(q))
             out = run([reader, "hdf5", "image"] + good + lp)
             assert out.splitlines()[0].startswith("ok 40 40 40") and out.strip().endswith("batch done")
 
