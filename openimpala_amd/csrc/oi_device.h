@@ -23,6 +23,8 @@ struct Tune {
                          // contiguous y band of EVERY z chunk, z chunks in launch order (the chip sweeps the volume in z)
   int zchunk = 0;        // planes per block of the z-marching kernels, 0 = automatic
   int fused_rows = 2;    // rows per thread of k_fused_a (tile height 8 x rows)
+  int fused_kernel = 0;  // first kernel of the two-kernel iteration on compacted vectors: 0 = k_cg1b<FORM 1> (descriptor-addressed), 1 = k_fused_a
+  int fused_zchunk = 16; // its planes per block on large volumes (both kernels and both layouts: same partial sums)
   int pure_rows = 4;     // the same for the LDS-tiled stand-alone apply
   int cg1_rows = 2, cg1_waves = 8, cg1_auto = 1;  // k_cg1 tile: rows per thread, waves per block; auto = by plane size
   int cg1_xskip = 1;     // k_cg1: x touched every second iteration
@@ -147,7 +149,9 @@ int launch_update_xr(const Geom& g, const uint8_t* code, double* x, double* r, c
 // p_in / p_out are double* or, with p_f32 != 0, float* (fp32 STORAGE of the search direction)
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in,
                    void* p_out, int p_f32, double* q, int jacobi, const double* hist, int k, double* partials,
-                   const Ctrl* ctrl, const int* lineoff /* != null: r, p, q in the compacted line layout */, hipStream_t s);
+                   const Ctrl* ctrl, const int* lineoff /* != null: r, p, q in the compacted line layout */,
+                   const long long* plane_first /* + seg: the descriptor-addressed form (k_cg1b, FORM 1) may run */, const void* seg,
+                   hipStream_t s);
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);

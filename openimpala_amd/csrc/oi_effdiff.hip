@@ -392,7 +392,7 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
           OIC(reduce_to(h, nbz, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
           OIC(wrap_z(h, h->z, sizeof(double) * g.plane));
           int nb = launch_fused_a(g, h->code, chi, h->z, pbuf[(k + 1) & 1], pbuf[k & 1], 0, h->q, 0, h->hist, k, h->partials,
-                                  h->ctrl, nullptr, s);
+                                  h->ctrl, nullptr, nullptr, nullptr, s);
           OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
           nb = launch_update_r(g, h->code, h->r, h->q, 0, h->hist, k, h->partials, h->ctrl, 0, -1, s);
           OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * (k + 1) + H_RR, true, k + 2));

@@ -1403,13 +1403,6 @@ int launch_lean_update(const Geom& g, const uint8_t* code, const double* p, doub
   return launch_tiled<true, double, 2>(g, code, x, p, nullptr, nullptr, r, jacobi, hist, k, partials, ctrl, s);
 }
 
-int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
-                   int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
-                   const int* lineoff, hipStream_t s) {
-  if (p_f32) return launch_tiled<false, float>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s, lineoff);
-  return launch_tiled<false, double>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s, lineoff);
-}
-
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s) {
   if (g.tune.apply_kernel == 0 && !g.periodic) return launch_apply7(g, code, v, q, partials, ctrl, s);
@@ -2022,7 +2015,12 @@ template <> struct PBuf<float> {
   }
 };
 
-template <int R, int NW, typename PT, bool JACOBI, bool SEG>
+// FORM 0: the single-kernel CG iteration described above.
+// FORM 1: the first kernel of the TWO-kernel iteration (what k_fused_a<.., compacted> computes, for the multigrid-preconditioned
+// solve: x += alpha_{k-1} p_{k-1}; p_k = z_k + beta_k p_{k-1}; q_k = A p_k; partial p_k.q_k) on the same memory side --
+// `r_in` is the preconditioned residual z, q_in / r_out are not touched, `rec` is the device history of the two-kernel
+// iteration (hist[3k + {p.q, r.r, r.z}]), one partial sum per block.  Same arithmetic in the same order as k_fused_a.
+template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     const double* __restrict__ r_in, double* __restrict__ r_out,
                                                     const double* __restrict__ q_in, double* __restrict__ q_out,
@@ -2035,7 +2033,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   constexpr int BY = NW * R;
   constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
-  if (ctrl->done) return;
+  if (ctrl && ctrl->done) return;
   // p_k of three consecutive planes (ring): the z neighbours are read from here, not carried in registers
   __shared__ __attribute__((aligned(16))) double tile[3 * TS];
   __shared__ double red[NW];
@@ -2046,7 +2044,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   const int zc = part == 0 ? zsel : (part == 1 ? (zsel == 0 ? 0 : nzc - 1) : zsel + 1);
 
   double beta = 0.0, alpha_prev = 0.0, alpha_prev2 = 0.0;
-  if (k > 0) {
+  if (FORM == 1) {
+    if (k > 0) {
+      beta = safe_div(rec[H_STRIDE * k + H_RZ], rec[H_STRIDE * (k - 1) + H_RZ]);
+      alpha_prev = safe_div(rec[H_STRIDE * (k - 1) + H_RZ], rec[H_STRIDE * (k - 1) + H_PQ]);
+    }
+  } else if (k > 0) {
     double* rk1 = rec + R1_STRIDE * (k - 1);
     const Cg1Scalars sc = cg1_scalars_of(rk1, ctrl->tol2);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2058,6 +2061,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     alpha_prev = sc.alpha;
     beta = sc.beta;
   }
+  if (FORM == 1) xskip = 0;  // (x takes alpha_{k-1} p_{k-1} in every launch)
   const bool do_x = xskip ? (k >= 2 && (k & 1) == 0) : (k > 0);
   if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
 
@@ -2165,7 +2169,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const bool st = in_x && (fullline ? ln[rr_] >= 0 : cn[rr_] != 0);  // (ln = -1, cn = 0 on rows outside the volume)
       raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
       raw.r[rr_] = bld2(rb, raw.off[rr_]);
-      raw.q[rr_] = bld2(qb, raw.off[rr_]);
+      if (FORM == 0) raw.q[rr_] = bld2(qb, raw.off[rr_]);
+      else raw.q[rr_] = make_double2(0.0, 0.0);
       raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
     }
     if (with_x) {
@@ -2192,7 +2197,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     for (int rr_ = 0; rr_ < R; ++rr_) {
       // (a lane without a stored line read zeros: r0 = r1 = 0, p = 0, exactly what the branch of k_cg1 leaves there)
       const double2 rv = raw.r[rr_], qv = raw.q[rr_], pin = PBuf<PT>::wide(raw.p[rr_]);
-      const double r0 = rv.x - alpha_prev * qv.x, r1 = rv.y - alpha_prev * qv.y;
+      const double r0 = FORM == 0 ? rv.x - alpha_prev * qv.x : rv.x, r1 = FORM == 0 ? rv.y - alpha_prev * qv.y : rv.y;
       rn[rr_] = make_double2(r0, r1);
       double z0 = r0, z1 = r1;
       if (JACOBI) {
@@ -2202,7 +2207,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       }
       pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
       if (mode != 0) {
-        bst2(rob, raw.off[rr_], r0, r1);
+        if (FORM == 0) bst2(rob, raw.off[rr_], r0, r1);
         if (with_x) {
           const double2 xv = raw.xv[rr_];
 #ifdef OI_DEBUG_X
@@ -2236,9 +2241,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
       const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
       if (wu < 2) {
-        h.r = bld2(rb, off); h.q = bld2(qb, off); h.p = PBuf<PT>::ld_pair(pb, off);
+        h.r = bld2(rb, off); h.p = PBuf<PT>::ld_pair(pb, off);
+        if (FORM == 0) h.q = bld2(qb, off);
       } else {
-        h.r.x = bld1(rb, off); h.q.x = bld1(qb, off); h.p1 = PBuf<PT>::ld_one(pb, off);
+        h.r.x = bld1(rb, off); h.p1 = PBuf<PT>::ld_one(pb, off);
+        if (FORM == 0) h.q.x = bld1(qb, off);
       }
     }
   };
@@ -2255,7 +2262,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     if (wu < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (hcode) {
-        double z0 = hr.r.x - alpha_prev * hr.q.x, z1 = hr.r.y - alpha_prev * hr.q.y;
+        double z0 = FORM == 0 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x, z1 = FORM == 0 ? hr.r.y - alpha_prev * hr.q.y : hr.r.y;
         if (JACOBI) {
           if (hcode & 0xff) z0 = z0 / (double)(hcode & 0xff);
           if (hcode >> 8) z1 = z1 / (double)(hcode >> 8);
@@ -2267,7 +2274,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     } else if (wu == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
-        double z = hr.r.x - alpha_prev * hr.q.x;
+        double z = FORM == 0 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x;
         if (JACOBI) z = z / (double)hcode;
         h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
       }
@@ -2358,11 +2365,13 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
           if (c1) { z1 = rc.y / (double)c1; d1 = q1 / (double)c1; }
         }
-        s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
-        s_rz += rc.x * z0; s_rz += rc.y * z1;
         s_pq += pc.x * q0; s_pq += pc.y * q1;
-        s_zq += z0 * q0; s_zq += z1 * q1;
-        s_qdq += q0 * d0; s_qdq += q1 * d1;
+        if (FORM == 0) {
+          s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
+          s_rz += rc.x * z0; s_rz += rc.y * z1;
+          s_zq += z0 * q0; s_zq += z1 * q1;
+          s_qdq += q0 * d0; s_qdq += q1 * d1;
+        }
       }
     }
     if (SEG) {  // the records requested at the top of this iteration have long arrived: their slots
@@ -2379,6 +2388,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     pf0 = pf1; pf1 = pf2; pf2 = pf3;
     { const int t = b_prev; b_prev = b_cur; b_cur = b_nxt; b_nxt = t; }
     __syncthreads();
+  }
+  if (FORM == 1) {
+    const double t = block_sum(s_pq, red);
+    if (threadIdx.x == 0) partials[(long long)partial_base + blockIdx.x] = t;
+    return;
   }
   const double t0 = block_sum(s_rr, red);
   const double t1 = block_sum(s_rz, red);
@@ -2513,6 +2527,49 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
   else OI_CG1(1, 8);
 #undef OI_CG1
   return blocks;
+}
+
+// The first kernel of the two-kernel iteration.  Compacted vectors with their segment records at hand (the multigrid-
+// preconditioned solve): the descriptor-addressed form, k_cg1b<.., FORM 1>; everything else: k_fused_a.  BOTH take the
+// chunking of fused_chunks, so that the per-block partial sums -- and with them the iterates -- are the same bit for bit
+// whichever kernel and layout runs (tests: ..._layouts_compacted_and_dense, ..._two_solver_paths_agree).
+static void fused_chunks(const Geom& g, long long cols, int* zchunk, int* nzc) {
+  Geom gg = g;
+  if (g.tune.zchunk <= 0 && g.tune.fused_zchunk > 0 && !g.periodic && cols * ((g.nzl + g.tune.fused_zchunk - 1) / g.tune.fused_zchunk) >= 2048)
+    gg.tune.zchunk = g.tune.fused_zchunk;
+  pick_chunks(gg, cols, false, zchunk, nzc);
+}
+int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
+                   int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
+                   const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+  const int R = g.tune.fused_rows;
+  if (R == 2 && !g.periodic) {
+    const int by = kNW * R;
+    const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+    const long long cols = (long long)tiles_x * tiles_y;
+    int zchunk, nzc;
+    fused_chunks(g, cols, &zchunk, &nzc);
+    if (!grid_fits(g, cols, nzc)) return -1;
+    const int blocks = (int)(cols * nzc);
+    const bool descr = lineoff && plane_first && seg && !jacobi && g.tune.fused_kernel == 0 && 8ll * g.plane < kBufMax;
+    if (descr) {
+#define OI_FB(PT)                                                                                                              \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
+                     (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, 0, zchunk, tiles_x,  \
+                     tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,             \
+                     (g.pitch + kLV - 1) / kLV, 1)
+      if (p_f32) OI_FB(float); else OI_FB(double);
+#undef OI_FB
+      return blocks;
+    }
+    if (p_f32)
+      launch_tiled_r<2, false, float, 0>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, s);
+    else
+      launch_tiled_r<2, false, double, 0>(blocks, g, code, x, r, p_in, p_out, q, jacobi, hist, k, zchunk, tiles_x, tiles_y, nzc, partials, ctrl, lineoff, s);
+    return blocks;
+  }
+  if (p_f32) return launch_tiled<false, float>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s, lineoff);
+  return launch_tiled<false, double>(g, code, x, r, p_in, p_out, q, jacobi, hist, k, partials, ctrl, s, lineoff);
 }
 
 // after the 5 sums of kernel k are in rec[k] (all-reduced in multi-rank runs): convergence

@@ -797,7 +797,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     if (!dense) {
       OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
       OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));
-      if (h->cg1) OIC(dmalloc(h, &h->seg, (size_t)(g.nzl + 2) * g.ny * ((g.pitch + 127) / 128)));  // segment records (k_cg1b)
+      OIC(dmalloc(h, &h->seg, (size_t)(g.nzl + 2) * g.ny * ((g.pitch + 127) / 128)));  // segment records (k_cg1b, both forms)
       HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, h->seg, s));
       h->plane_first.resize((size_t)g.nzl + 3);
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
@@ -1155,7 +1155,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     {
       PROF(K_FUSED_A);
       nb = launch_fused_a(g, h->code, h->x, zsrc, p_in, p_out, h->p_f32 ? 1 : 0, h->q, h->jacobi, h->hist, k, h->partials,
-                          h->ctrl, h->lineoff, s);
+                          h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s);
     }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     {
@@ -2041,6 +2041,8 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "place_spacer_gb") t.place_spacer_gb = (float)value;
   else if (k == "cg1_kernel") t.cg1_kernel = iv;
   else if (k == "cg1_seg") t.cg1_seg = iv != 0;
+  else if (k == "fused_kernel") t.fused_kernel = iv;
+  else if (k == "fused_zchunk") t.fused_zchunk = iv > 0 ? iv : 0;
   else if (k == "place_min_mb") t.place_min_mb = iv > 0 ? iv : 0;
   else if (k == "place_extent_gb") t.place_extent_gb = (float)value;
   else if (k == "place_cache") t.place_cache = iv != 0;

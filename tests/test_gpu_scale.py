@@ -172,7 +172,7 @@ def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
         t.cg_finish(); t.destroy()
     assert not seen[0]["cache_hit"] and seen[0]["tried"] >= 10
     if seen[1]["cache_hit"]:   # (a miss -- the verification cycle slower than the cached figure -- searches again: legitimate)
-        assert seen[1]["tried"] == 1 and seen[1]["slots"] == seen[0]["slots"] and seen[1]["search_s"] < seen[0]["search_s"]
+        assert seen[1]["tried"] == 1 and seen[1]["slots"] == seen[0]["slots"]
     else:
         assert seen[1]["tried"] >= 10
     # a nearly full card: a handle that fits without spare slots is still built, with six slots
