@@ -24,6 +24,7 @@ struct Tune {
   int zchunk = 0;        // planes per block of the z-marching kernels, 0 = automatic
   int fused_rows = 2;    // rows per thread of k_fused_a (tile height 8 x rows)
   int fused_kernel = 0;  // first kernel of the two-kernel iteration on compacted vectors: 0 = k_cg1b<FORM 1> (descriptor-addressed), 1 = k_fused_a
+  int mg_norot = 0;      // 1: keep k_update_r_lines + the pre-smoother as two kernels (cross-check of the rotated iteration)
   int fused_zchunk = 16; // its planes per block on large volumes (both kernels and both layouts: same partial sums)
   int pure_rows = 4;     // the same for the LDS-tiled stand-alone apply
   int cg1_rows = 2, cg1_waves = 8, cg1_auto = 1;  // k_cg1 tile: rows per thread, waves per block; auto = by plane size
@@ -178,6 +179,12 @@ struct MgCoarse {
   long long csz;
   int cnzl = 0, periodic = 0;  // owned coarse planes; 1 = periodic cell problem (plain fine kernels only)
 };
+// the two-kernel iteration on compacted vectors, descriptor-addressed forms (k_cg1b FORM 1 / 2): may they run on this slab?
+bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi);
+// residual update + fine pre-smoother + restriction in one pass (k_cg1b FORM 2); see oi_kernels.hip
+int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in, double* r_out, const double* q, const double* hist, int k,
+                         MgCoarse c, float* bcoarse, double omega, double* partials, const Ctrl* ctrl, const int* lineoff,
+                         const long long* plane_first, const void* seg, hipStream_t s);
 // fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
 // (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)

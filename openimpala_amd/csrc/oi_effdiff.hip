@@ -311,13 +311,18 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
     size_t mg_bytes = 0;
     h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);
     if (!h->mg) return OI_HIP_ERROR;
-    // even extents: pairs and aggregates never straddle the periodic seam, the LDS-tiled kernels of the flow-through
-    // path wrap x / y by index -> their fused two-kernel iteration (needs a second p buffer)
-    h->fused = ((nx | ny | nz) & 1) == 0 && !g.tune.mg_plain;
-    if (h->fused) {
-      HIPC(hipMalloc((void**)&h->p2, sizeof(double) * g.nvec));
-      HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * g.nvec, s));
-    }
+    // even nx: a thread's x pair never straddles the periodic seam, the LDS-tiled kernels of the flow-through path wrap
+    // x / y by index -> their fused two-kernel iteration (needs a second p buffer).  Odd ny / nz are fine (round 3: the
+    // coarse parent of the image planes beyond an odd nz is the coarse ghost plane, cplane_of in k_mg_fine)
+    h->fused = (nx & 1) == 0 && !g.tune.mg_plain;
+  } else if (h->n_active > 0 && (nx & 1) == 0 && nx >= 4 && ny >= 2 && !g.tune.mg_plain) {
+    // plain CG (precond = none / jacobi is not offered here): the same two-kernel iteration with z = r.  Only x must be
+    // even (a thread owns an x pair, which must not straddle the seam); y and z wrap by row / through the ghost planes
+    h->fused = true;
+  }
+  if (h->fused) {
+    HIPC(hipMalloc((void**)&h->p2, sizeof(double) * g.nvec));
+    HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * g.nvec, s));
   }
   *out = h.release();
   return OI_OK;
@@ -387,11 +392,15 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
           // z = M^-1 r; p_k = z + beta p_{k-1}, q = A p_k, p.q, chi += alpha_{k-1} p_{k-1}; r -= alpha q
           double* pbuf[2] = {h->p, h->p2};
           OIC(wrap_z(h, h->r, sizeof(double) * g.plane));
-          const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, 1, nullptr, s);
-          if (nbz < 0) return OI_RCCL_ERROR;
-          OIC(reduce_to(h, nbz, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
-          OIC(wrap_z(h, h->z, sizeof(double) * g.plane));
-          int nb = launch_fused_a(g, h->code, chi, h->z, pbuf[(k + 1) & 1], pbuf[k & 1], 0, h->q, 0, h->hist, k, h->partials,
+          const double* zsrc = h->r;  // plain CG: z = r, and r.z = r.r is already in hist[k] (k_ed_rhs / launch_update_r)
+          if (h->mg) {
+            const int nbz = oi::mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, 1, nullptr, s);
+            if (nbz < 0) return OI_RCCL_ERROR;
+            OIC(reduce_to(h, nbz, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+            OIC(wrap_z(h, h->z, sizeof(double) * g.plane));
+            zsrc = h->z;
+          }
+          int nb = launch_fused_a(g, h->code, chi, zsrc, pbuf[(k + 1) & 1], pbuf[k & 1], 0, h->q, 0, h->hist, k, h->partials,
                                   h->ctrl, nullptr, nullptr, nullptr, s);
           OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
           nb = launch_update_r(g, h->code, h->r, h->q, 0, h->hist, k, h->partials, h->ctrl, 0, -1, s);

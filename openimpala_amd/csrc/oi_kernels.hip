@@ -1462,8 +1462,16 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
   // v at one voxel (the pad column and the ghost planes beyond the domain hold code 0, so the coarse
   // correction is never indexed for them; ghost planes of a neighbour slab map to its ghost coarse plane)
   // scaled coarse correction of the aggregate that holds voxel (ii, jj, gz)
+  // coarse plane (local, ghosts 0 and cnzl + 1) of the aggregate that holds fine plane gz; periodic problem: the planes
+  // beyond the two ends are images whose parents sit in the coarse GHOST planes (an odd nz does not give that by itself)
+  auto cplane_of = [&](int gz) -> int {
+    const int kg = g.z0 + gz - 1;
+    if (C.periodic && kg >= g.nz) return C.cnzl + 1;
+    if (C.periodic && kg < 0) return 0;
+    return (kg >> 1) - C.z0c + 1;
+  };
   auto corr_at = [&](int ii, int jj, int gz) -> double {
-    const long long cm = (long long)(ii >> 1) + (long long)C.cnx * (jj >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+    const long long cm = (long long)(ii >> 1) + (long long)C.cnx * (jj >> 1) + C.csz * cplane_of(gz);
     float cv = C.xc[cm];
     if (C.xc2) cv += C.xc2[cm];
     return scale * (double)cv;
@@ -1499,7 +1507,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         if (COMPACT ? ln[rr_] >= 0 : dense_live) {  // b and the output vanish on non-free voxels: lines without one are not moved
           braw[rr_] = ld2(b + (COMPACT ? (long long)kLV * ln[rr_] + (i & (kLV - 1)) : e));
           if (MODE == 2 && cc) {  // voxels i and i + 1 share their aggregate (i is even)
-            const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * (((g.z0 + gz - 1) >> 1) - C.z0c + 1);
+            const long long cm = (long long)(i >> 1) + (long long)C.cnx * (j >> 1) + C.csz * cplane_of(gz);
             float cv = C.xc[cm];
             if (C.xc2) cv += C.xc2[cm];
             craw[rr_] = cv;
@@ -2020,6 +2028,11 @@ template <> struct PBuf<float> {
 // solve: x += alpha_{k-1} p_{k-1}; p_k = z_k + beta_k p_{k-1}; q_k = A p_k; partial p_k.q_k) on the same memory side --
 // `r_in` is the preconditioned residual z, q_in / r_out are not touched, `rec` is the device history of the two-kernel
 // iteration (hist[3k + {p.q, r.r, r.z}]), one partial sum per block.  Same arithmetic in the same order as k_fused_a.
+// FORM 2: the residual update of the two-kernel iteration FUSED with the fine-level pre-smoother and the restriction of the
+// multigrid cycle (k_update_r_lines + k_mg_fine MODE 3 in one pass): r_k = r_{k-1} - alpha_{k-1} q_{k-1} (read from r_in / q_in,
+// stored to r_out -- double-buffered, the halo ring recomputes it from the inputs), partial r_k.r_k, v = omega r_k / c staged,
+// res = r_k - A v, and the 2x2x2 block sums of res as the fp32 right-hand side of the first coarse level (`bcoarse`, `C`).
+// Chunks hold whole z pairs (even first plane, even length).  Same arithmetic in the same order as the two kernels it replaces.
 template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     const double* __restrict__ r_in, double* __restrict__ r_out,
@@ -2029,7 +2042,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
                                                     int tiles_x, int tiles_y, int nzc, int part, int partial_base,
                                                     double* __restrict__ partials, Ctrl* ctrl,
                                                     const int* __restrict__ lineoff, const long long* __restrict__ plane_first,
-                                                    const uint2* __restrict__ seg, int LW, int fullline) {
+                                                    const uint2* __restrict__ seg, int LW, int fullline,
+                                                    float* __restrict__ bcoarse, MgCoarse C, double omega) {
   constexpr int BY = NW * R;
   constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
@@ -2037,6 +2051,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   // p_k of three consecutive planes (ring): the z neighbours are read from here, not carried in registers
   __shared__ __attribute__((aligned(16))) double tile[3 * TS];
   __shared__ double red[NW];
+  // FORM 2: y-pair sums of the restriction (odd waves publish, even waves own the aggregates), omega / c for c = 0..6
+  __shared__ double ysum[FORM == 2 ? 2 : 1][FORM == 2 ? R * (NW / 2) * 64 : 1];
+  __shared__ double wtab[8];
+  if (FORM == 2) {
+    static_assert(FORM != 2 || (NW & 1) == 0, "rows 2m and 2m+1 of a tile belong to waves w and w+1");
+    if (threadIdx.x < 8) wtab[threadIdx.x] = threadIdx.x ? omega / (double)threadIdx.x : 0.0;
+    __syncthreads();
+  }
 
   const int nsel = part == 0 ? nzc : (part == 1 ? min(2, nzc) : nzc - 2);
   const int L = tile_of_block(blockIdx.x, tiles_x * tiles_y, nsel, g.tune.tile_map);
@@ -2049,6 +2071,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       beta = safe_div(rec[H_STRIDE * k + H_RZ], rec[H_STRIDE * (k - 1) + H_RZ]);
       alpha_prev = safe_div(rec[H_STRIDE * (k - 1) + H_RZ], rec[H_STRIDE * (k - 1) + H_PQ]);
     }
+  } else if (FORM == 2) {
+    if (k > 0) alpha_prev = safe_div(rec[H_STRIDE * (k - 1) + H_RZ], rec[H_STRIDE * (k - 1) + H_PQ]);
   } else if (k > 0) {
     double* rk1 = rec + R1_STRIDE * (k - 1);
     const Cg1Scalars sc = cg1_scalars_of(rk1, ctrl->tol2);
@@ -2061,8 +2085,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     alpha_prev = sc.alpha;
     beta = sc.beta;
   }
-  if (FORM == 1) xskip = 0;  // (x takes alpha_{k-1} p_{k-1} in every launch)
-  const bool do_x = xskip ? (k >= 2 && (k & 1) == 0) : (k > 0);
+  if (FORM != 0) xskip = 0;  // (FORM 1: x takes alpha_{k-1} p_{k-1} in every launch)
+  const bool do_x = FORM == 2 ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
   if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
 
   const int lane = threadIdx.x & 63;
@@ -2169,9 +2193,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const bool st = in_x && (fullline ? ln[rr_] >= 0 : cn[rr_] != 0);  // (ln = -1, cn = 0 on rows outside the volume)
       raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
       raw.r[rr_] = bld2(rb, raw.off[rr_]);
-      if (FORM == 0) raw.q[rr_] = bld2(qb, raw.off[rr_]);
+      if (FORM != 1) raw.q[rr_] = bld2(qb, raw.off[rr_]);
       else raw.q[rr_] = make_double2(0.0, 0.0);
-      raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
+      if (FORM != 2) raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
+      else raw.p[rr_] = PPair();
     }
     if (with_x) {
       const __amdgpu_buffer_rsrc_t xb = x_buf(p);
@@ -2197,8 +2222,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     for (int rr_ = 0; rr_ < R; ++rr_) {
       // (a lane without a stored line read zeros: r0 = r1 = 0, p = 0, exactly what the branch of k_cg1 leaves there)
       const double2 rv = raw.r[rr_], qv = raw.q[rr_], pin = PBuf<PT>::wide(raw.p[rr_]);
-      const double r0 = FORM == 0 ? rv.x - alpha_prev * qv.x : rv.x, r1 = FORM == 0 ? rv.y - alpha_prev * qv.y : rv.y;
+      const double r0 = FORM != 1 ? rv.x - alpha_prev * qv.x : rv.x, r1 = FORM != 1 ? rv.y - alpha_prev * qv.y : rv.y;
       rn[rr_] = make_double2(r0, r1);
+      if (FORM == 2) {  // what is staged is the first damped-Jacobi iterate v = omega r / c of the new residual
+        const unsigned short cc = cn[rr_];
+        pn[rr_] = make_double2(r0 * wtab[cc & 0xffu], r1 * wtab[cc >> 8]);
+        if (mode != 0) bst2(rob, raw.off[rr_], r0, r1);
+        continue;
+      }
       double z0 = r0, z1 = r1;
       if (JACOBI) {
         const unsigned short cc = cn[rr_];
@@ -2241,11 +2272,13 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
       const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
       if (wu < 2) {
-        h.r = bld2(rb, off); h.p = PBuf<PT>::ld_pair(pb, off);
-        if (FORM == 0) h.q = bld2(qb, off);
+        h.r = bld2(rb, off);
+        if (FORM != 2) h.p = PBuf<PT>::ld_pair(pb, off);
+        if (FORM != 1) h.q = bld2(qb, off);
       } else {
-        h.r.x = bld1(rb, off); h.p1 = PBuf<PT>::ld_one(pb, off);
-        if (FORM == 0) h.q.x = bld1(qb, off);
+        h.r.x = bld1(rb, off);
+        if (FORM != 2) h.p1 = PBuf<PT>::ld_one(pb, off);
+        if (FORM != 1) h.q.x = bld1(qb, off);
       }
     }
   };
@@ -2262,21 +2295,28 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     if (wu < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (hcode) {
-        double z0 = FORM == 0 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x, z1 = FORM == 0 ? hr.r.y - alpha_prev * hr.q.y : hr.r.y;
+        double z0 = FORM != 1 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x, z1 = FORM != 1 ? hr.r.y - alpha_prev * hr.q.y : hr.r.y;
+        if (FORM == 2) {
+          if (hcode & 0xff) h.x = z0 * wtab[hcode & 0xff];
+          if (hcode >> 8) h.y = z1 * wtab[hcode >> 8];
+        }
         if (JACOBI) {
           if (hcode & 0xff) z0 = z0 / (double)(hcode & 0xff);
           if (hcode >> 8) z1 = z1 / (double)(hcode >> 8);
         }
-        const double2 hp = PBuf<PT>::wide(hr.p);
-        h.x = PIo<PT>::rnd(z0 + beta * hp.x); h.y = PIo<PT>::rnd(z1 + beta * hp.y);
+        if (FORM != 2) {
+          const double2 hp = PBuf<PT>::wide(hr.p);
+          h.x = PIo<PT>::rnd(z0 + beta * hp.x); h.y = PIo<PT>::rnd(z1 + beta * hp.y);
+        }
       }
       *reinterpret_cast<double2*>(&T[((wu == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
     } else if (wu == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
-        double z = FORM == 0 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x;
+        double z = FORM != 1 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x;
         if (JACOBI) z = z / (double)hcode;
-        h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
+        if (FORM == 2) h = z * wtab[hcode];
+        else h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
       }
       T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
     }
@@ -2309,6 +2349,28 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   }
   __syncthreads();
 
+  // FORM 2: even waves own the 2x2x2 block sums of the pre-smoothing residual; `own` = their x-pair sum of the plane just
+  // finished, `acc` the running 2 x 2 x (1 or 2) sum; plane gzp is consumed one barrier after it was computed (k_mg_fine, MODE 3)
+  double own[R], acc[R];
+#pragma unroll
+  for (int rr_ = 0; rr_ < R; ++rr_) { own[rr_] = 0.0; acc[rr_] = 0.0; }
+  auto consume = [&](int gzp) {
+    if (FORM != 2 || (wu & 1)) return;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const double* Y = ysum[FORM == 2 ? (gzp & 1) : 0];
+    const int kg = g.z0 + gzp - 1;  // global fine plane
+    const bool store = (kg & 1) != 0 || gzp == ge - 1;
+#pragma unroll
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      acc[rr_] += own[rr_] + Y[(rr_ * (NW / 2) + (wu >> 1)) * 64 + lane];
+      if (store) {
+        const int I = tx * (kBX / 2) + lane, J = (j0 + wu + rr_ * NW) >> 1;
+        if (I < C.cnx && J < C.cny) bcoarse[(long long)I + (long long)C.cnx * J + C.csz * ((kg >> 1) - C.z0c + 1)] = (float)acc[rr_];
+        acc[rr_] = 0.0;
+      }
+    }
+  };
   double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
   for (int gz = gs; gz < ge; ++gz) {
     // pf0 .. pf2 = first slots of planes gz, gz + 1, gz + 2
@@ -2335,16 +2397,19 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       stage_halo(tile + b_nxt, hr);
     }
     hcode = hcode_next; hslot = hslot_next;
+    if (FORM == 2 && gz > gs) consume(gz - 1);
     const double* T = tile + b_cur;
     const double* Tp = tile + b_prev;
     const long long nbq = (long long)(8 * kLV) * (pf1 - pf0);
-    const __amdgpu_buffer_rsrc_t qob = buf_of(q_out + kLV * pf0, nbq);
+    const __amdgpu_buffer_rsrc_t qob = buf_of(FORM == 2 ? (double*)nullptr : q_out + kLV * pf0, FORM == 2 ? 0 : nbq);
+    double xsum[R];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const unsigned short cc = cc_cur[rr_];
       const bool stored = in_x && lo_cur[rr_] >= 0;
       const int qoff = (lo_cur[rr_] - (int)pf0) * (8 * kLV) + sub;
-      if (fullline && !cc && stored) bst2(qob, qoff, 0.0, 0.0);  // whole lines
+      xsum[rr_] = 0.0;
+      if (FORM != 2 && fullline && !cc && stored) bst2(qob, qoff, 0.0, 0.0);  // whole lines
       if (cc) {  // q and every partial sum vanish where both voxels are non-free
         const int base = (wu + rr_ * NW + 1) * kLP + 2 + 2 * lane;
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
@@ -2359,6 +2424,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + zm.y) + pn_nxt[rr_].y;
         const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
         const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
+        if (FORM == 2) {  // residual of the first Jacobi iterate: r - A v; its x-pair sum goes to the restriction
+          const double o0 = c0 ? rc.x - q0 : 0.0, o1 = c1 ? rc.y - q1 : 0.0;
+          xsum[rr_] = o0 + o1;
+          s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
+          continue;
+        }
         bst2(qob, qoff, q0, q1);
         double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
         if (JACOBI) {
@@ -2372,6 +2443,16 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           s_zq += z0 * q0; s_zq += z1 * q1;
           s_qdq += q0 * d0; s_qdq += q1 * d1;
         }
+      }
+    }
+    if (FORM == 2) {  // odd waves publish their x-pair sums, even waves keep theirs until the barrier has passed
+      int lane = threadIdx.x & 63;
+      asm volatile("" : "+v"(lane));
+      double* Y = ysum[FORM == 2 ? (gz & 1) : 0];
+#pragma unroll
+      for (int rr_ = 0; rr_ < R; ++rr_) {
+        if (wu & 1) Y[(rr_ * (NW / 2) + (wu >> 1)) * 64 + lane] = xsum[rr_];
+        else own[rr_] = xsum[rr_];
       }
     }
     if (SEG) {  // the records requested at the top of this iteration have long arrived: their slots
@@ -2392,6 +2473,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   if (FORM == 1) {
     const double t = block_sum(s_pq, red);
     if (threadIdx.x == 0) partials[(long long)partial_base + blockIdx.x] = t;
+    return;
+  }
+  if (FORM == 2) {  // {r.r, r.z} with z = r, the two sums launch_update_r leaves
+    consume(ge - 1);
+    const double t = block_sum(s_rr, red);
+    if (threadIdx.x == 0) { partials[2 * ((long long)partial_base + blockIdx.x)] = t; partials[2 * ((long long)partial_base + blockIdx.x) + 1] = t; }
     return;
   }
   const double t0 = block_sum(s_rr, red);
@@ -2432,11 +2519,13 @@ static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double
   if (seg && g.tune.cg1_seg)
     hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
                        (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
-                       partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
+                       partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline,
+                       (float*)nullptr, MgCoarse{}, 0.0);
   else
     hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, false>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
                        (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
-                       partials, ctrl, lineoff, plane_first, (const uint2*)nullptr, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline);
+                       partials, ctrl, lineoff, plane_first, (const uint2*)nullptr, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline,
+                       (float*)nullptr, MgCoarse{}, 0.0);
 }
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
@@ -2533,11 +2622,34 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
 // preconditioned solve): the descriptor-addressed form, k_cg1b<.., FORM 1>; everything else: k_fused_a.  BOTH take the
 // chunking of fused_chunks, so that the per-block partial sums -- and with them the iterates -- are the same bit for bit
 // whichever kernel and layout runs (tests: ..._layouts_compacted_and_dense, ..._two_solver_paths_agree).
-static void fused_chunks(const Geom& g, long long cols, int* zchunk, int* nzc) {
+static void fused_chunks(const Geom& g, long long cols, bool even, int* zchunk, int* nzc) {
   Geom gg = g;
   if (g.tune.zchunk <= 0 && g.tune.fused_zchunk > 0 && !g.periodic && cols * ((g.nzl + g.tune.fused_zchunk - 1) / g.tune.fused_zchunk) >= 2048)
     gg.tune.zchunk = g.tune.fused_zchunk;
-  pick_chunks(gg, cols, false, zchunk, nzc);
+  pick_chunks(gg, cols, even, zchunk, nzc);
+}
+// can the descriptor-addressed forms of the two-kernel iteration (k_cg1b FORM 1 / FORM 2) run on this slab?
+bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi) {
+  return lineoff && plane_first && seg && !jacobi && g.tune.fused_kernel == 0 && g.tune.fused_rows == 2 && !g.periodic && 8ll * g.plane < kBufMax;
+}
+// k_cg1b FORM 2: r_out = r_in - alpha_{k-1} q (alpha from hist, 0 for k = 0), partials {r.r, r.r} per block, and the fp32
+// right-hand side of the first coarse level (owned planes) from the pre-smoothed residual.  Needs an even g.z0.  Returns the
+// number of blocks, -1 when the grid does not fit the partial-sum array
+int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in, double* r_out, const double* q, const double* hist, int k,
+                         MgCoarse c, float* bcoarse, double omega, double* partials, const Ctrl* ctrl, const int* lineoff,
+                         const long long* plane_first, const void* seg, hipStream_t s) {
+  const int by = kNW * 2;
+  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)tiles_x * tiles_y;
+  int zchunk, nzc;
+  fused_chunks(g, cols, true, &zchunk, &nzc);
+  if (!grid_fits(g, cols, nzc)) return -1;
+  const int blocks = (int)(cols * nzc);
+  hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r_in, r_out, q,
+                     (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc,
+                     0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1, bcoarse, c,
+                     omega);
+  return blocks;
 }
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
                    int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
@@ -2548,16 +2660,16 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
     const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
     const long long cols = (long long)tiles_x * tiles_y;
     int zchunk, nzc;
-    fused_chunks(g, cols, &zchunk, &nzc);
+    fused_chunks(g, cols, false, &zchunk, &nzc);
     if (!grid_fits(g, cols, nzc)) return -1;
     const int blocks = (int)(cols * nzc);
-    const bool descr = lineoff && plane_first && seg && !jacobi && g.tune.fused_kernel == 0 && 8ll * g.plane < kBufMax;
+    const bool descr = fused_descr_ok(g, lineoff, plane_first, seg, jacobi);
     if (descr) {
 #define OI_FB(PT)                                                                                                              \
   hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
                      (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, 0, zchunk, tiles_x,  \
                      tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,             \
-                     (g.pitch + kLV - 1) / kLV, 1)
+                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0)
       if (p_f32) OI_FB(float); else OI_FB(double);
 #undef OI_FB
       return blocks;

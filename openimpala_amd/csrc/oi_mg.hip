@@ -858,9 +858,10 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   MgLevelHost& C = Ls[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   const bool transition = mg->comm && C.replicated;  // owned contributions are summed across ranks afterwards
-  // periodic problem: the LDS-tiled fine kernels wrap x / y by index when every extent is even (pairs and 2x2x2
-  // aggregates then never straddle the seam); other shapes take the plain kernels
-  if (mg->periodic && !(g.periodic && ((g.nx | g.ny | g.nz) & 1) == 0)) tiled = 0;
+  // periodic problem: the LDS-tiled fine kernels wrap x / y by index when nx is even (a thread's x pair must not straddle
+  // the seam; odd ny / nz only leave a single row / plane in the last aggregates, as in the open problem); an odd nx
+  // takes the plain kernels
+  if (mg->periodic && !(g.periodic && (g.nx & 1) == 0)) tiled = 0;
   if (tiled && (g.z0 & 1) == 0) {
     // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
     if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);
@@ -883,6 +884,36 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
     return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
   hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl);
   return launch_dot(g, r, z, partials, s);
+}
+
+// ---- the cycle in two halves, for a caller that produces the first coarse right-hand side itself ----
+// (the two-kernel iteration on compacted vectors forms r_k = r_{k-1} - alpha q, pre-smooths it and restricts it in ONE
+// kernel, launch_mg_pre_update; it needs to know where the block sums go, and then runs everything after the restriction)
+// where the fp32 right-hand side of the first coarse level lives, and its layout; *omega / the cycle's fixed parameters.
+// `prepare` zeroes the target first where the owned contributions are summed across ranks afterwards.
+bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* omega, hipStream_t s) {
+  MgLevelHost& C = mg->levels[0];
+  *c = MgCoarse{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
+  *bcoarse = C.b;
+  *omega = (double)kOmega;
+  if (mg->comm && C.replicated) return hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s) == hipSuccess;
+  return true;
+}
+// everything after the restriction: ghost planes / rank sum of the coarse right-hand side, the coarse cycle, and the fine
+// post-smoother z = x2 + w (r - A x2) / c with the partial sums of z.r (returns their number, -1 on a transport failure)
+int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
+                                const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+  MgLevelHost& C = mg->levels[0];
+  MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
+  if (!finish_child_array(mg, C, false, C.b, s)) return -1;
+  if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
+  if (mg->wmask & 1u) {
+    OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, 1, C.b, C.x2, C.b2);
+    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s)) return -1;
+    if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
+    cref.xc2 = C.xs;
+  }
+  return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
 }
 
 // (A hipGraph replay of the cycle's ~250 launches was measured in round 1: no gain on ROCm 7.2 -- back-to-back dependent

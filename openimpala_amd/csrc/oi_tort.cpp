@@ -127,6 +127,9 @@ struct oi_tort {
   size_t bytes_device = 0;
 
   // state
+  bool rot = false;    // multigrid two-kernel iteration, rotated: kernel A of iteration k forms r_k = r_{k-1} - alpha q, pre-smooths and
+                       // restricts it in one pass (launch_mg_pre_update; r double-buffered in r / r2), so iteration k is complete
+                       // when launch k + 1 has run -- the bookkeeping of the single-kernel variant
   bool fused = true;   // fused two-kernel iteration or single-kernel iteration (double-buffered p)
   bool cg1 = false;    // single-kernel iteration
   int xskip = 0;       // cg1: x touched every second iteration (frozen at cg_begin)
@@ -824,6 +827,13 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
       h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
     }
   }
+  if (want_mg && h->fused && h->lineoff) {
+    // the rotated iteration (residual update fused into the pre-smoother): every slab must be able to run it
+    int cannot = (fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, h->jacobi ? 1 : 0) && h->mg_tiled && (g.z0 & 1) == 0 && !g.tune.mg_norot) ? 0 : 1;
+    if (h->comm) OIC(h->comm->allreduce_max_i32_host(&cannot, 1, s));
+    h->rot = !cannot;
+    if (h->rot) OIC(dmalloc(h, &h->r2, (size_t)h->nvec_cg));
+  }
   if (want_mg) {
     OIC(dmalloc(h, &h->z, (size_t)h->nvec_cg));
     HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
@@ -1073,6 +1083,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   if (h->p[1]) HIPC(hipMemsetAsync(h->p[1], 0, h->p_elem * h->nvec_cg, s));
   { PROF(K_INIT); launch_init_field(g, h->active, h->x, s); }
   int nb;
+  if (h->rot) HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * h->nvec_cg, s));
   h->xskip = h->cg1 ? g.tune.cg1_xskip : 0;
   if (h->cg1) {
     // kernel 0 reads buffer 1: r_{-1} := r_0 with alpha_{-1} = 0, q_{-1} = p_{-1} = 0
@@ -1141,6 +1152,34 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
       HIPC(hipStreamWaitEvent(s, h->ev_exchanged, 0));  // the next kernel reads the ghost planes of q
     }
+  } else if (h->rot) {
+    // rotated multigrid two-kernel iteration.  A: r_k = r_{k-1} - alpha_{k-1} q_{k-1} (k = 0: a copy of r_0), ||r_k||^2 and the
+    // stop test, pre-smoother + restriction; B: the rest of the cycle, z_k and r_k.z_k; C: p_k, q_k, p_k.q_k, x += alpha p
+    void* p_in = h->p[(k + 1) & 1];
+    void* p_out = h->p[k & 1];
+    const double* r_in = (k & 1) ? h->r2 : h->r;
+    double* r_out = (k & 1) ? h->r : h->r2;
+    MgCoarse cref{};
+    float* bcoarse = nullptr;
+    double omega = 0.0;
+    if (!mg_coarse_target(h->mg, &cref, &bcoarse, &omega, s)) return OI_HIP_ERROR;
+    {
+      PROF(K_UPDATE_R);
+      nb = launch_mg_pre_update(g, h->code, r_in, r_out, h->q, h->hist, k, cref, bcoarse, omega, h->partials, h->ctrl, h->lineoff,
+                                h->plane_first_dev, h->seg, s);
+    }
+    OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * k + H_RR, true, k + 1));
+    { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, s); }
+    if (nb < 0) return OI_RCCL_ERROR;
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+    OIC(exchange_cg_vec(h, h->z, sizeof(double), s));
+    {
+      PROF(K_FUSED_A);
+      nb = launch_fused_a(g, h->code, h->x, h->z, p_in, p_out, h->p_f32 ? 1 : 0, h->q, 0, h->hist, k, h->partials, h->ctrl, h->lineoff,
+                          h->plane_first_dev, h->seg, s);
+    }
+    OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
+    OIC(exchange_cg_vec(h, h->q, sizeof(double), s));  // (kernel A of the next iteration forms r on the ghost planes from r and q there)
   } else if (h->fused) {
     void* p_in = h->p[(k + 1) & 1];
     void* p_out = h->p[k & 1];
@@ -1222,7 +1261,7 @@ extern "C" oi_status oi_tort_cg_iterate(oi_tort* h, int n) {
   if (!h || n < 0) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (!h->cg_active) { oi::set_error("%s: no CG run is open (oi_tort_cg_begin first)", __func__); return OI_BAD_ARG; }
   HIPC(hipSetDevice(h->device));
-  const int limit = h->maxiter + (h->cg1 ? 1 : 0);  // kernel k of the single-kernel variant completes iteration k
+  const int limit = h->maxiter + ((h->cg1 || h->rot) ? 1 : 0);  // launch k of the single-kernel / rotated variants completes iteration k - 1
   int issued = 0;
   for (int i = 0; i < n; ++i) {
     if (h->iters_issued >= limit) break;
@@ -1250,14 +1289,17 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
   // iterations whose x/r updates are in effect
-  const int K = done ? done - 1 : (h->cg1 ? std::max(0, h->iters_issued - 1) : h->iters_issued);
+  const int K = done ? done - 1 : ((h->cg1 || h->rot) ? std::max(0, h->iters_issued - 1) : h->iters_issued);
   if (h->cg1 && h->xskip && (K & 1) && h->iters_issued > 0) {
     // pairwise x updates: an odd final state still lacks alpha_{K-1} p_{K-1}
     PROF(K_AXPY);
     launch_axpy_ptr(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->rec + (size_t)kRec1Stride * (K - 1) + kRec1Alpha,
                     h->lineoff, h->stream);
   }
-  if (h->fused && !h->cg1 && K > 0) {
+  // (rotated variant: stopped at convergence -- kernel A of launch K raised the flag, kernels B and C of that launch returned at
+  // once -- x lacks alpha_{K-1} p_{K-1} like the plain fused variant; stopped for another reason, K = launches - 1 and kernel C
+  // of the last launch has already added alpha_{K-1} p_{K-1}: x = x_K as it is)
+  if (h->fused && !h->cg1 && K > 0 && !(h->rot && !done)) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
     PROF(K_AXPY);
     launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->hist, K - 1, h->lineoff, h->stream);
@@ -1303,7 +1345,7 @@ extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* 
   HIPC(hipSetDevice(h->device));
   OIC(poll_ctrl(h));
   const int done = h->h_ctrl->done;
-  const int K = done ? done - 1 : (h->cg1 ? std::max(0, h->iters_issued - 1) : h->iters_issued);
+  const int K = done ? done - 1 : ((h->cg1 || h->rot) ? std::max(0, h->iters_issued - 1) : h->iters_issued);
   const double* rr_src = h->cg1 ? h->rec + (size_t)kRec1Stride * K : h->hist + H_STRIDE * K + H_RR;
   HIPC(hipMemcpyAsync(h->h_scal, rr_src, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
@@ -1331,7 +1373,7 @@ static oi_status solve(oi_tort* h) {
   // initial check (converged before iterating)
   rc = poll_ctrl(h);
   if (rc == OI_OK && h->h_ctrl->done) stop = true;
-  const int limit = h->maxiter + (h->cg1 ? 1 : 0);
+  const int limit = h->maxiter + ((h->cg1 || h->rot) ? 1 : 0);
   while (rc == OI_OK && !stop && h->iters_issued < limit) {
     rc = oi_tort_cg_iterate(h, batch);
     if (rc != OI_OK) break;
@@ -2042,6 +2084,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "cg1_kernel") t.cg1_kernel = iv;
   else if (k == "cg1_seg") t.cg1_seg = iv != 0;
   else if (k == "fused_kernel") t.fused_kernel = iv;
+  else if (k == "mg_norot") t.mg_norot = iv != 0;
   else if (k == "fused_zchunk") t.fused_zchunk = iv > 0 ? iv : 0;
   else if (k == "place_min_mb") t.place_min_mb = iv > 0 ? iv : 0;
   else if (k == "place_extent_gb") t.place_extent_gb = (float)value;

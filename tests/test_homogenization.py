@@ -123,13 +123,14 @@ def test_gpu_homogenization_on_a_ring_of_slabs(sample_phase, nranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,pid", [((40, 36, 44), 1), ((25, 31, 33), 0), ((16, 18, 130), 1), ((64, 64, 64), 1), ((12, 40, 300), 1)])
+@pytest.mark.parametrize("shape,pid", [((40, 36, 44), 1), ((25, 31, 33), 0), ((16, 18, 130), 1), ((64, 64, 64), 1), ((12, 40, 300), 1),
+                                       ((25, 31, 36), 0), ((17, 40, 132), 1), ((40, 19, 44), 1)])
 def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
     """OI_PRECOND_MG on the periodic cell problems: the aggregation hierarchy wraps in x, y (by index) and z (ghost
     planes), odd sizes leave single-child aggregates next to the wrap.  Same chi and tensor, far fewer iterations.
     Even extents run the flow-through path's LDS-tiled kernels and fused two-kernel iteration with x / y wrapped by
-    index (domain ends inside a tile: 18 and 40 rows over 16-row tiles, 130 and 300 columns over 128-column tiles);
-    odd extents the plain kernels."""
+    index (domain ends inside a tile: 18 and 40 rows over 16-row tiles, 130 and 300 columns over 128-column tiles), also
+    with odd ny / nz (round 3: the last three shapes); an odd nx takes the plain kernels."""
     import openimpala_amd as oia
     nz, ny, nx = shape
     sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
@@ -184,11 +185,14 @@ def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, oi_option, nranks,
 
 
 @pytest.mark.gpu
-def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, oi_option):
+@pytest.mark.parametrize("shape", [(36, 52, 172), (35, 51, 132), (33, 40, 20), (40, 37, 64)])
+def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, oi_option, shape):
     """The two kernel families behind OI_PRECOND_MG on the cell problems (OI_MG_PLAIN selects the plain one): same
-    iteration counts, chi fields equal to solver tolerance."""
+    iteration counts, chi fields equal to solver tolerance.  Round 3: odd ny / nz run the tiled kernels too (an odd nx
+    still takes the plain ones): a single row / plane in the last aggregates, image planes beyond an odd nz."""
     import openimpala_amd as oia
-    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:36, :52, :172])
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
 
     def run():
         h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-11, precond=oia.PRECOND_MG)
