@@ -170,7 +170,13 @@ def test_searching_single_kernel_handles_release_their_arenas():
         free.append(oia.device_memory()[0])
     oia.set_option("place_alloc_budget_s", 0.5)
     ph.free()
-    assert max(free[1:]) - min(free[1:]) < (64 << 20), [f >> 20 for f in free]
+    # (a reading right after a destroy may lag by a whole handle -- the driver reports freed arrays a little later, see
+    # test_handles_release_their_device_memory -- so the test is on the highest readings: no handle left memory behind for good)
+    import time
+    time.sleep(0.5)
+    final = oia.device_memory()[0] - int(np.prod(shape))   # (the phase buffer has just gone back too)
+    top = sorted(free[1:])[-2:]
+    assert top[1] - top[0] < (64 << 20) and top[1] - final < (64 << 20), ([f >> 20 for f in free], final >> 20)
     # while alive a handle holds what it accounts for -- the spare slots of the search have been released (the driver may
     # report them free a little later: the bound leaves room for two of the six spare slots of 0.47 GB)
     for alive, accounted in held[1:]:
