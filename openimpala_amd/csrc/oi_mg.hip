@@ -45,7 +45,9 @@ namespace oi {
 
 namespace {
 
-constexpr float kOmega = 0.8f;   // Jacobi damping
+constexpr float kOmega = 0.9f;   // Jacobi damping (default; option mg_omega).  Round 3: 0.8 -> 0.9 after a sweep on the product
+                                 // (profiles/r03/mg_omega_*.txt: 23 -> 22 iterations at 1024^3 spheres, 48 -> 46 on 768^3 blobs; the
+                                 // prototype agrees: 21 -> 20, 28 -> 27); any value < 1 keeps the cycle positive definite
 constexpr float kScale = 1.5f;   // over-correction of the piecewise-constant coarse correction
 constexpr int kCoarsestSweeps = 16;
 constexpr long long kCoarsestCells = 512;
@@ -59,6 +61,7 @@ struct Dims {
   int nzg;              // planes of the whole level
   int periodic;         // 1: the homogenization cell problem (x, y wrap by index, z through the ghost planes)
   long long sz;         // plane stride = nx * ny; arrays hold nzl + 2 planes (ghosts at 0 and nzl + 1)
+  float omega;          // Jacobi damping of the cycle (MgHierarchy::omega, the same on every level)
 };
 
 template <class W, class D>
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(256) k_mg_pre(LevelT<W, D> L, int kfirst, cons
   const float d = (float)L.diag[m];
   float res = 0.f;
   if (d > 0.f) {
-    auto xs = [&](long long mm) -> float { const float dd = (float)L.diag[mm]; return dd > 0.f ? kOmega * b[mm] * rcp(dd) : 0.f; };
+    auto xs = [&](long long mm) -> float { const float dd = (float)L.diag[mm]; return dd > 0.f ? L.omega * b[mm] * rcp(dd) : 0.f; };
     OI_MG_NBRS(L)
     const float s = offdiag(L, m, mxm, mym, xs(mxm), xs(mxp), xs(mym), xs(myp), xs(m - sz), xs(m + sz));
     res = b[m] - (d * xs(m) - s);
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, con
     const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
     float c = xc[cm];
     if (xc2) c += xc2[cm];
-    return xpre ? xpre[mm] + scale * c : kOmega * b[mm] * rcp(dd) + scale * c;
+    return xpre ? xpre[mm] + scale * c : L.omega * b[mm] * rcp(dd) + scale * c;
   };
   float o = 0.f;
   const float d = (float)L.diag[m];
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, con
     const float s = offdiag(L, m, mxm, mym, (per || i > 0) ? x2(mxm, ixm, j, k) : 0.f, (per || i < L.nx - 1) ? x2(mxp, ixp, j, k) : 0.f,
                             (per || j > 0) ? x2(mym, i, jym, k) : 0.f, (per || j < L.ny - 1) ? x2(myp, i, jyp, k) : 0.f,
                             x2(m - sz, i, j, k - 1), x2(m + sz, i, j, k + 1));
-    o = c + kOmega * (b[m] - (d * c - s)) * rcp(d);
+    o = c + L.omega * (b[m] - (d * c - s)) * rcp(d);
   }
   out[m] = o;
 }
@@ -336,7 +339,7 @@ template <class W, class D, int SRC, int OUT>
 __global__ void __launch_bounds__(256) k_mg_lin4(LevelT<W, D> L, int kfirst, int nplanes, const float* __restrict__ b,
                                                   const float* __restrict__ x, float* __restrict__ r) {
   OI_MG_CELL4(L)
-  auto xs1 = [&](float bb, float dd) -> float { return dd > 0.f ? kOmega * bb * rcp(dd) : 0.f; };
+  auto xs1 = [&](float bb, float dd) -> float { return dd > 0.f ? L.omega * bb * rcp(dd) : 0.f; };
   auto u4 = [&](long long mm, float (&o)[4]) {
     if (SRC == 1) { ld4(x + mm, o); return; }
     float bb[4], dd[4];
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(256) k_mg_lin4(LevelT<W, D> L, int kfirst, int
       s += wzm[c] * xzm[c];
       s += wzc[c] * xzp[c];
       const float rr = bc[c] - (dc[c] * xc_[c] - s);
-      res[c] = OUT == 0 ? rr : xc_[c] + kOmega * rr * rcp(dc[c]);
+      res[c] = OUT == 0 ? rr : xc_[c] + L.omega * rr * rcp(dc[c]);
     }
   }
   *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
   OI_MG_CELL4(L)
   const bool per = L.periodic != 0;
   // xpre != null: the iterate before the coarse correction is a stored vector (two pre-smoothing sweeps), not w b / D
-  auto x21 = [&](float bb, float dd, float cc) -> float { return dd > 0.f ? kOmega * bb * rcp(dd) + scale * cc : 0.f; };
+  auto x21 = [&](float bb, float dd, float cc) -> float { return dd > 0.f ? L.omega * bb * rcp(dd) + scale * cc : 0.f; };
   auto x21p = [&](float xp, float dd, float cc) -> float { return dd > 0.f ? xp + scale * cc : 0.f; };
   auto par = [&](long long cm) -> float {
     float c = xc[cm];
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
       s += wyc[c] * xyp[c];
       s += wzm[c] * xzm[c];
       s += wzc[c] * xzp[c];
-      o[c] = cc[c] + kOmega * (bc[c] - (dc[c] * cc[c] - s)) * rcp(dc[c]);
+      o[c] = cc[c] + L.omega * (bc[c] - (dc[c] * cc[c] - s)) * rcp(dc[c]);
     }
   }
   *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
@@ -450,11 +453,11 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
   float o = 0.f;
   if (d > 0.f) {
     if (first) {
-      o = kOmega * b[m] * rcp(d);
+      o = L.omega * b[m] * rcp(d);
     } else {
       const float c = xin[m];
       OI_MG_NBRS(L)
-      o = c + kOmega * (b[m] - (d * c - offdiag(L, m, mxm, mym, xin[mxm], xin[mxp], xin[mym], xin[myp], xin[m - sz], xin[m + sz]))) * rcp(d);
+      o = c + L.omega * (b[m] - (d * c - offdiag(L, m, mxm, mym, xin[mxm], xin[mxp], xin[mym], xin[myp], xin[m - sz], xin[m + sz]))) * rcp(d);
     }
   }
   xout[m] = o;
@@ -464,10 +467,10 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
 // fine vectors live in the pitched / ghost-plane layout; b vanishes on non-free cells and its
 // ghost planes hold the neighbours' values.   r1 = b - A (w b / code)
 __global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
-                                                      double* __restrict__ r1, const Ctrl* __restrict__ ctrl, int periodic) {
+                                                      double* __restrict__ r1, const Ctrl* __restrict__ ctrl, int periodic, double omega_) {
   if (ctrl && ctrl->done) return;
   const long long n = (long long)g.nzl * g.ny * g.nx;
-  const double w = (double)kOmega;
+  const double w = omega_;
   auto xs = [&](long long e) -> double { const unsigned c = code[e]; return c ? w * b[e] / (double)c : 0.0; };
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
@@ -493,10 +496,10 @@ __global__ void __launch_bounds__(256) k_mg_fine_pre(Geom g, const uint8_t* __re
 
 // z = x2 + w (b - A x2) / code,  x2 = w b / code + kScale * P (xc + xc2)
 __global__ void __launch_bounds__(256) k_mg_fine_post(Geom g, const uint8_t* __restrict__ code, const double* __restrict__ b,
-                                                       MgCoarse C, double sc, double* __restrict__ z, const Ctrl* __restrict__ ctrl) {
+                                                       MgCoarse C, double sc, double* __restrict__ z, const Ctrl* __restrict__ ctrl, double omega_) {
   if (ctrl && ctrl->done) return;
   const long long n = (long long)g.nzl * g.ny * g.nx;
-  const double w = (double)kOmega;
+  const double w = omega_;
   auto x2 = [&](int i, int j, int gz) -> double {  // gz: plane incl. ghost offset
     const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
     const unsigned c = code[e];
@@ -583,6 +586,7 @@ struct MgHierarchy {
   size_t bytes = 0;
   unsigned wmask = kWCycleMask;
   float scale = kScale;
+  float omega = kOmega;
   bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
   int nu_coarse = 1;    // damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (1 or 2)
   bool failed = false;
@@ -675,6 +679,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   if (g.tune.mg_replicate_cells > 0) replicate_cells = g.tune.mg_replicate_cells;  // tests: distribute small levels too
   if (g.tune.mg_wmask >= 0) mg->wmask = (unsigned)g.tune.mg_wmask;                   // experiments with the cycle shape
   if (g.tune.mg_scale > 0.f) mg->scale = g.tune.mg_scale;
+  if (g.tune.mg_omega > 0.f && g.tune.mg_omega < 1.f) mg->omega = g.tune.mg_omega;
   mg->novec4 = g.tune.mg_novec4 != 0;
   mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
   for (int l = 0; l < 24; ++l) {
@@ -683,6 +688,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
     L.d.sz = (long long)L.d.nx * L.d.ny;
     L.d.nzg = L.nz;
     L.d.periodic = periodic ? 1 : 0;
+    L.d.omega = mg->omega;
     L.compact = l < kCompactLevels;
     // keep the slab partition while every rank's slab starts on an even plane, holds at least two
     // planes and the level is worth distributing; otherwise this and all deeper levels are replicated
@@ -865,12 +871,12 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   if (tiled && (g.z0 & 1) == 0) {
     // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
     if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);
-    launch_mg_fine(3, g, code, r, cref, (double)kOmega, (double)mg->scale, nullptr, C.b, partials, ctrl, lineoff, s);
+    launch_mg_fine(3, g, code, r, cref, (double)mg->omega, (double)mg->scale, nullptr, C.b, partials, ctrl, lineoff, s);
     if (!finish_child_array(mg, C, false, C.b, s)) return -1;
   } else {
     if (lineoff) { oi::set_error("compacted vectors need the fused fine-level kernels (even first plane)"); return -1; }
-    if (tiled) launch_mg_fine(1, g, code, r, cref, (double)kOmega, (double)mg->scale, scratch, nullptr, partials, ctrl, nullptr, s);
-    else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl, mg->periodic ? 1 : 0);
+    if (tiled) launch_mg_fine(1, g, code, r, cref, (double)mg->omega, (double)mg->scale, scratch, nullptr, partials, ctrl, nullptr, s);
+    else hipLaunchKernelGGL(k_mg_fine_pre, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, scratch, ctrl, mg->periodic ? 1 : 0, (double)mg->omega);
     if (!restrict_to(mg, &g, code, scratch, nullptr, C, C.b, s)) return -1;
   }
   if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
@@ -881,8 +887,8 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
     cref.xc2 = C.xs;
   }
   if (tiled)  // also leaves the per-block partial sums of z.r
-    return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
-  hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl);
+    return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
+  hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl, (double)mg->omega);
   return launch_dot(g, r, z, partials, s);
 }
 
@@ -895,7 +901,7 @@ bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* ome
   MgLevelHost& C = mg->levels[0];
   *c = MgCoarse{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   *bcoarse = C.b;
-  *omega = (double)kOmega;
+  *omega = (double)mg->omega;
   if (mg->comm && C.replicated) return hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s) == hipSuccess;
   return true;
 }
@@ -913,7 +919,7 @@ int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* c
     if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
     cref.xc2 = C.xs;
   }
-  return launch_mg_fine(2, g, code, r, cref, (double)kOmega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
+  return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
 }
 
 // (A hipGraph replay of the cycle's ~250 launches was measured in round 1: no gain on ROCm 7.2 -- back-to-back dependent

@@ -307,6 +307,38 @@ def test_multigrid_two_coarse_sweeps(sample, goldens, oi_option):
         t.destroy()
 
 
+@pytest.mark.parametrize("p_storage", [oia.STORE_F64, oia.STORE_F32])
+def test_multigrid_rotated_iteration_and_its_cross_checks(sample, goldens, oi_option, p_storage):
+    """The default multigrid-preconditioned solve runs the ROTATED two-kernel iteration (residual update + fine pre-smoother +
+    restriction in one descriptor-addressed pass, k_cg1b FORM 2; first kernel k_cg1b FORM 1).  Its cross-checks -- the unrotated
+    iteration (`mg_norot`), k_fused_a as first kernel (`fused_kernel` = 1, which also un-rotates) -- produce the same iterates bit
+    for bit: same iteration count, tau and solution, the same residual norm to summation order; and stepping n launches reports
+    n - 1 complete iterations in the rotated form (launch k forms r_k first, like the single-kernel variant), n in the other."""
+    g = goldens["phases"]["1"]
+    reset = {"mg_norot": 0, "fused_kernel": 0}
+    out = {}
+    for name, opts in (("default", {}), ("norot", {"mg_norot": 1}), ("fused_a", {"fused_kernel": 1})):
+        for k_, v_ in opts.items():
+            oi_option(k_, v_, reset=reset[k_])
+        t = oia.TortuosityMI355(sample, 1, 1, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG, p_storage=p_storage)
+        tau = t.value()
+        st = t.stats()
+        assert st.converged and tau == pytest.approx(g["tau"][1], rel=1e-7)
+        sol = t.solution()
+        t.cg_begin(); t.cg_iterate(7); t.sync()
+        its, rel, conv = t.cg_state()
+        t.cg_finish()
+        out[name] = (tau, st.iterations, st.final_relres, sol, its, rel)
+        t.destroy()
+        for k_ in opts:
+            oia.set_option(k_, reset[k_])
+    for name in ("norot", "fused_a"):
+        assert out[name][0] == out["default"][0] and out[name][1] == out["default"][1], name
+        assert out[name][2] == pytest.approx(out["default"][2], rel=1e-12), name   # (||r||^2 is summed tile-wise here, line-wise there)
+        assert np.array_equal(out[name][3], out["default"][3]), name
+        assert out[name][4] == 7 and out["default"][4] == 6
+
+
 def test_multigrid_ragged_shapes_and_refusals():
     phase = o.gen_spheres((37, 45, 51), 6, 5, 0.5)       # odd sizes: truncated aggregates on every level
     for d in range(3):
