@@ -2203,8 +2203,17 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const __amdgpu_buffer_rsrc_t ob = buf_of(p_out + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
 #pragma unroll
       for (int rr_ = 0; rr_ < R; ++rr_) {
+#ifdef OI_SOFFSET_TEST  // TEST BUILD ONLY (tools/soffset_experiment.sh): the row offset of the x accesses as the instruction's scalar
+        // offset, the form that read x from wrong rows in round 2 (profiles/r02/k_cg1b_soffset_hazard.txt); 2 = with wait states
+        raw.xoff[rr_] = raw.off[rr_] == kOob ? kOob : ivox8;
+        raw.xv[rr_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(xb, raw.xoff[rr_], row_of(rr_) * g.pitch * 8, 0));
+#if OI_SOFFSET_TEST == 2
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+#else
         raw.xoff[rr_] = raw.off[rr_] == kOob ? kOob : ivox8 + row_of(rr_) * g.pitch * 8;
         raw.xv[rr_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(xb, raw.xoff[rr_], 0, 0));
+#endif
         if (xskip) raw.pold[rr_] = PBuf<PT>::ld_pair(ob, raw.off[rr_]);  // p_{k-2}
       }
     }
@@ -2254,8 +2263,16 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
             const double2 pold = PBuf<PT>::wide(raw.pold[rr_]);
             a0 = alpha_prev2 * pold.x + a0; a1 = alpha_prev2 * pold.y + a1;
           }
+#ifdef OI_SOFFSET_TEST
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(xv.x + a0, xv.y + a1)), xb,
+                                                 raw.xoff[rr_], row_of(rr_) * g.pitch * 8, 0);
+#if OI_SOFFSET_TEST == 2
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+#else
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(xv.x + a0, xv.y + a1)), xb,
                                                  raw.xoff[rr_], 0, 0);
+#endif
         }
         PBuf<PT>::st_pair(pob, raw.off[rr_], pn[rr_].x, pn[rr_].y);
       }

@@ -284,3 +284,20 @@ def test_launch_geometry_never_exceeds_the_partial_sum_array(descr):
     # the default of the descriptor-addressed kernel at the bench size: 16-row tiles, 16-plane chunks
     assert oia.cg1_grid(1024, 1024, 1024, descr=1)[:3] == (16, 16, 8 * 64 * 64)
     assert oia.cg1_grid(1024, 1024, 1024, descr=0)[0] == 32
+
+
+def test_descriptor_kernels_carry_no_scalar_offset_register():
+    """profiles/r03/k_cg1b_soffset_hazard_confirmed.txt: on gfx950 a buffer instruction may pick its SCALAR offset up after a
+    following SALU instruction has rewritten the register (variant builds with and without wait states, three GPU runs each);
+    the descriptor-addressed kernels therefore pass 0 there and carry rows in the lane offset.  This disassembles the code
+    object that ships and fails if the compiler has put a scalar-offset register on any buffer instruction of k_cg1b."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    if not os.path.exists(check_isa.OBJDUMP):
+        pytest.skip("no llvm-objdump")
+    lib = os.path.join(ROOT, "openimpala_amd", "libopenimpala_amd.so")
+    found, counts = check_isa.scan(check_isa.device_disassembly(lib))
+    assert len(counts) >= 16 and sum(counts.values()) > 1000, counts     # the kernels were found and do use buffer instructions
+    assert not found, {k: v[:2] for k, v in found.items()}
