@@ -10,7 +10,6 @@
 // CPU oracle, so single-kernel outputs are bit-identical to it.
 #include "oi_device.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -493,6 +492,59 @@ __global__ void __launch_bounds__(256) k_line_finalize(long long n, long long pe
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
     if (!flags[t]) slots[t] = -1;
 }
+// ---- exclusive prefix sum of the line flags (set-up, once per handle): three passes, hand-written ----
+// blocks of 256 threads x 16 consecutive items: (1) block totals, (2) one block scans the totals in place, (3) every block
+// scans its items again and adds its offset.  Integer sums: the order does not matter, the result is exact.
+constexpr int kScanItems = 16, kScanBlock = 256 * kScanItems;
+__device__ __forceinline__ int scan_block_exclusive(int v, int* total) {  // exclusive scan of one value per thread over 256 threads
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();  // (wsum may still be read by a previous call)
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < w; ++k) base += wsum[k];
+  if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + inc - v;
+}
+__global__ void __launch_bounds__(256) k_scan_totals(long long n, const int* __restrict__ flags, int* __restrict__ totals) {
+  const long long first = (long long)blockIdx.x * kScanBlock + (long long)threadIdx.x * kScanItems;
+  int sum = 0;
+  for (int k = 0; k < kScanItems; ++k)
+    if (first + k < n) sum += flags[first + k];
+  int tot = 0;
+  (void)scan_block_exclusive(sum, &tot);
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan_offsets(int nblocks, int* __restrict__ totals) {  // one block: totals -> their exclusive scan
+  int carry = 0;
+  for (int b0 = 0; b0 < nblocks; b0 += 256) {
+    const int i = b0 + (int)threadIdx.x;
+    const int v = i < nblocks ? totals[i] : 0;
+    int tot = 0;
+    const int ex = scan_block_exclusive(v, &tot);
+    if (i < nblocks) totals[i] = carry + ex;
+    carry += tot;
+  }
+}
+__global__ void __launch_bounds__(256) k_scan_apply(long long n, const int* __restrict__ flags, const int* __restrict__ offsets,
+                                                     int* __restrict__ out) {
+  const long long first = (long long)blockIdx.x * kScanBlock + (long long)threadIdx.x * kScanItems;
+  int f[kScanItems], sum = 0;
+  for (int k = 0; k < kScanItems; ++k) { f[k] = first + k < n ? flags[first + k] : 0; sum += f[k]; }
+  int run = offsets[blockIdx.x] + scan_block_exclusive(sum, nullptr);
+  for (int k = 0; k < kScanItems; ++k) {
+    if (first + k < n) out[first + k] = run;
+    run += f[k];
+  }
+}
+
 // lineoff: (nzl + 2) * ny * LW ints; plane_first_dev: nzl + 3 long longs.  Returns hipSuccess or the failing call's error.
 hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, long long* plane_first_dev, void* seg, hipStream_t s) {
   const int LW = (g.pitch + kLV - 1) / kLV;
@@ -500,14 +552,18 @@ hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, 
   const long long n = (long long)(g.nzl + 2) * g.ny * LW;
   if (n >= (1ll << 31)) return hipErrorInvalidValue;
   int* flags = nullptr;
-  void* tmp = nullptr;
-  size_t tmp_bytes = 0;
+  int* tmp = nullptr;
   hipError_t e = hipMalloc((void**)&flags, sizeof(int) * n);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_line_flags, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, g, code, LW, flags);
-  e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flags, lineoff, (int)n, s);
-  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
-  if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, lineoff, (int)n, s);
+  const int sblocks = (int)((n + kScanBlock - 1) / kScanBlock);
+  e = hipMalloc((void**)&tmp, sizeof(int) * (size_t)(sblocks > 0 ? sblocks : 1));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_scan_totals, dim3(sblocks), dim3(256), 0, s, n, flags, tmp);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(256), 0, s, sblocks, tmp);
+    hipLaunchKernelGGL(k_scan_apply, dim3(sblocks), dim3(256), 0, s, n, flags, tmp, lineoff);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_line_finalize, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, n, (long long)g.ny * LW, LW, TX, flags, lineoff,
                        plane_first_dev, (uint2*)seg);
