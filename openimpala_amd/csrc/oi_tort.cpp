@@ -451,8 +451,10 @@ static oi_status vecset_alloc(oi_tort* h, bool search) {
       // profiles/r03/place_runs_a.txt).  x and six slots are needed whatever they cost; what the search adds is bounded
       if (k >= 6 && now_s() - t0 > (double)h->g.tune.place_alloc_budget_s) { want = k; break; }
       if (k == na && k >= 6) ok = hipMalloc((void**)&spacer, (size_t)(spacer_gb * 1e9)) == hipSuccess;
+      const double ta = now_s();
       ok = ok && hipMalloc((void**)&v.slot[k], h->slot_bytes) == hipSuccess;
       if (ok) v.nslots = k + 1;
+      if (h->opts.verbose > 2) fprintf(stderr, "[openimpala_amd]   slot %d allocated in %.1f ms (%.2f s since the set was begun)\n", k, 1e3 * (now_s() - ta), now_s() - t0);
     }
     if (spacer) (void)hipFree(spacer);
     if (ok) {
