@@ -19,3 +19,4 @@ cat $out/summary.txt
 # keep only the small files
 find $out -name "*.db" -delete
 find $out -name "*agent_info*" -delete
+find $out -name "*.csv" -size +2M -delete   # (the summary is what is kept; gpurun brings back 64 MiB at most)

@@ -27,7 +27,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        want = os.environ.get("OI_SQ_KERNEL", "k_cg1").split(",")
+        want = os.environ.get("OI_SQ_KERNEL", "k_cg1").split(";")   # (kernel names hold commas: ';' separates several)
         hit = [w for w in want if w in k]
         if not hit: continue
         acc[hit[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -37,3 +37,4 @@ for k, d in acc.items():
         print(f"{k:24s} {c:34s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
 PY
 find $out -name "*.db" -delete; find $out -name "*agent_info*" -delete; find $out -name "*kernel_trace*" -delete
+find $out -name "*.csv" -size +2M -delete   # (gpurun brings back 64 MiB at most: the summary above is what is kept)
