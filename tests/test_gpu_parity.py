@@ -339,6 +339,28 @@ def test_multigrid_rotated_iteration_and_its_cross_checks(sample, goldens, oi_op
         assert out[name][4] == 7 and out["default"][4] == 6
 
 
+def test_multigrid_rotated_iteration_when_the_budget_runs_out(sample, goldens, oi_option):
+    """maxiter reached without convergence: the rotated iteration issues maxiter + 1 launches (launch k completes iteration k - 1,
+    as in the single-kernel variant) and ends in the state of exactly maxiter iterations -- same iteration count, residual,
+    status and x as the unrotated iteration; value() is NaN with OI_NOT_CONVERGED as the reference returns it
+    (TortuosityHypre.cpp:782-787)."""
+    g = goldens["phases"]["1"]
+    out = {}
+    for name, norot in (("rot", 0), ("norot", 1)):
+        oi_option("mg_norot", norot, reset=0)
+        for maxiter in (1, 6, 7):
+            t = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], eps=1e-12, precond=oia.PRECOND_MG, maxiter=maxiter)
+            tau = t.value()
+            st = t.stats()
+            assert math.isnan(tau) and t.status == oia.OI_NOT_CONVERGED and not st.converged and st.iterations == maxiter
+            out[(name, maxiter)] = (st.final_relres, t.solution())
+            t.destroy()
+    for maxiter in (1, 6, 7):
+        assert out[("rot", maxiter)][0] == pytest.approx(out[("norot", maxiter)][0], rel=1e-12)
+        assert np.array_equal(out[("rot", maxiter)][1], out[("norot", maxiter)][1]), maxiter
+    assert out[("rot", 7)][0] < out[("rot", 6)][0] < out[("rot", 1)][0]
+
+
 def test_multigrid_ragged_shapes_and_refusals():
     phase = o.gen_spheres((37, 45, 51), 6, 5, 0.5)       # odd sizes: truncated aggregates on every level
     for d in range(3):
