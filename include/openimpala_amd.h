@@ -68,7 +68,8 @@ typedef struct oi_tort_opts {
   int maxiter;
   int precond;        /* OI_PRECOND_* */
   int remspot_passes; /* tortuosity.remspot_passes (TortuosityHypre.cpp:254-256), default 0 */
-  int remspot_box_size; /* the inputs file's box_size (default 48): the filter runs per box, see oi_remspot; works on z-slabs */
+  int remspot_box_size; /* the inputs file's box_size (default 32, the reference's: Diffusion.cpp:185, tTortuosity.cpp:125): the filter runs
+                         * per box of ba.maxSize(box_size), see oi_remspot; <= 0 = one box spanning the whole domain; works on z-slabs */
   int verbose;        /* 0 silent .. 3 */
   int check_every;    /* host looks at the device convergence flag every this many iterations (<=0: auto) */
   int kernel;         /* OI_KERNEL_* */
