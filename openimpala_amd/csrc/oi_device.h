@@ -39,6 +39,7 @@ struct Tune {
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
   float mg_omega = 0.f;  // in (0, 1): Jacobi damping of the cycle (default 0.9)
+  int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)
   int mg_nu_coarse = 1;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (1 or 2; the fine level: 1)
   int place_trials = 48; // single-kernel CG: vector placements (six of place_slots allocations made back to back) timed when
                          // the handle is built, the fastest kept; 0 = six slots in order, no search (env OI_PLACE_TRIALS)

@@ -463,6 +463,49 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
   xout[m] = o;
 }
 
+// coarsest level, all sweeps in ONE launch: <= 512 cells, one thread per cell, weights and right-hand side in registers, the
+// iterate in two LDS planes, a barrier between sweeps (the per-sweep launches of k_mg_jacobi -- 16 sweeps x 8 visits per cycle --
+// were 0.9 ms of every cycle at 1024^3, all of it launch latency).  Same arithmetic in the same order as k_mg_jacobi: bit-identical.
+// Open (non-periodic) levels that live whole on this rank only.
+constexpr int kCoarsestLds = 512 + 2 * 512;
+template <class W, class D>
+__global__ void __launch_bounds__(512) k_mg_coarsest(LevelT<W, D> L, const float* __restrict__ b, float* __restrict__ out, int sweeps) {
+  __shared__ float xb[2][kCoarsestLds];
+  const int n = (int)(L.sz * (L.nzl + 2)), cells = (int)(L.sz * L.nzl);
+  for (int t = threadIdx.x; t < n; t += blockDim.x) { xb[0][t] = 0.f; xb[1][t] = 0.f; }
+  const int t = threadIdx.x;
+  const bool act = t < cells;
+  const int sz = (int)L.sz, sy = L.nx;
+  const int m = sz + t, mxm = m - 1, mxp = m + 1, mym = m - sy, myp = m + sy;
+  float d = 0.f, bb = 0.f, wxl = 0.f, wxc = 0.f, wyl = 0.f, wyc = 0.f, wzl = 0.f, wzc = 0.f;
+  if (act) {
+    d = (float)L.diag[m]; bb = b[m];
+    wxl = (float)L.wx[mxm]; wxc = (float)L.wx[m]; wyl = (float)L.wy[mym]; wyc = (float)L.wy[m]; wzl = (float)L.wz[m - sz]; wzc = (float)L.wz[m];
+  }
+  __syncthreads();
+  float c = (act && d > 0.f) ? L.omega * bb * rcp(d) : 0.f;  // sweep 1, from zero
+  if (act) xb[0][m] = c;
+  __syncthreads();
+  for (int it = 2; it <= sweeps; ++it) {
+    const float* xi = xb[it & 1];      // written by sweep it - 1
+    float* xo = xb[(it & 1) ^ 1];
+    float o = 0.f;
+    if (act && d > 0.f) {
+      float s_ = wxl * xi[mxm];
+      s_ += wxc * xi[mxp];
+      s_ += wyl * xi[mym];
+      s_ += wyc * xi[myp];
+      s_ += wzl * xi[m - sz];
+      s_ += wzc * xi[m + sz];
+      o = c + L.omega * (bb - (d * c - s_)) * rcp(d);
+    }
+    if (act) xo[m] = o;
+    c = o;
+    __syncthreads();
+  }
+  if (act) out[m] = c;
+}
+
 // ------------------------------ plain fine-level kernels (cross-check of the tiled ones) ------------------------------
 // fine vectors live in the pitched / ghost-plane layout; b vanishes on non-free cells and its
 // ghost planes hold the neighbours' values.   r1 = b - A (w b / code)
@@ -588,6 +631,7 @@ struct MgHierarchy {
   float scale = kScale;
   float omega = kOmega;
   bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
+  bool coarsest_plain = false;  // cross-check: one launch per sweep on the coarsest level instead of k_mg_coarsest
   int nu_coarse = 1;    // damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (1 or 2)
   bool failed = false;
 };
@@ -682,6 +726,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   if (g.tune.mg_omega > 0.f && g.tune.mg_omega < 1.f) mg->omega = g.tune.mg_omega;
   mg->novec4 = g.tune.mg_novec4 != 0;
   mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
+  mg->coarsest_plain = g.tune.mg_coarsest_plain != 0;
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
     L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
@@ -795,6 +840,10 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   MgLevelHost& L = Ls[l];
   const int kfirst = 1;
   if (l == (int)Ls.size() - 1) {  // coarsest: a fixed number of damped-Jacobi sweeps, the last one lands in `out`
+    if (!mg->periodic && (!mg->comm || L.replicated) && !L.compact && !mg->coarsest_plain && L.d.sz * L.d.nzl <= 512 && L.d.sz <= 512) {
+      hipLaunchKernelGGL((k_mg_coarsest<float, float>), dim3(1), dim3(512), 0, s, L.dev<float, float>(), rhs, out, kCoarsestSweeps);
+      return true;
+    }
     for (int it = 1; it <= kCoarsestSweeps; ++it) {
       const bool to_out = ((kCoarsestSweeps - it) & 1) == 0;
       float* dst = to_out ? out : L.r;
