@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import openimpala_amd as oia
 if len(sys.argv) > 1 and sys.argv[1] == "dirty":
-    bufs = [oia.gen_bernoulli_device((1024, 1024, 1024 * 8), 1 + k, 0.5) for k in range(28)]   # 28 x 8.6 GB, every byte written
+    bufs = [oia.gen_bernoulli_device((1024, 1024, 1024 * 8), 1 + k, 0.5) for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 28)]   # N x 8.6 GB, every byte written
     print("dirtied", sum(1 for _ in bufs) * 8.6, "GB; free now", oia.device_memory()[0] / 1e9)
     sys.exit(0)
 n = 1024
