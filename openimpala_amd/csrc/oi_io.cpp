@@ -8,7 +8,7 @@
 //               planar config; 1-bit data honours FILLORDER and ignores PHOTOMETRIC;
 //               voxel > threshold -> 1 else 0.
 //               Encodings decoded here (what libtiff decodes for the reference): none, LZW (5),
-//               Deflate (8 / 32946, zlib), PackBits (32773), horizontal predictor (317 = 2), floating-point predictor (317 = 3);
+//               Deflate (8 / 32946, zlib), PackBits (32773), baseline JPEG (7, with JPEGTables), horizontal predictor (317 = 2), floating-point predictor (317 = 3);
 //               classic TIFF and BigTIFF, both byte orders.  Anything else is reported, never guessed.
 //   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
 #include <fcntl.h>
@@ -101,6 +101,7 @@ struct Ifd {
   uint32_t w = 0, h = 0, bps = 1, comp = 1, spp = 1, rps = 0, fmt = 1, fill = 1, planar = 1, predictor = 1;
   uint32_t tile_w = 0, tile_h = 0;
   std::vector<uint64_t> offs, counts;
+  std::vector<uint8_t> jpeg_tables;  // tag 347: abbreviated table-specification stream shared by the strips / tiles (compression 7)
   bool tiled = false;
 };
 
@@ -165,11 +166,269 @@ bool parse_ifd(const File& f, size_t off, Ifd& ifd, size_t& next) {
       case 324: ifd.offs = v; ifd.tiled = true; break;
       case 325: ifd.counts = v; ifd.tiled = true; break;
       case 339: ifd.fmt = (uint32_t)v[0]; break;
+      case 347: ifd.jpeg_tables.resize(v.size()); for (size_t i = 0; i < v.size(); ++i) ifd.jpeg_tables[i] = (uint8_t)v[i]; break;
       default: break;
     }
   }
   const size_t np = off + cnt_bytes + ent_bytes * (size_t)n;
   next = f.big ? (size_t)f.u64(np) : f.u32(np);
+  return true;
+}
+
+// ---- baseline JPEG (TIFF compression 7, "new-style" JPEG-in-TIFF; TIFF Technical Note 2) ----
+// What libtiff + libjpeg decode for the reference when a tomogram was saved with JPEG compression: every strip / tile is a JPEG
+// stream of its own (SOI ... EOI), usually abbreviated -- the quantisation and Huffman tables sit once in the JPEGTables tag.
+// Decoded here: sequential DCT, Huffman coding, 8-bit precision, ONE component (the readers take one sample per pixel only),
+// restart intervals; the inverse DCT is libjpeg's default integer one ("islow", Loeffler-Ligtenberg-Moschytz with 13-bit
+// constants: what jpeg_idct_islow and libjpeg-turbo's SIMD versions of it compute).  Progressive, arithmetic-coded, 12-bit and
+// multi-component streams and old-style JPEG (compression 6) are reported.
+struct JpegTables {
+  uint16_t q[4][64] = {};   // quantisation tables in natural (de-zigzagged) order
+  bool have_q[4] = {false, false, false, false};
+  struct Huff { uint8_t bits[17] = {}; uint8_t vals[256] = {}; int mincode[17] = {}, maxcode[18] = {}, valptr[17] = {}; bool ok = false; } dc[4], ac[4];
+  int restart = 0;
+};
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+bool jpeg_build_huff(JpegTables::Huff& h) {
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    h.valptr[l] = k;
+    h.mincode[l] = code;
+    code += h.bits[l];
+    k += h.bits[l];
+    h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+    if (code > (1 << l)) return false;  // over-subscribed
+    code <<= 1;
+  }
+  h.maxcode[17] = 0x7fffffff;
+  h.ok = k <= 256;
+  return h.ok;
+}
+
+// the marker segments of one stream up to (and including the header of) SOS; returns the offset of the entropy-coded data
+struct JpegFrame { int w = 0, h = 0, tq = 0, td = 0, ta = 0; bool have_sof = false; };
+bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& fr, size_t& data_off, bool tables_only, std::string& why) {
+  size_t i = 0;
+  if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) { why = "no SOI marker"; return false; }
+  i = 2;
+  while (i + 4 <= n) {
+    if (p[i] != 0xFF) { why = "marker expected"; return false; }
+    const unsigned m = p[i + 1];
+    if (m == 0xFF) { ++i; continue; }  // fill byte
+    if (m == 0xD9) { data_off = i; return tables_only; }  // EOI: fine for a tables-only stream
+    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
+    const size_t len = (size_t)p[i + 2] << 8 | p[i + 3];
+    if (len < 2 || i + 2 + len > n) { why = "truncated marker segment"; return false; }
+    const uint8_t* s = p + i + 4;
+    const size_t sl = len - 2;
+    if (m == 0xDB) {  // DQT
+      size_t o = 0;
+      while (o < sl) {
+        const int pq = s[o] >> 4, tq = s[o] & 15;
+        ++o;
+        if (tq > 3 || pq > 1 || o + (pq ? 128 : 64) > sl) { why = "bad quantisation table"; return false; }
+        for (int z = 0; z < 64; ++z) {
+          t.q[tq][kZigzag[z]] = pq ? (uint16_t)(s[o] << 8 | s[o + 1]) : s[o];
+          o += pq ? 2 : 1;
+        }
+        t.have_q[tq] = true;
+      }
+    } else if (m == 0xC4) {  // DHT
+      size_t o = 0;
+      while (o < sl) {
+        if (o + 17 > sl) { why = "bad Huffman table"; return false; }
+        const int tc = s[o] >> 4, th = s[o] & 15;
+        if (tc > 1 || th > 3) { why = "bad Huffman table id"; return false; }
+        JpegTables::Huff& h = tc ? t.ac[th] : t.dc[th];
+        int total = 0;
+        h.bits[0] = 0;
+        for (int l = 1; l <= 16; ++l) { h.bits[l] = s[o + l]; total += h.bits[l]; }
+        o += 17;
+        if (total > 256 || o + (size_t)total > sl) { why = "bad Huffman table"; return false; }
+        memcpy(h.vals, s + o, (size_t)total);
+        o += (size_t)total;
+        if (!jpeg_build_huff(h)) { why = "inconsistent Huffman table"; return false; }
+      }
+    } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: sequential, Huffman
+      if (sl < 6) { why = "bad frame header"; return false; }
+      const int prec = s[0], nc = s[5];
+      fr.h = s[1] << 8 | s[2];
+      fr.w = s[3] << 8 | s[4];
+      if (prec != 8) { why = "JPEG sample precision " + std::to_string(prec) + " (8 is read)"; return false; }
+      if (nc != 1 || sl < 9) { why = std::to_string(nc) + "-component JPEG (one sample per pixel is read)"; return false; }
+      fr.tq = s[8] & 3;
+      fr.have_sof = true;
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      why = m == 0xC2 ? "progressive JPEG" : "JPEG process SOF" + std::to_string(m - 0xC0) + " (baseline / extended sequential Huffman are read)";
+      return false;
+    } else if (m == 0xDD) {  // DRI
+      if (sl < 2) { why = "bad restart interval"; return false; }
+      t.restart = s[0] << 8 | s[1];
+    } else if (m == 0xDA) {  // SOS
+      if (sl < 6 || s[0] != 1) { why = "bad scan header"; return false; }
+      fr.td = s[2] >> 4; fr.ta = s[2] & 15;
+      if (fr.td > 3 || fr.ta > 3) { why = "bad scan header"; return false; }
+      data_off = i + 2 + len;
+      return !tables_only;
+    }
+    i += 2 + len;
+  }
+  why = tables_only ? "" : "no scan in the JPEG stream";
+  data_off = n;
+  return tables_only;
+}
+
+// libjpeg's jpeg_idct_islow on one dequantised block (natural order), output samples 0..255
+void jpeg_idct_islow(const int* in, uint8_t* out, size_t stride) {
+  constexpr int CB = 13, P1 = 2;
+  constexpr long F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137,
+                 F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };
+  long ws[64];
+  for (int c = 0; c < 8; ++c) {
+    const int* ip = in + c;
+    long* wp = ws + c;
+    if (!(ip[8] | ip[16] | ip[24] | ip[32] | ip[40] | ip[48] | ip[56])) {
+      const long dc = (long)ip[0] * (1L << P1);
+      for (int r = 0; r < 8; ++r) wp[8 * r] = dc;
+      continue;
+    }
+    long z2 = ip[16], z3 = ip[48];
+    long z1 = (z2 + z3) * F0541;
+    long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    z2 = ip[0]; z3 = ip[32];
+    long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = ip[56]; tmp1 = ip[40]; tmp2 = ip[24]; tmp3 = ip[8];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1175;
+    tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+    z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    wp[0] = descale(tmp10 + tmp3, CB - P1); wp[56] = descale(tmp10 - tmp3, CB - P1);
+    wp[8] = descale(tmp11 + tmp2, CB - P1); wp[48] = descale(tmp11 - tmp2, CB - P1);
+    wp[16] = descale(tmp12 + tmp1, CB - P1); wp[40] = descale(tmp12 - tmp1, CB - P1);
+    wp[24] = descale(tmp13 + tmp0, CB - P1); wp[32] = descale(tmp13 - tmp0, CB - P1);
+  }
+  for (int r = 0; r < 8; ++r) {
+    const long* wp = ws + 8 * r;
+    uint8_t* op = out + (size_t)r * stride;
+    auto clamp = [](long v) { v += 128; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+    long z2 = wp[2], z3 = wp[6];
+    long z1 = (z2 + z3) * F0541;
+    long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    long tmp0 = (wp[0] + wp[4]) * (1L << CB), tmp1 = (wp[0] - wp[4]) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = wp[7]; tmp1 = wp[5]; tmp2 = wp[3]; tmp3 = wp[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1175;
+    tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+    z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    constexpr int SH = CB + P1 + 3;
+    op[0] = clamp(descale(tmp10 + tmp3, SH)); op[7] = clamp(descale(tmp10 - tmp3, SH));
+    op[1] = clamp(descale(tmp11 + tmp2, SH)); op[6] = clamp(descale(tmp11 - tmp2, SH));
+    op[2] = clamp(descale(tmp12 + tmp1, SH)); op[5] = clamp(descale(tmp12 - tmp1, SH));
+    op[3] = clamp(descale(tmp13 + tmp0, SH)); op[4] = clamp(descale(tmp13 - tmp0, SH));
+  }
+}
+
+// one strip / tile: `src` is its JPEG stream, `tables` the stream of the JPEGTables tag (may be empty); out = expect_w x expect_h
+// 8-bit samples, row-major.  false + why on anything that is not a one-component sequential Huffman stream of that size.
+bool unjpeg(const uint8_t* src, size_t n, const std::vector<uint8_t>& tables, std::vector<uint8_t>& out, size_t expect_w, size_t expect_h,
+            std::string& why) {
+  JpegTables t;
+  JpegFrame fr;
+  size_t off = 0;
+  if (!tables.empty() && !jpeg_parse_segments(tables.data(), tables.size(), t, fr, off, true, why)) {
+    if (why.empty()) why = "bad JPEGTables";
+    return false;
+  }
+  fr = JpegFrame();
+  if (!jpeg_parse_segments(src, n, t, fr, off, false, why)) return false;
+  if (!fr.have_sof || fr.w <= 0 || fr.h <= 0) { why = "no frame header"; return false; }
+  if ((size_t)fr.w != expect_w || (size_t)fr.h > expect_h) { why = "JPEG frame size differs from the strip / tile"; return false; }
+  if (!t.have_q[fr.tq] || !t.dc[fr.td].ok || !t.ac[fr.ta].ok) { why = "missing quantisation / Huffman table"; return false; }
+  const size_t bw = ((size_t)fr.w + 7) / 8, bh = ((size_t)fr.h + 7) / 8;
+  std::vector<uint8_t> img(bw * 8 * bh * 8);
+  // entropy-coded segment: MSB-first bits, FF00 = a data byte FF, RSTn between restart intervals
+  size_t pos = off;
+  uint32_t acc = 0;
+  int nbits = 0;
+  bool hit_marker = false;
+  auto fill = [&]() {
+    while (nbits <= 24) {
+      unsigned b = 0;
+      if (!hit_marker && pos < n) {
+        b = src[pos];
+        if (b == 0xFF) {
+          if (pos + 1 < n && src[pos + 1] == 0x00) pos += 2;
+          else { hit_marker = true; b = 0; }   // a marker: feed zeros, the caller checks for RSTn / EOI
+        } else {
+          ++pos;
+        }
+      }
+      acc |= (uint32_t)b << (24 - nbits);
+      nbits += 8;
+    }
+  };
+  auto getbits = [&](int c) -> int {
+    if (c == 0) return 0;
+    if (nbits < c) fill();
+    const int v = (int)(acc >> (32 - c));
+    acc <<= c;
+    nbits -= c;
+    return v;
+  };
+  auto decode = [&](const JpegTables::Huff& h) -> int {
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+      code = code << 1 | getbits(1);
+      if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return -1;
+  };
+  auto extend = [](int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; };
+  int pred = 0, blk[64];
+  size_t mcu = 0;
+  for (size_t by = 0; by < bh; ++by)
+    for (size_t bx = 0; bx < bw; ++bx, ++mcu) {
+      if (t.restart && mcu && mcu % (size_t)t.restart == 0) {  // RSTn: byte-align, skip the marker, reset the predictor
+        acc = 0; nbits = 0; hit_marker = false;
+        while (pos + 1 < n && !(src[pos] == 0xFF && src[pos + 1] >= 0xD0 && src[pos + 1] <= 0xD7)) ++pos;
+        if (pos + 1 >= n) { why = "missing restart marker"; return false; }
+        pos += 2;
+        pred = 0;
+      }
+      for (int k = 0; k < 64; ++k) blk[k] = 0;
+      const int s = decode(t.dc[fr.td]);
+      if (s < 0 || s > 11) { why = "corrupt JPEG data (DC)"; return false; }
+      pred += extend(getbits(s), s);
+      blk[0] = pred * t.q[fr.tq][0];
+      for (int k = 1; k < 64;) {
+        const int rs = decode(t.ac[fr.ta]);
+        if (rs < 0) { why = "corrupt JPEG data (AC)"; return false; }
+        const int r = rs >> 4, sz = rs & 15;
+        if (sz == 0) {
+          if (r != 15) break;  // EOB
+          k += 16;
+          continue;
+        }
+        k += r;
+        if (k > 63) { why = "corrupt JPEG data (run)"; return false; }
+        blk[kZigzag[k]] = extend(getbits(sz), sz) * t.q[fr.tq][kZigzag[k]];
+        ++k;
+      }
+      jpeg_idct_islow(blk, img.data() + (by * 8) * (bw * 8) + bx * 8, bw * 8);
+    }
+  out.assign(expect_w * expect_h, 0);
+  for (size_t y = 0; y < (size_t)fr.h && y < expect_h; ++y) memcpy(out.data() + y * expect_w, img.data() + y * bw * 8, expect_w);
   return true;
 }
 
@@ -379,9 +638,13 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
     oi::set_error("'%s': page %zu differs in size/depth from page 0", path, k);
     return OI_IO_ERROR;
   }
-  const bool known = pg.comp == 1 || pg.comp == 5 || pg.comp == 8 || pg.comp == 32946 || pg.comp == 32773;
+  const bool known = pg.comp == 1 || pg.comp == 5 || pg.comp == 8 || pg.comp == 32946 || pg.comp == 32773 || pg.comp == 7;
   if (!known) {
-    oi::set_error("'%s': TIFF compression %u is not supported (none, LZW, Deflate and PackBits are)", path, pg.comp);
+    oi::set_error("'%s': TIFF compression %u is not supported (none, LZW, Deflate, PackBits and baseline JPEG are)", path, pg.comp);
+    return OI_IO_ERROR;
+  }
+  if (pg.comp == 7 && (pg.bps != 8 || pg.fmt != 1)) {
+    oi::set_error("'%s': JPEG-compressed TIFF with %u-bit samples of format %u (8-bit unsigned is read)", path, pg.bps, pg.fmt);
     return OI_IO_ERROR;
   }
   const bool float_pred = pg.predictor == 3 && pg.fmt == 3 && (pg.bps == 32 || pg.bps == 64) && pg.spp == 1;
@@ -414,7 +677,11 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
       size_t avail = n;
       if (pg.comp != 1 || pg.predictor != 1) {
         bool ok = true;
-        if (pg.comp == 32773) ok = unpackbits(src, n, buf, expect);
+        std::string jwhy;
+        if (pg.comp == 7) {
+          ok = unjpeg(src, n, pg.jpeg_tables, buf, cw, rows_here, jwhy);
+          if (!ok) { oi::set_error("'%s': JPEG strip / tile of page %zu: %s", path, k, jwhy.c_str()); return OI_IO_ERROR; }
+        } else if (pg.comp == 32773) ok = unpackbits(src, n, buf, expect);
         else if (pg.comp == 5) ok = unlzw(src, n, buf, expect);
         else if (pg.comp == 8 || pg.comp == 32946) ok = uninflate(src, n, buf, expect);
         else buf.assign(src, src + std::min<size_t>(n, expect));

@@ -220,17 +220,79 @@ def test_tiff_reader_floating_point_predictor(tmp_path, compression):
     assert np.array_equal(got, (vol.astype(np.float64) > thr).astype(np.uint8)) and 0 < got.mean() < 1
 
 
-def test_tiff_reader_rejects_what_it_cannot_decode(tmp_path):
+def _jpeg_volume(seed, shape):
+    rng = np.random.default_rng(seed)
+    v = np.cumsum(rng.integers(-9, 10, size=shape), axis=2) + 128 + np.cumsum(rng.integers(-5, 6, size=shape), axis=1)
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("quality,rps", [(90, None), (60, 8), (100, 24)])
+def test_tiff_reader_jpeg_compressed_stacks(tmp_path, quality, rps):
+    """Compression 7 (JPEG-in-TIFF with a JPEGTables tag) on 8-bit stacks written by libtiff + libjpeg: one or several strips per
+    page, extents that are no multiples of 8.  Expected voxels = libtiff's own decode of the same file; the decoder here
+    (sequential Huffman, libjpeg's integer inverse DCT) reproduces it EXACTLY, so every threshold agrees."""
     Image = _pil()
-    a = (np.arange(64 * 64) % 256).astype(np.uint8).reshape(64, 64)
+    vol = _jpeg_volume(5, (3, 83, 131))
+    pages = [Image.fromarray(v) for v in vol]
     p = tmp_path / "jpeg.tif"
+    kw = dict(format="TIFF", compression="jpeg", quality=quality, save_all=True, append_images=pages[1:])
+    if rps:
+        kw["tiffinfo"] = {278: rps}
     try:
-        Image.fromarray(a).save(p, format="TIFF", compression="jpeg")
+        pages[0].save(p, **kw)
     except Exception:
         pytest.skip("libtiff without JPEG")
-    with pytest.raises(oia.OpenImpalaError) as e:
-        oia.TiffReader(str(p)).threshold(1.0)
-    assert "compression" in str(e.value)
+    with Image.open(p) as im:
+        assert im.tag_v2.get(259) == 7
+    expect = np.stack([_page(Image, p, k) for k in range(vol.shape[0])])
+    assert np.abs(expect.astype(int) - vol.astype(int)).max() < 80     # lossy, but the same picture
+    for thr in (60.5, 100.5, 127.5, 128.5, 170.5):
+        got = oia.TiffReader(str(p)).threshold(thr)
+        assert np.array_equal(got, (expect > thr).astype(np.uint8)), thr
+    assert np.array_equal(oia.TiffReader(str(p)).threshold(128.5, z0=1, nz_local=2), (expect[1:] > 128.5).astype(np.uint8))
+
+
+def test_tiff_reader_jpeg_restart_intervals_and_refusals(tmp_path):
+    """A JPEG strip with restart markers (DRI; written by libjpeg through Pillow's JPEG writer, wrapped into a TIFF by hand: a
+    self-contained stream, no JPEGTables tag) decodes to libjpeg's own pixels; progressive streams and colour images are named."""
+    Image = _pil()
+    import io, struct
+    a = _jpeg_volume(9, (1, 64, 96))[0]
+
+    def wrap(jpeg_bytes, w, h):   # classic little-endian TIFF, one strip
+        tags = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 8), (259, 3, 1, 7), (262, 3, 1, 1), (273, 4, 1, 8), (277, 3, 1, 1),
+                (278, 3, 1, h), (279, 4, 1, len(jpeg_bytes))]
+        ifd_off = 8 + len(jpeg_bytes) + (len(jpeg_bytes) & 1)
+        out = b"II" + struct.pack("<HI", 42, ifd_off) + jpeg_bytes + (b"\0" if len(jpeg_bytes) & 1 else b"")
+        out += struct.pack("<H", len(tags))
+        for tag, typ, cnt, val in tags:
+            out += struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+        return out + struct.pack("<I", 0)
+
+    for name, kw, ok in (("restart", dict(quality=85, restart_marker_blocks=5), True), ("plain", dict(quality=75), True),
+                         ("progressive", dict(quality=85, progressive=True), False)):
+        buf = io.BytesIO()
+        try:
+            Image.fromarray(a).save(buf, format="JPEG", **kw)
+        except Exception:
+            pytest.skip("Pillow without these JPEG options")
+        data = buf.getvalue()
+        if name == "restart" and b"\xff\xdd" not in data:
+            pytest.skip("this Pillow does not write restart intervals")
+        p = tmp_path / f"{name}.tif"
+        p.write_bytes(wrap(data, a.shape[1], a.shape[0]))
+        if ok:
+            expect = np.array(Image.open(io.BytesIO(data)))
+            for thr in (100.5, 128.5, 150.5):
+                assert np.array_equal(oia.TiffReader(str(p)).threshold(thr)[0], (expect > thr).astype(np.uint8)), (name, thr)
+        else:
+            with pytest.raises(oia.OpenImpalaError) as e:
+                oia.TiffReader(str(p)).threshold(1.0)
+            assert "progressive" in str(e.value)
+    rgb = tmp_path / "rgb.tif"
+    Image.fromarray(np.stack([a] * 3, axis=-1)).save(rgb, format="TIFF", compression="jpeg")
+    with pytest.raises(oia.OpenImpalaError):   # three samples per pixel: refused like every multi-sample TIFF (TiffReader.cpp:167-173)
+        oia.TiffReader(str(rgb)).threshold(1.0)
 
 
 def test_readers_load_a_z_slab_only(tmp_path):

@@ -64,6 +64,22 @@ def test_corrupted_and_crafted_files_under_sanitizers(drivers, tmp_path):
     for name, data in crafted.items():
         (tmp_path / name).write_bytes(data)
         paths.append(str(tmp_path / name))
+    # JPEG-compressed strips (round 3: the Huffman / inverse-DCT decoder): corrupted and truncated copies of a libtiff-written stack
+    try:
+        from PIL import Image, features
+        if features.check("libtiff"):
+            jv = np.clip(np.cumsum(np.random.default_rng(2).integers(-9, 10, size=(2, 40, 70)), axis=2) + 128, 0, 255).astype(np.uint8)
+            jp = tmp_path / "jpeg_src.tif"
+            Image.fromarray(jv[0]).save(jp, format="TIFF", compression="jpeg", quality=80, save_all=True, append_images=[Image.fromarray(jv[1])],
+                                        tiffinfo={278: 16})
+            jsrc = jp.read_bytes()
+            paths.append(str(jp))
+            for t in range(90):
+                q = tmp_path / f"j{t}.tif"
+                q.write_bytes(bytes(corrupt(jsrc, t, rng)))
+                paths.append(str(q))
+    except Exception:
+        pass
     out = run([reader, "tiff", "-"] + paths)
     assert out.strip().endswith("batch done") and len(out.splitlines()) == len(paths) + 1
     arr = (np.random.default_rng(1).random((12, 20, 28)) * 255).astype(np.uint8)
