@@ -311,13 +311,12 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
     size_t mg_bytes = 0;
     h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);
     if (!h->mg) return OI_HIP_ERROR;
-    // even nx: a thread's x pair never straddles the periodic seam, the LDS-tiled kernels of the flow-through path wrap
-    // x / y by index -> their fused two-kernel iteration (needs a second p buffer).  Odd ny / nz are fine (round 3: the
-    // coarse parent of the image planes beyond an odd nz is the coarse ghost plane, cplane_of in k_mg_fine)
-    h->fused = (nx & 1) == 0 && !g.tune.mg_plain;
-  } else if (h->n_active > 0 && (nx & 1) == 0 && nx >= 4 && ny >= 2 && !g.tune.mg_plain) {
-    // plain CG (precond = none / jacobi is not offered here): the same two-kernel iteration with z = r.  Only x must be
-    // even (a thread owns an x pair, which must not straddle the seam); y and z wrap by row / through the ghost planes
+    // the LDS-tiled kernels of the flow-through path wrap x / y by index -> their fused two-kernel iteration (needs a second p
+    // buffer).  Odd extents included (round 3): the coarse parent of the image planes beyond an odd nz is the coarse ghost plane
+    // (cplane_of in k_mg_fine), and with an odd nx the pair (nx - 1, pad) keeps the wrapped column 0 in its second LDS slot
+    h->fused = !g.tune.mg_plain;
+  } else if (h->n_active > 0 && nx >= 4 && ny >= 2 && !g.tune.mg_plain) {
+    // plain CG (precond = none / jacobi is not offered here): the same two-kernel iteration with z = r
     h->fused = true;
   }
   if (h->fused) {

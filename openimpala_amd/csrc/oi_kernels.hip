@@ -994,8 +994,11 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
     double* T = tile[b];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
-      if (!(per && (i == g.nx || j0 + w + rr_ * kNW == g.ny)))  // (that slot holds the wrapped column / row)
-        *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+      if (!(per && (i == g.nx || j0 + w + rr_ * kNW == g.ny))) {  // (that slot holds the wrapped column / row)
+        // odd nx, periodic: the pair (nx - 1, nx) straddles the seam -- its second slot holds the wrapped column 0 (wave 2)
+        if (per && i + 1 == g.nx) T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane] = pn[rr_].x;
+        else *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+      }
     if (PURE && LEAN == 0) {  // any v: nothing decides the halo loads
       if (w < 2) {
         double2 h = make_double2(0.0, 0.0);
@@ -1095,7 +1098,9 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
         const long long ev = (!PURE && COMPACT) ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e;  // q, p_out (x stays at e)
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 pc = pn_cur[rr_];
-        const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
+        // odd nx, periodic: the +x neighbour of voxel nx - 1 is the wrapped column 0, staged in the pair's second slot
+        const double pxp = (per && i + 1 == g.nx) ? T[base + 1] : pc.y;
+        const double s0 = ((((lf.y + pxp) + ym.x) + yp.x) + pn_prev[rr_].x) + pn_nxt[rr_].x;
         const double s1 = ((((pc.x + rt.x) + ym.y) + yp.y) + pn_prev[rr_].y) + pn_nxt[rr_].y;
         const double q0 = c0 ? (double)c0 * pc.x - s0 : 0.0;
         const double q1 = c1 ? (double)c1 * pc.y - s1 : 0.0;
@@ -1593,8 +1598,10 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
     double* T = tile[bsel];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_)
-      if (!(per && (i == g.nx || j0 + w + rr_ * kNW == g.ny)))  // (that slot holds the wrapped column / row)
-        *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = vn[rr_];
+      if (!(per && (i == g.nx || j0 + w + rr_ * kNW == g.ny))) {  // (that slot holds the wrapped column / row)
+        if (per && i + 1 == g.nx) T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane] = vn[rr_].x;  // (odd nx: see k_fused_a)
+        else *reinterpret_cast<double2*>(&T[(w + rr_ * kNW + 1) * kLP + 2 + 2 * lane]) = vn[rr_];
+      }
     // halo code bytes and slots were fetched a plane ahead (load_halo_codes, see k_cg1)
     if (w < 2) {
       double2 h = make_double2(0.0, 0.0);
@@ -1690,7 +1697,8 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 vc = v_cur[rr_], bc = b_cur[rr_];
-        const double s0 = ((((lf.y + vc.y) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
+        const double vxp = (per && i + 1 == g.nx) ? T[base + 1] : vc.y;  // (odd nx, periodic: see k_fused_a)
+        const double s0 = ((((lf.y + vxp) + ym.x) + yp.x) + v_prev[rr_].x) + v_nxt[rr_].x;
         const double s1 = ((((vc.x + rt.x) + ym.y) + yp.y) + v_prev[rr_].y) + v_nxt[rr_].y;
         double o0 = 0.0, o1 = 0.0;
         if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + (bc.x - av) * wtab[c0]; }

@@ -913,10 +913,10 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   MgLevelHost& C = Ls[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   const bool transition = mg->comm && C.replicated;  // owned contributions are summed across ranks afterwards
-  // periodic problem: the LDS-tiled fine kernels wrap x / y by index when nx is even (a thread's x pair must not straddle
-  // the seam; odd ny / nz only leave a single row / plane in the last aggregates, as in the open problem); an odd nx
-  // takes the plain kernels
-  if (mg->periodic && !(g.periodic && (g.nx & 1) == 0)) tiled = 0;
+  // periodic problem: the LDS-tiled fine kernels wrap x / y by index; odd extents leave a single column / row / plane in the
+  // last aggregates as in the open problem, and with an odd nx the pair (nx - 1, pad) keeps the wrapped column 0 in its
+  // second LDS slot (k_fused_a, k_mg_fine)
+  if (mg->periodic && !g.periodic) tiled = 0;
   if (tiled && (g.z0 & 1) == 0) {
     // pre-smoothing residual and its restriction in one pass: the residual itself is never stored
     if (transition) (void)hipMemsetAsync(C.b, 0, sizeof(float) * C.n, s);

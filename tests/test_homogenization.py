@@ -130,7 +130,7 @@ def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
     planes), odd sizes leave single-child aggregates next to the wrap.  Same chi and tensor, far fewer iterations.
     Even extents run the flow-through path's LDS-tiled kernels and fused two-kernel iteration with x / y wrapped by
     index (domain ends inside a tile: 18 and 40 rows over 16-row tiles, 130 and 300 columns over 128-column tiles), also
-    with odd ny / nz (round 3: the last three shapes); an odd nx takes the plain kernels."""
+    with odd extents (round 3: odd ny / nz -- the last three shapes -- and odd nx, (25, 31, 33))."""
     import openimpala_amd as oia
     nz, ny, nx = shape
     sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
@@ -185,11 +185,12 @@ def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, oi_option, nranks,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(36, 52, 172), (35, 51, 132), (33, 40, 20), (40, 37, 64)])
+@pytest.mark.parametrize("shape", [(36, 52, 172), (35, 51, 132), (33, 40, 20), (40, 37, 64), (36, 52, 171), (33, 41, 67), (20, 24, 129), (16, 16, 127)])
 def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, oi_option, shape):
     """The two kernel families behind OI_PRECOND_MG on the cell problems (OI_MG_PLAIN selects the plain one): same
-    iteration counts, chi fields equal to solver tolerance.  Round 3: odd ny / nz run the tiled kernels too (an odd nx
-    still takes the plain ones): a single row / plane in the last aggregates, image planes beyond an odd nz."""
+    iteration counts, chi fields equal to solver tolerance.  Round 3: odd extents run the tiled kernels too: a single column /
+    row / plane in the last aggregates, image planes beyond an odd nz, and with an odd nx the x pair (nx - 1, pad) whose second
+    LDS slot holds the wrapped column 0 (domain end inside a tile: 171, 67; one voxel past / before a tile boundary: 129, 127)."""
     import openimpala_amd as oia
     nz, ny, nx = shape
     sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
