@@ -2042,6 +2042,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kOob = 0x7ffff000;          // lane offset that every descriptor's range check rejects
+#ifndef OI_CG1B_EARLY
+#define OI_CG1B_EARLY 1   // 0: the first form (requests at the top of the iteration), kept for A/B builds (tools/early_issue_ab.sh)
+#endif
 constexpr long long kBufMax = 0x7fff0000;  // largest range (bytes) a descriptor may cover here
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* p, long long bytes) {
@@ -2410,9 +2413,19 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   auto pf_at = [&](int p) { return plane_first[min(p, g.nzl + 2)]; };
   long long pfm = pf_at(gs - 1), pf0 = pf_at(gs), pf1 = pf_at(gs + 1), pf2 = pf_at(gs + 2);
   int b_prev = 0, b_cur = TS, b_nxt = 2 * TS;  // ring positions (doubles) of planes gz - 1, gz, gz + 1
+  // OI_CG1B_EARLY: the vectors of plane gz + 2 (and its halo) are requested at the END of iteration gz, before the barrier, not
+  // at the top of iteration gz + 1: they are in flight while the block waits at the barrier and while the next iteration
+  // requests its code bytes and records -- the one memory round trip of a plane step starts that much earlier.  The raw
+  // values live across the barrier; the peak register demand (the stencil of plane gz) lies before the requests.
+  // (FORM 0 has no registers to spare for it: 86 spills at the 128-register budget; FORM 1 / 2 take it with 109 / 111)
+  constexpr bool kEarly = (OI_CG1B_EARLY != 0) && FORM != 0;
+  Raw raw_e;   // (kEarly only: the requests of a plane outlive the iteration that makes them; FORM 0 keeps iteration-local
+  HRaw hr_e;   // objects, whose registers are dead at the barrier)
   {
-    Raw raw;
-    HRaw hr;
+    Raw raw_p;
+    HRaw hr_p;
+    Raw& raw = raw_p;
+    HRaw& hr = hr_p;
     halo_codes_issue(gs, false);
     codes_issue(gs - 1, cc_nn, lo_nn, false);
     codes_issue(gs, cc_cur, lo_cur, false);
@@ -2427,6 +2440,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     stage_rows(tile + b_cur, pn_nxt);
     stage_halo(tile + b_cur, hr);
     halo_codes_issue(gs + 1, false);
+    if (kEarly) {  // plane gs + 1 for the first iteration
+      const int mode1 = gs + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
+      const int hoff1 = halo_offset(pf1);
+      plane_issue(gs + 1, cc_nxt, lo_nxt, pf1, pf2, raw_e, mode1);
+      if (gs + 1 < ge) halo_issue(pf1, pf2, hoff1, hr_e);
+    }
   }
   __syncthreads();
 
@@ -2453,18 +2472,20 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   };
   double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
-  for (int gz = gs; gz < ge; ++gz) {
+  auto step = [&](const int gz, Raw& raw, HRaw& hr) {
     // pf0 .. pf2 = first slots of planes gz, gz + 1, gz + 2
     const long long pf3 = pf_at(gz + 3);
     const int mode = gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
     const bool more = gz + 1 < ge;
-    Raw raw;
-    HRaw hr;
-    // every load of this iteration, back to back: plane gz + 1's vectors and halo, plane gz + 2's codes and slots
-    const int hoff = halo_offset(pf1);  // (first: the slot came with the previous iteration's loads, nothing newer is waited for)
-    __builtin_amdgcn_sched_barrier(0);
-    plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
-    if (more) halo_issue(pf1, pf2, hoff, hr);
+    if (!kEarly) {
+      // every load of this iteration, back to back: plane gz + 1's vectors and halo, plane gz + 2's codes and slots
+      const int hoff = halo_offset(pf1);  // (first: the slot came with the previous iteration's loads, nothing newer is waited for)
+      __builtin_amdgcn_sched_barrier(0);
+      plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
+      if (more) halo_issue(pf1, pf2, hoff, hr);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);  // (plane gz + 1's vectors and halo were requested before the barrier)
+    }
     const unsigned hcode_now = hcode;
     codes_issue(gz + 2, cc_nn, lo_nn, true);
     if (more) halo_codes_issue(gz + 2, true);
@@ -2549,7 +2570,24 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
     pf0 = pf1; pf1 = pf2; pf2 = pf3;
     { const int t = b_prev; b_prev = b_cur; b_cur = b_nxt; b_nxt = t; }
+    if (kEarly && gz + 1 < ge) {  // the next iteration's plane (gz + 2): its code bytes and slots have arrived and been rotated into *_nxt
+      const int mode2 = gz + 2 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
+      const int hoff2 = halo_offset(pf1);
+      __builtin_amdgcn_sched_barrier(0);
+      plane_issue(gz + 2, cc_nxt, lo_nxt, pf1, pf2, raw, mode2);
+      if (gz + 2 < ge) halo_issue(pf1, pf2, hoff2, hr);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
+  };
+  if (kEarly) {
+    for (int gz = gs; gz < ge; ++gz) step(gz, raw_e, hr_e);
+  } else {
+    for (int gz = gs; gz < ge; ++gz) {
+      Raw raw;
+      HRaw hr;
+      step(gz, raw, hr);
+    }
   }
   if (FORM == 1) {
     const double t = block_sum(s_pq, red);
