@@ -39,6 +39,7 @@ struct Tune {
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
   float mg_omega = 0.f;  // in (0, 1): Jacobi damping of the cycle (default 0.9)
+  int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)
   int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)
   int mg_nu_coarse = 1;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (1 or 2; the fine level: 1)
   int place_trials = 48; // single-kernel CG: vector placements (six of place_slots allocations made back to back) timed when
@@ -187,6 +188,9 @@ bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_fi
 int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in, double* r_out, const double* q, const double* hist, int k,
                          MgCoarse c, float* bcoarse, double omega, double* partials, const Ctrl* ctrl, const int* lineoff,
                          const long long* plane_first, const void* seg, hipStream_t s);
+// the fine post-smoother on compacted vectors, descriptor-addressed (k_cg1b FORM 3): what launch_mg_fine mode 2 computes
+int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale, double* z,
+                   double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s);
 // fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
 // (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)

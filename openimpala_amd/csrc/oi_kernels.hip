@@ -1729,6 +1729,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+static void fused_chunks(const Geom& g, long long cols, bool even, int* zchunk, int* nzc);
 // mode 1 = pre (out = b - A v), 2 = post (out = z, partial z.b); returns the number of partials
 // mode 3 = pre with the restriction fused in: `bcoarse` receives the block sums of the planes this slab
 // owns (needs an even g.z0: z pairs must not straddle the z chunks)
@@ -1740,7 +1741,10 @@ int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
   int zchunk, nzc;
-  pick_chunks(g, cols, mode == 3, &zchunk, &nzc);
+  // (the post-smoother takes the chunks of the two-kernel iteration, as its descriptor-addressed form launch_mg_post does: the
+  // partial sums of z.r -- and with them the iterates -- are then the same in the dense and the compacted layout)
+  if (mode == 2) fused_chunks(g, cols, false, &zchunk, &nzc);
+  else pick_chunks(g, cols, mode == 3, &zchunk, &nzc);
   if (!grid_fits(g, cols, nzc)) return -1;
   const int blocks = (int)(cols * nzc);
 #define OI_MGF(M, C)                                                                                                     \
@@ -2110,7 +2114,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
                                                     double* __restrict__ partials, Ctrl* ctrl,
                                                     const int* __restrict__ lineoff, const long long* __restrict__ plane_first,
                                                     const uint2* __restrict__ seg, int LW, int fullline,
-                                                    float* __restrict__ bcoarse, MgCoarse C, double omega) {
+                                                    float* __restrict__ bcoarse, MgCoarse C, double omega, double scale) {
   constexpr int BY = NW * R;
   constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
@@ -2121,7 +2125,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   // FORM 2: y-pair sums of the restriction (odd waves publish, even waves own the aggregates), omega / c for c = 0..6
   __shared__ double ysum[FORM == 2 ? 2 : 1][FORM == 2 ? R * (NW / 2) * 64 : 1];
   __shared__ double wtab[8];
-  if (FORM == 2) {
+  if (FORM >= 2) {
     static_assert(FORM != 2 || (NW & 1) == 0, "rows 2m and 2m+1 of a tile belong to waves w and w+1");
     if (threadIdx.x < 8) wtab[threadIdx.x] = threadIdx.x ? omega / (double)threadIdx.x : 0.0;
     __syncthreads();
@@ -2140,6 +2144,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   } else if (FORM == 2) {
     if (k > 0) alpha_prev = safe_div(rec[H_STRIDE * (k - 1) + H_RZ], rec[H_STRIDE * (k - 1) + H_PQ]);
+  } else if (FORM == 3) {
   } else if (k > 0) {
     double* rk1 = rec + R1_STRIDE * (k - 1);
     const Cg1Scalars sc = cg1_scalars_of(rk1, ctrl->tol2);
@@ -2153,7 +2158,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     beta = sc.beta;
   }
   if (FORM != 0) xskip = 0;  // (FORM 1: x takes alpha_{k-1} p_{k-1} in every launch)
-  const bool do_x = FORM == 2 ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
+  const bool do_x = FORM >= 2 ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
   if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
 
   const int lane = threadIdx.x & 63;
@@ -2246,8 +2251,18 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   };
   typedef typename PBuf<PT>::Pair PPair;
-  struct Raw { double2 r[R], q[R], xv[R]; PPair p[R], pold[R]; int off[R], xoff[R]; };
-  struct HRaw { double2 r, q; PPair p; typename PBuf<PT>::One p1; };
+  struct Raw { double2 r[R], q[R], xv[R]; PPair p[R], pold[R]; int off[R], xoff[R]; float c[R]; };
+  struct HRaw { double2 r, q; PPair p; typename PBuf<PT>::One p1; float c; };
+  // FORM 3: the fp32 coarse correction of the aggregate that holds a voxel pair (x pairs share it: i is even); the offset inside
+  // the coarse plane does not change along the march, the plane comes with the descriptor
+  auto cplane_of = [&](int gz) { return ((g.z0 + gz - 1) >> 1) - C.z0c + 1; };
+  auto corr_buf = [&](const float* a, int gz) { return buf_of(a + C.csz * cplane_of(gz), 4ll * C.csz); };
+  auto corr_ld = [&](int gz, int off) {
+    float cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(corr_buf(C.xc, gz), off, 0, 0));
+    if (C.xc2) cv += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(corr_buf(C.xc2, gz), off, 0, 0));
+    return cv;
+  };
+  const int hcoff = yhalo ? ((i >> 1) + C.cnx * (hrow >> 1)) * 4 : (xhalo ? ((xh_i >> 1) + C.cnx * (xh_row >> 1)) * 4 : kOob);
 
   // ---- issue every load of plane p: r, q, p of the tile rows; x and p_{k-2} where x is updated ----
   auto plane_issue = [&](int p, const unsigned short (&cn)[R], const int (&ln)[R], long long pfa, long long pfb, Raw& raw, int mode) {
@@ -2260,10 +2275,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const bool st = in_x && (fullline ? ln[rr_] >= 0 : cn[rr_] != 0);  // (ln = -1, cn = 0 on rows outside the volume)
       raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
       raw.r[rr_] = bld2(rb, raw.off[rr_]);
-      if (FORM != 1) raw.q[rr_] = bld2(qb, raw.off[rr_]);
+      if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2(qb, raw.off[rr_]);
       else raw.q[rr_] = make_double2(0.0, 0.0);
-      if (FORM != 2) raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
+      if (FORM < 2) raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
       else raw.p[rr_] = PPair();
+      raw.c[rr_] = 0.f;
+      if (FORM == 3) raw.c[rr_] = corr_ld(p, (in_x && cn[rr_]) ? ((i >> 1) + C.cnx * (row_of(rr_) >> 1)) * 4 : kOob);
     }
     if (with_x) {
       const __amdgpu_buffer_rsrc_t xb = x_buf(p);
@@ -2298,8 +2315,19 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     for (int rr_ = 0; rr_ < R; ++rr_) {
       // (a lane without a stored line read zeros: r0 = r1 = 0, p = 0, exactly what the branch of k_cg1 leaves there)
       const double2 rv = raw.r[rr_], qv = raw.q[rr_], pin = PBuf<PT>::wide(raw.p[rr_]);
-      const double r0 = FORM != 1 ? rv.x - alpha_prev * qv.x : rv.x, r1 = FORM != 1 ? rv.y - alpha_prev * qv.y : rv.y;
+      const double r0 = (FORM == 0 || FORM == 2) ? rv.x - alpha_prev * qv.x : rv.x, r1 = (FORM == 0 || FORM == 2) ? rv.y - alpha_prev * qv.y : rv.y;
       rn[rr_] = make_double2(r0, r1);
+      if (FORM == 3) {  // what is staged is v = omega b / c + s * (coarse correction of the pair's aggregate)   (k_mg_fine, MODE 2)
+        const unsigned short cc = cn[rr_];
+        double v0 = r0 * wtab[cc & 0xffu], v1 = r1 * wtab[cc >> 8];
+        if (cc) {
+          const double cr = scale * (double)raw.c[rr_];
+          if (cc & 0xffu) v0 += cr;
+          if (cc >> 8) v1 += cr;
+        }
+        pn[rr_] = make_double2(v0, v1);
+        continue;
+      }
       if (FORM == 2) {  // what is staged is the first damped-Jacobi iterate v = omega r / c of the new residual
         const unsigned short cc = cn[rr_];
         pn[rr_] = make_double2(r0 * wtab[cc & 0xffu], r1 * wtab[cc >> 8]);
@@ -2346,24 +2374,33 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   };
   // ---- the halo of plane p (its code bytes and slots came an iteration ahead) ----
+#ifdef OI_TIMING_NOHALO  // TIMING BUILDS ONLY (wrong results; tools/variant_build.sh): what the halo's vector reads cost. 1: rows, 2: columns
+  auto halo_offset = [&](long long pfa) {
+    if (((OI_TIMING_NOHALO & 1) && wu < 2) || ((OI_TIMING_NOHALO & 2) && wu == 2)) return kOob;
+    return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob;
+  };
+#else
   auto halo_offset = [&](long long pfa) { return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob; };
-  auto halo_issue = [&](long long pfa, long long pfb, int off, HRaw& h) {
+#endif
+  auto halo_issue = [&](int hp, long long pfa, long long pfb, int off, HRaw& h) {
     h.r = h.q = make_double2(0.0, 0.0);
     h.p = PPair();
     h.p1 = 0;
+    h.c = 0.f;
     if (wu < 3) {
       const long long nb = (long long)(8 * kLV) * (pfb - pfa);
       const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
       const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
       if (wu < 2) {
         h.r = bld2(rb, off);
-        if (FORM != 2) h.p = PBuf<PT>::ld_pair(pb, off);
-        if (FORM != 1) h.q = bld2(qb, off);
+        if (FORM < 2) h.p = PBuf<PT>::ld_pair(pb, off);
+        if (FORM == 0 || FORM == 2) h.q = bld2(qb, off);
       } else {
         h.r.x = bld1(rb, off);
-        if (FORM != 2) h.p1 = PBuf<PT>::ld_one(pb, off);
-        if (FORM != 1) h.q.x = bld1(qb, off);
+        if (FORM < 2) h.p1 = PBuf<PT>::ld_one(pb, off);
+        if (FORM == 0 || FORM == 2) h.q.x = bld1(qb, off);
       }
+      if (FORM == 3) h.c = corr_ld(hp, off == kOob ? kOob : hcoff);
     }
   };
   auto stage_rows = [&](double* T, const double2 (&pn)[R]) {
@@ -2379,16 +2416,21 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     if (wu < 2) {
       double2 h = make_double2(0.0, 0.0);
       if (hcode) {
-        double z0 = FORM != 1 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x, z1 = FORM != 1 ? hr.r.y - alpha_prev * hr.q.y : hr.r.y;
+        double z0 = (FORM == 0 || FORM == 2) ? hr.r.x - alpha_prev * hr.q.x : hr.r.x, z1 = (FORM == 0 || FORM == 2) ? hr.r.y - alpha_prev * hr.q.y : hr.r.y;
         if (FORM == 2) {
           if (hcode & 0xff) h.x = z0 * wtab[hcode & 0xff];
           if (hcode >> 8) h.y = z1 * wtab[hcode >> 8];
+        }
+        if (FORM == 3) {
+          const double cr = scale * (double)hr.c;
+          if (hcode & 0xff) h.x = z0 * wtab[hcode & 0xff] + cr;
+          if (hcode >> 8) h.y = z1 * wtab[hcode >> 8] + cr;
         }
         if (JACOBI) {
           if (hcode & 0xff) z0 = z0 / (double)(hcode & 0xff);
           if (hcode >> 8) z1 = z1 / (double)(hcode >> 8);
         }
-        if (FORM != 2) {
+        if (FORM < 2) {
           const double2 hp = PBuf<PT>::wide(hr.p);
           h.x = PIo<PT>::rnd(z0 + beta * hp.x); h.y = PIo<PT>::rnd(z1 + beta * hp.y);
         }
@@ -2397,9 +2439,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     } else if (wu == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
-        double z = FORM != 1 ? hr.r.x - alpha_prev * hr.q.x : hr.r.x;
+        double z = (FORM == 0 || FORM == 2) ? hr.r.x - alpha_prev * hr.q.x : hr.r.x;
         if (JACOBI) z = z / (double)hcode;
         if (FORM == 2) h = z * wtab[hcode];
+        else if (FORM == 3) { h = z * wtab[hcode]; h += scale * (double)hr.c; }
         else h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
       }
       T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
@@ -2435,7 +2478,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     stage_rows(tile + b_prev, pn_nxt);
     const int hoff = halo_offset(pf0);
     plane_issue(gs, cc_cur, lo_cur, pf0, pf1, raw, 1);
-    halo_issue(pf0, pf1, hoff, hr);
+    halo_issue(gs, pf0, pf1, hoff, hr);
     plane_finish(gs, cc_cur, pf0, pf1, raw, pn_nxt, rn_cur, 1);
     stage_rows(tile + b_cur, pn_nxt);
     stage_halo(tile + b_cur, hr);
@@ -2444,7 +2487,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const int mode1 = gs + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
       const int hoff1 = halo_offset(pf1);
       plane_issue(gs + 1, cc_nxt, lo_nxt, pf1, pf2, raw_e, mode1);
-      if (gs + 1 < ge) halo_issue(pf1, pf2, hoff1, hr_e);
+      if (gs + 1 < ge) halo_issue(gs + 1, pf1, pf2, hoff1, hr_e);
     }
   }
   __syncthreads();
@@ -2472,38 +2515,13 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   };
   double s_rr = 0.0, s_rz = 0.0, s_pq = 0.0, s_zq = 0.0, s_qdq = 0.0;
-  auto step = [&](const int gz, Raw& raw, HRaw& hr) {
-    // pf0 .. pf2 = first slots of planes gz, gz + 1, gz + 2
-    const long long pf3 = pf_at(gz + 3);
-    const int mode = gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
-    const bool more = gz + 1 < ge;
-    if (!kEarly) {
-      // every load of this iteration, back to back: plane gz + 1's vectors and halo, plane gz + 2's codes and slots
-      const int hoff = halo_offset(pf1);  // (first: the slot came with the previous iteration's loads, nothing newer is waited for)
-      __builtin_amdgcn_sched_barrier(0);
-      plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
-      if (more) halo_issue(pf1, pf2, hoff, hr);
-    } else {
-      __builtin_amdgcn_sched_barrier(0);  // (plane gz + 1's vectors and halo were requested before the barrier)
-    }
-    const unsigned hcode_now = hcode;
-    codes_issue(gz + 2, cc_nn, lo_nn, true);
-    if (more) halo_codes_issue(gz + 2, true);
-    const unsigned hcode_next = hcode;
-    const int hslot_next = hslot;
-    __builtin_amdgcn_sched_barrier(0);
-    plane_finish(gz + 1, cc_nxt, pf1, pf2, raw, pn_nxt, rn_nxt, mode);
-    if (more) {
-      stage_rows(tile + b_nxt, pn_nxt);
-      hcode = hcode_now;
-      stage_halo(tile + b_nxt, hr);
-    }
-    hcode = hcode_next; hslot = hslot_next;
-    if (FORM == 2 && gz > gs) consume(gz - 1);
+  // q = A p of plane gz (FORM 2 / 3: the smoother's stencil) from the LDS ring and the next plane's registers, its stores and sums
+  auto stencil = [&](const int gz) {
     const double* T = tile + b_cur;
     const double* Tp = tile + b_prev;
     const long long nbq = (long long)(8 * kLV) * (pf1 - pf0);
-    const __amdgpu_buffer_rsrc_t qob = buf_of(FORM == 2 ? (double*)nullptr : q_out + kLV * pf0, FORM == 2 ? 0 : nbq);
+    // (FORM 3: what is written is z, through r_out)
+    const __amdgpu_buffer_rsrc_t qob = buf_of(FORM == 2 ? (double*)nullptr : (FORM == 3 ? r_out : q_out) + kLV * pf0, FORM == 2 ? 0 : nbq);
     double xsum[R];
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
@@ -2532,6 +2550,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
           continue;
         }
+        if (FORM == 3) {  // z = v + omega (b - A v) / c and the partial sum of z.b
+          const double o0 = c0 ? pc.x + (rc.x - q0) * wtab[c0] : 0.0, o1 = c1 ? pc.y + (rc.y - q1) * wtab[c1] : 0.0;
+          bst2(qob, qoff, o0, o1);
+          s_pq += o0 * rc.x; s_pq += o1 * rc.y;
+          continue;
+        }
         bst2(qob, qoff, q0, q1);
         double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
         if (JACOBI) {
@@ -2557,6 +2581,36 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         else own[rr_] = xsum[rr_];
       }
     }
+  };
+  auto step = [&](const int gz, Raw& raw, HRaw& hr) {
+    // pf0 .. pf2 = first slots of planes gz, gz + 1, gz + 2
+    const long long pf3 = pf_at(gz + 3);
+    const int mode = gz + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
+    const bool more = gz + 1 < ge;
+    if (!kEarly) {
+      // every load of this iteration, back to back: plane gz + 1's vectors and halo, plane gz + 2's codes and slots
+      const int hoff = halo_offset(pf1);  // (first: the slot came with the previous iteration's loads, nothing newer is waited for)
+      __builtin_amdgcn_sched_barrier(0);
+      plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
+      if (more) halo_issue(gz + 1, pf1, pf2, hoff, hr);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);  // (plane gz + 1's vectors and halo were requested before the barrier)
+    }
+    const unsigned hcode_now = hcode;
+    codes_issue(gz + 2, cc_nn, lo_nn, true);
+    if (more) halo_codes_issue(gz + 2, true);
+    const unsigned hcode_next = hcode;
+    const int hslot_next = hslot;
+    __builtin_amdgcn_sched_barrier(0);
+    plane_finish(gz + 1, cc_nxt, pf1, pf2, raw, pn_nxt, rn_nxt, mode);
+    if (more) {
+      stage_rows(tile + b_nxt, pn_nxt);
+      hcode = hcode_now;
+      stage_halo(tile + b_nxt, hr);
+    }
+    hcode = hcode_next; hslot = hslot_next;
+    if (FORM == 2 && gz > gs) consume(gz - 1);
+    stencil(gz);
     if (SEG) {  // the records requested at the top of this iteration have long arrived: their slots
 #pragma unroll
       for (int rr_ = 0; rr_ < R; ++rr_) lo_nn[rr_] = slot_own(rec_nn[rr_]);
@@ -2575,7 +2629,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const int hoff2 = halo_offset(pf1);
       __builtin_amdgcn_sched_barrier(0);
       plane_issue(gz + 2, cc_nxt, lo_nxt, pf1, pf2, raw, mode2);
-      if (gz + 2 < ge) halo_issue(pf1, pf2, hoff2, hr);
+      if (gz + 2 < ge) halo_issue(gz + 2, pf1, pf2, hoff2, hr);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -2589,7 +2643,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       step(gz, raw, hr);
     }
   }
-  if (FORM == 1) {
+  if (FORM == 1 || FORM == 3) {
     const double t = block_sum(s_pq, red);
     if (threadIdx.x == 0) partials[(long long)partial_base + blockIdx.x] = t;
     return;
@@ -2639,12 +2693,12 @@ static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double
     hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
                        (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
                        partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline,
-                       (float*)nullptr, MgCoarse{}, 0.0);
+                       (float*)nullptr, MgCoarse{}, 0.0, 0.0);
   else
     hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, false>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
                        (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
                        partials, ctrl, lineoff, plane_first, (const uint2*)nullptr, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline,
-                       (float*)nullptr, MgCoarse{}, 0.0);
+                       (float*)nullptr, MgCoarse{}, 0.0, 0.0);
 }
 template <int R, int NW, typename PT>
 static void launch_cg1_r(int blocks, const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out,
@@ -2767,7 +2821,25 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
   hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r_in, r_out, q,
                      (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc,
                      0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1, bcoarse, c,
-                     omega);
+                     omega, 0.0);
+  return blocks;
+}
+// k_cg1b FORM 3, the fine post-smoother of the cycle on compacted vectors: z = v + omega (b - A v) / c with
+// v = omega b / c + scale * (coarse correction), partial sums of z.b per block (what launch_mg_fine mode 2 leaves, chunk for
+// chunk: same arithmetic in the same order).  Returns the number of blocks, -1 when the grid does not fit
+int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale, double* z,
+                   double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+  const int by = kNW * 2;
+  const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
+  const long long cols = (long long)tiles_x * tiles_y;
+  int zchunk, nzc;
+  fused_chunks(g, cols, false, &zchunk, &nzc);
+  if (!grid_fits(g, cols, nzc)) return -1;
+  const int blocks = (int)(cols * nzc);
+  hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, b, z,
+                     (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, (double*)nullptr, 0, 0, zchunk,
+                     tiles_x, tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,
+                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, c, omega, scale);
   return blocks;
 }
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
@@ -2788,7 +2860,7 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
   hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
                      (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, 0, zchunk, tiles_x,  \
                      tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,             \
-                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0)
+                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0, 0.0)
       if (p_f32) OI_FB(float); else OI_FB(double);
 #undef OI_FB
       return blocks;

@@ -21,13 +21,14 @@ void mg_destroy(MgHierarchy* mg);
 // tiled = 0 selects the plain (cache-served) fine-level kernels kept as a cross-check.
 // lineoff != null: r and z are in the compacted line layout (launch_build_lines); needs tiled != 0 and an even g.z0
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
-              double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s);
+              double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s,
+              const long long* plane_first = nullptr, const void* seg = nullptr /* with both: the post-smoother as k_cg1b FORM 3 */);
 // The cycle in two halves, for a caller that forms the first coarse right-hand side itself (launch_mg_pre_update: residual
 // update + pre-smoother + restriction in one kernel): where the block sums go (`prepare`s the target), then the rest of
 // the cycle -- coarse levels and the fine post-smoother, partial sums of z.r as mg_vcycle leaves them
 bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* omega, hipStream_t s);
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
-                                const Ctrl* ctrl, const int* lineoff, hipStream_t s);
+                                const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s);
 int mg_levels(const MgHierarchy* mg);
 int mg_replicated_from(const MgHierarchy* mg);  // first level (1 = first coarse) solved redundantly on every rank, -1 = none
 // partial sums of a.b over the owned planes; returns the number of partials

@@ -906,8 +906,17 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
 // z = M^-1 r on the fine level; `scratch` is a fine vector the caller does not need meanwhile.
 // r's ghost planes must hold the neighbours' values.  Returns the number of z.r partials, -1 on a
 // transport failure.
+// the fine post-smoother with the partial sums of z.r: compacted vectors with their segment records at hand take the
+// descriptor-addressed form (k_cg1b FORM 3), everything else k_mg_fine<2, 2>; same chunks, same sums
+static int post_smooth(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, const MgCoarse& cref, double* z, double* partials,
+                       const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+  if (!g.tune.mg_post_kernel && fused_descr_ok(g, lineoff, plane_first, seg, 0))
+    return launch_mg_post(g, code, r, cref, (double)mg->omega, (double)mg->scale, z, partials, ctrl, lineoff, plane_first, seg, s);
+  return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
+}
 static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
-                            double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s) {
+                            double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s,
+                            const long long* plane_first, const void* seg) {
   auto& Ls = mg->levels;
   const long long nfine = (long long)g.nzl * g.ny * g.nx;
   MgLevelHost& C = Ls[0];
@@ -936,7 +945,7 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
     cref.xc2 = C.xs;
   }
   if (tiled)  // also leaves the per-block partial sums of z.r
-    return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
+    return post_smooth(mg, g, code, r, cref, z, partials, ctrl, lineoff, plane_first, seg, s);
   hipLaunchKernelGGL(k_mg_fine_post, dim3(nblk(nfine)), dim3(256), 0, s, g, code, r, cref, (double)mg->scale, z, ctrl, (double)mg->omega);
   return launch_dot(g, r, z, partials, s);
 }
@@ -957,7 +966,7 @@ bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* ome
 // everything after the restriction: ghost planes / rank sum of the coarse right-hand side, the coarse cycle, and the fine
 // post-smoother z = x2 + w (r - A x2) / c with the partial sums of z.r (returns their number, -1 on a transport failure)
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
-                                const Ctrl* ctrl, const int* lineoff, hipStream_t s) {
+                                const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
   MgLevelHost& C = mg->levels[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   if (!finish_child_array(mg, C, false, C.b, s)) return -1;
@@ -968,14 +977,14 @@ int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* c
     if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
     cref.xc2 = C.xs;
   }
-  return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
+  return post_smooth(mg, g, code, r, cref, z, partials, ctrl, lineoff, plane_first, seg, s);
 }
 
 // (A hipGraph replay of the cycle's ~250 launches was measured in round 1: no gain on ROCm 7.2 -- back-to-back dependent
 // launches already run at the dispatch latency -- and it did not survive rocprofv3 --kernel-trace; removed.)
 int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
-              double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s) {
-  return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, lineoff, s);
+              double* partials, const Ctrl* ctrl, int tiled, const int* lineoff, hipStream_t s, const long long* plane_first, const void* seg) {
+  return mg_vcycle_launch(mg, g, code, r, scratch, z, partials, ctrl, tiled, lineoff, s, plane_first, seg);
 }
 
 int mg_levels(const MgHierarchy* mg) { return mg ? (int)mg->levels.size() + 1 : 0; }

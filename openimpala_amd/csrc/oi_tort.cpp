@@ -1176,7 +1176,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
                                 h->plane_first_dev, h->seg, s);
     }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * k + H_RR, true, k + 1));
-    { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, s); }
+    { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s); }
     if (nb < 0) return OI_RCCL_ERROR;
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
     OIC(exchange_cg_vec(h, h->z, sizeof(double), s));
@@ -1192,7 +1192,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     void* p_out = h->p[k & 1];
     const double* zsrc = h->r;
     if (h->mg) {  // preconditioned residual from the multigrid V-cycle, and r.z into hist[k]
-      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, h->lineoff, s); }
+      { PROF(K_MG); nb = mg_vcycle(h->mg, g, h->code, h->r, h->q, h->z, h->partials, h->ctrl, h->mg_tiled, h->lineoff, s, h->plane_first_dev, h->seg); }
       if (nb < 0) return OI_RCCL_ERROR;
       OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
       OIC(exchange_cg_vec(h, h->z, sizeof(double), s));
@@ -2094,6 +2094,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "cg1_seg") t.cg1_seg = iv != 0;
   else if (k == "fused_kernel") t.fused_kernel = iv;
   else if (k == "mg_norot") t.mg_norot = iv != 0;
+  else if (k == "mg_post_kernel") t.mg_post_kernel = iv != 0;
   else if (k == "fused_zchunk") t.fused_zchunk = iv > 0 ? iv : 0;
   else if (k == "place_min_mb") t.place_min_mb = iv > 0 ? iv : 0;
   else if (k == "place_extent_gb") t.place_extent_gb = (float)value;
@@ -2113,7 +2114,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_compact = old.cg1_compact;
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
-  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_coarsest_plain = old.mg_coarsest_plain;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel;
   t.force_comm = old.force_comm;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;

@@ -310,15 +310,17 @@ def test_multigrid_two_coarse_sweeps(sample, goldens, oi_option):
 @pytest.mark.parametrize("p_storage", [oia.STORE_F64, oia.STORE_F32])
 def test_multigrid_rotated_iteration_and_its_cross_checks(sample, goldens, oi_option, p_storage):
     """The default multigrid-preconditioned solve runs the ROTATED two-kernel iteration (residual update + fine pre-smoother +
-    restriction in one descriptor-addressed pass, k_cg1b FORM 2; first kernel k_cg1b FORM 1).  Its cross-checks -- the unrotated
+    restriction in one descriptor-addressed pass, k_cg1b FORM 2; first kernel k_cg1b FORM 1; fine post-smoother k_cg1b FORM 3).  Its cross-checks -- the unrotated
     iteration (`mg_norot`), k_fused_a as first kernel (`fused_kernel` = 1, which also un-rotates) -- produce the same iterates bit
     for bit: same iteration count, tau and solution, the same residual norm to summation order; and stepping n launches reports
     n - 1 complete iterations in the rotated form (launch k forms r_k first, like the single-kernel variant), n in the other."""
     g = goldens["phases"]["1"]
-    reset = {"mg_norot": 0, "fused_kernel": 0, "mg_coarsest_plain": 0}
+    reset = {"mg_norot": 0, "fused_kernel": 0, "mg_coarsest_plain": 0, "mg_post_kernel": 0}
     out = {}
-    # (+ the coarsest level's sixteen sweeps as separate launches instead of the one-launch kernel k_mg_coarsest)
-    for name, opts in (("default", {}), ("norot", {"mg_norot": 1}), ("fused_a", {"fused_kernel": 1}), ("coarsest", {"mg_coarsest_plain": 1})):
+    # (+ the coarsest level's sixteen sweeps as separate launches instead of the one-launch kernel k_mg_coarsest; + the fine
+    # post-smoother as k_mg_fine<2, 2> instead of the descriptor-addressed k_cg1b FORM 3: the same sums chunk for chunk)
+    for name, opts in (("default", {}), ("norot", {"mg_norot": 1}), ("fused_a", {"fused_kernel": 1}), ("coarsest", {"mg_coarsest_plain": 1}),
+                       ("post", {"mg_post_kernel": 1})):
         for k_, v_ in opts.items():
             oi_option(k_, v_, reset=reset[k_])
         t = oia.TortuosityMI355(sample, 1, 1, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG, p_storage=p_storage)
@@ -333,12 +335,12 @@ def test_multigrid_rotated_iteration_and_its_cross_checks(sample, goldens, oi_op
         t.destroy()
         for k_ in opts:
             oia.set_option(k_, reset[k_])
-    for name in ("norot", "fused_a", "coarsest"):
+    for name in ("norot", "fused_a", "coarsest", "post"):
         assert out[name][0] == out["default"][0] and out[name][1] == out["default"][1], name
         assert out[name][2] == pytest.approx(out["default"][2], rel=1e-12), name   # (||r||^2 is summed tile-wise here, line-wise there)
         assert np.array_equal(out[name][3], out["default"][3]), name
-        assert out[name][4] == (6 if name == "coarsest" else 7) and out["default"][4] == 6
-    assert out["coarsest"][2] == out["default"][2]
+        assert out[name][4] == (6 if name in ("coarsest", "post") else 7) and out["default"][4] == 6
+    assert out["coarsest"][2] == out["default"][2] and out["post"][2] == out["default"][2] and out["post"][5] == out["default"][5]
 
 
 def test_multigrid_rotated_iteration_when_the_budget_runs_out(sample, goldens, oi_option):
@@ -361,6 +363,29 @@ def test_multigrid_rotated_iteration_when_the_budget_runs_out(sample, goldens, o
         assert out[("rot", maxiter)][0] == pytest.approx(out[("norot", maxiter)][0], rel=1e-12)
         assert np.array_equal(out[("rot", maxiter)][1], out[("norot", maxiter)][1]), maxiter
     assert out[("rot", 7)][0] < out[("rot", 6)][0] < out[("rot", 1)][0]
+
+
+@pytest.mark.parametrize("zchunk", [0, 6])
+def test_multigrid_post_smoother_forms_agree_across_tile_columns(oi_option, zchunk):
+    """k_cg1b FORM 3 against k_mg_fine<2, 2> where a row spans three 128-voxel tile columns (the x-halo lanes fetch their own coarse
+    correction), rows and planes end inside tiles and chunks, odd extents leave truncated aggregates: same iterates bit for bit."""
+    phase = o.gen_spheres((29, 45, 301), 9, 5, 0.5)
+    out = {}
+    try:
+        oia.set_tuning(16, zchunk, 32)
+        for post in (0, 1):
+            oi_option("mg_post_kernel", post, reset=0)
+            t = oia.TortuosityMI355(phase, 1, 2, -1.0, 1.0, eps=1e-10, precond=oia.PRECOND_MG)
+            tau = t.value()
+            st = t.stats()
+            assert st.converged
+            out[post] = (tau, st.iterations, st.final_relres, t.solution())
+            t.destroy()
+    finally:
+        oia.set_tuning()
+    assert out[0][:3] == out[1][:3] and np.array_equal(out[0][3], out[1][3])
+    ref = o.tortuosity(phase, 1, 2, -1.0, 1.0, eps=1e-10)
+    assert out[0][0] == pytest.approx(ref["tau"], rel=1e-8)
 
 
 def test_multigrid_ragged_shapes_and_refusals():
