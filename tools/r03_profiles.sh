@@ -15,6 +15,6 @@ for r in list(csv.DictReader(open(sys.argv[1])))[:24]:
     print("%-60s calls %5s avg %10.1f us total %9.1f ms %5.1f%%" % (r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void oi::", "").replace("oi::", "")[:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"])))
 PY
 find $out -name "*.db" -delete; find $out -name "*agent_info*" -delete; find $out -name "*kernel_trace*" -delete
-OI_SQ_SCRIPT=tools/mg_bench.py OI_SQ_KERNEL="k_cg1b<2, 8, double, false, true, 1>;k_cg1b<2, 8, double, false, true, 2>;k_mg_fine<2, 2" bash $R/tools/sq_counters.sh ${tag}_mg > $R/gpurun_out/sq_${tag}_mg.txt 2>&1 || tail -5 $R/gpurun_out/sq_${tag}_mg.txt
+OI_SQ_SCRIPT=tools/mg_bench.py OI_SQ_KERNEL="k_cg1b<2, 8, double, false, true, 1>;k_cg1b<2, 8, double, false, true, 2>;k_cg1b<2, 8, double, false, true, 3>" bash $R/tools/sq_counters.sh ${tag}_mg > $R/gpurun_out/sq_${tag}_mg.txt 2>&1 || tail -5 $R/gpurun_out/sq_${tag}_mg.txt
 find $R/gpurun_out/prof_${tag} $R/gpurun_out/prof_${tag}_mg $R/gpurun_out/sq_${tag}_mg -name "*.csv" -size +2M -delete 2>/dev/null
 du -sh $R/gpurun_out
