@@ -2046,6 +2046,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1(Geom g, const
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int kOob = 0x7ffff000;          // lane offset that every descriptor's range check rejects
+#ifndef OI_TIMING_KNOCK
+#define OI_TIMING_KNOCK 0  // TIMING BUILDS ONLY (tools/variant_build.sh + tools/knock_bench.py, wrong results): 1 no barrier per plane, 2 no LDS
+                           // reads, 4 no LDS writes, 8 no vector traffic (every offset out of range), 16 code bytes / records of one plane
+#endif
 #ifndef OI_CG1B_EARLY
 #define OI_CG1B_EARLY 1   // 0: the first form (requests at the top of the iteration), kept for A/B builds (tools/early_issue_ab.sh)
 #endif
@@ -2118,7 +2122,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   constexpr int BY = NW * R;
   constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
-  if (ctrl && ctrl->done) return;
+  if (!(OI_TIMING_KNOCK & 8) && ctrl && ctrl->done) return;
   // p_k of three consecutive planes (ring): the z neighbours are read from here, not carried in registers
   __shared__ __attribute__((aligned(16))) double tile[3 * TS];
   __shared__ double red[NW];
@@ -2151,9 +2155,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       rk1[R1_ALPHA] = sc.alpha;
       rk1[R1_BETA] = sc.beta;
-      if (sc.converged) ctrl->done = k;
+      if (!(OI_TIMING_KNOCK & 8) && sc.converged) ctrl->done = k;
     }
-    if (sc.converged) return;
+    if (!(OI_TIMING_KNOCK & 8) && sc.converged) return;
     alpha_prev = sc.alpha;
     beta = sc.beta;
   }
@@ -2207,6 +2211,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   auto codes_issue = [&](int p, unsigned short (&cn)[R], int (&ln)[R], bool defer) {
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) { cn[rr_] = 0; ln[rr_] = -1; rec_nn[rr_] = make_uint2(0u, 0u); }
+#if OI_TIMING_KNOCK & 16  // TIMING BUILDS ONLY: the code bytes and records of the chunk's first plane for every plane (cache hits)
+    if (defer) p = gs;
+#endif
     if (p <= g.nzl + 1) {
       const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
 #pragma unroll
@@ -2235,6 +2242,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   auto halo_codes_issue = [&](int p, bool defer) {
     hcode = 0; hslot = 0;
     hrec_s = make_uint2(0u, 0u);
+#if OI_TIMING_KNOCK & 16
+    if (defer) p = gs;
+#endif
     if (p <= g.nzl + 1 && wu < 3) {
       const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
       if (wu < 2) hcode = __builtin_amdgcn_raw_buffer_load_b16(cb, hvox, 0, 0);
@@ -2273,7 +2283,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const bool st = in_x && (fullline ? ln[rr_] >= 0 : cn[rr_] != 0);  // (ln = -1, cn = 0 on rows outside the volume)
+#if OI_TIMING_KNOCK & 8  // TIMING BUILDS ONLY: no vector traffic at all (every offset out of range), the instructions stay
+      raw.off[rr_] = (st && ln[rr_] == -12345) ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
+#else
       raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
+#endif
       raw.r[rr_] = bld2(rb, raw.off[rr_]);
       if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2(qb, raw.off[rr_]);
       else raw.q[rr_] = make_double2(0.0, 0.0);
@@ -2374,7 +2388,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   };
   // ---- the halo of plane p (its code bytes and slots came an iteration ahead) ----
-#ifdef OI_TIMING_NOHALO  // TIMING BUILDS ONLY (wrong results; tools/variant_build.sh): what the halo's vector reads cost. 1: rows, 2: columns
+#if OI_TIMING_KNOCK & 8
+  auto halo_offset = [&](long long pfa) { return (is_halo && hcode && hslot == -12345) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob; };
+#elif defined(OI_TIMING_NOHALO)  // TIMING BUILDS ONLY (wrong results; tools/variant_build.sh): what the halo's vector reads cost. 1: rows, 2: columns
   auto halo_offset = [&](long long pfa) {
     if (((OI_TIMING_NOHALO & 1) && wu < 2) || ((OI_TIMING_NOHALO & 2) && wu == 2)) return kOob;
     return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob;
@@ -2527,17 +2543,26 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     for (int rr_ = 0; rr_ < R; ++rr_) {
       const unsigned short cc = cc_cur[rr_];
       const bool stored = in_x && lo_cur[rr_] >= 0;
+#if OI_TIMING_KNOCK & 8
+      const int qoff = lo_cur[rr_] == -12345 ? (lo_cur[rr_] - (int)pf0) * (8 * kLV) + sub : kOob;
+#else
       const int qoff = (lo_cur[rr_] - (int)pf0) * (8 * kLV) + sub;
+#endif
       xsum[rr_] = 0.0;
       if (FORM != 2 && fullline && !cc && stored) bst2(qob, qoff, 0.0, 0.0);  // whole lines
       if (cc) {  // q and every partial sum vanish where both voxels are non-free
         const int base = (wu + rr_ * NW + 1) * kLP + 2 + 2 * lane;
+#if OI_TIMING_KNOCK & 2  // TIMING BUILDS ONLY (wrong results): the stencil without its LDS reads
+        const double2 lf = pn_nxt[rr_], pc = rn_cur[rr_], rt = pn_nxt[rr_], ym = rn_cur[rr_], yp = pn_nxt[rr_], zm = rn_cur[rr_];
+        (void)T; (void)Tp; (void)base;
+#else
         const double2 lf = *reinterpret_cast<const double2*>(&T[base - 2]);
         const double2 pc = *reinterpret_cast<const double2*>(&T[base]);
         const double2 rt = *reinterpret_cast<const double2*>(&T[base + 2]);
         const double2 ym = *reinterpret_cast<const double2*>(&T[base - kLP]);
         const double2 yp = *reinterpret_cast<const double2*>(&T[base + kLP]);
         const double2 zm = *reinterpret_cast<const double2*>(&Tp[base]);
+#endif
         const unsigned c0 = cc & 0xffu, c1 = cc >> 8;
         const double2 rc = rn_cur[rr_];
         const double s0 = ((((lf.y + pc.y) + ym.x) + yp.x) + zm.x) + pn_nxt[rr_].x;
@@ -2603,7 +2628,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     const int hslot_next = hslot;
     __builtin_amdgcn_sched_barrier(0);
     plane_finish(gz + 1, cc_nxt, pf1, pf2, raw, pn_nxt, rn_nxt, mode);
+#if OI_TIMING_KNOCK & 4  // TIMING BUILDS ONLY: nothing staged in LDS
+    if (more && hr.r.x == 1.2345e300) {
+#else
     if (more) {
+#endif
       stage_rows(tile + b_nxt, pn_nxt);
       hcode = hcode_now;
       stage_halo(tile + b_nxt, hr);
@@ -2632,7 +2661,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       if (gz + 2 < ge) halo_issue(gz + 2, pf1, pf2, hoff2, hr);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if !(OI_TIMING_KNOCK & 1)  // (TIMING BUILDS ONLY: 1 = no barrier per plane)
     __syncthreads();
+#endif
   };
   if (kEarly) {
     for (int gz = gs; gz < ge; ++gz) step(gz, raw_e, hr_e);
