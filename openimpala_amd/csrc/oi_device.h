@@ -39,6 +39,7 @@ struct Tune {
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
   float mg_omega = 0.f;  // in (0, 1): Jacobi damping of the cycle (default 0.9)
+  int mg_xfirst = 0;          // 1: x += alpha p stays in the first kernel of the rotated iteration (cross-check; default: in the post-smoother)
   int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)
   int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)
   int mg_nu_coarse = 1;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (1 or 2; the fine level: 1)
@@ -155,7 +156,7 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
                    void* p_out, int p_f32, double* q, int jacobi, const double* hist, int k, double* partials,
                    const Ctrl* ctrl, const int* lineoff /* != null: r, p, q in the compacted line layout */,
                    const long long* plane_first /* + seg: the descriptor-addressed form (k_cg1b, FORM 1) may run */, const void* seg,
-                   hipStream_t s);
+                   hipStream_t s, int x_elsewhere = 0 /* 1: x already took alpha_{k-1} p_{k-1} (launch_mg_post); descriptor form only */);
 // stand-alone tiled stencil apply q = A v (17 B/voxel), partials {v.q}
 int launch_apply_tiled(const Geom& g, const uint8_t* code, const double* v, double* q, double* partials,
                        const Ctrl* ctrl, hipStream_t s);
@@ -189,8 +190,11 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
                          MgCoarse c, float* bcoarse, double omega, double* partials, const Ctrl* ctrl, const int* lineoff,
                          const long long* plane_first, const void* seg, hipStream_t s);
 // the fine post-smoother on compacted vectors, descriptor-addressed (k_cg1b FORM 3): what launch_mg_fine mode 2 computes
+// x != null: also x += alpha_{k-1} p_{k-1} (alpha from hist[k - 1]; p_prev in fp32 if p_f32), the update the first kernel of the
+// iteration then leaves out (launch_fused_a, x_elsewhere)
 int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale, double* z,
-                   double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s);
+                   double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
+                   double* x = nullptr, const void* p_prev = nullptr, int p_f32 = 0, const double* hist = nullptr, int k = 0);
 // fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
 // (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)

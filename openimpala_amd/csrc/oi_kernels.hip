@@ -2148,7 +2148,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     }
   } else if (FORM == 2) {
     if (k > 0) alpha_prev = safe_div(rec[H_STRIDE * (k - 1) + H_RZ], rec[H_STRIDE * (k - 1) + H_PQ]);
-  } else if (FORM == 3) {
+  } else if (FORM == 3) {  // (x += alpha_{k-1} p_{k-1} rides along when the caller hands x over: see do_x)
+    if (k > 0 && x) alpha_prev = safe_div(rec[H_STRIDE * (k - 1) + H_RZ], rec[H_STRIDE * (k - 1) + H_PQ]);
   } else if (k > 0) {
     double* rk1 = rec + R1_STRIDE * (k - 1);
     const Cg1Scalars sc = cg1_scalars_of(rk1, ctrl->tol2);
@@ -2161,8 +2162,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     alpha_prev = sc.alpha;
     beta = sc.beta;
   }
-  if (FORM != 0) xskip = 0;  // (FORM 1: x takes alpha_{k-1} p_{k-1} in every launch)
-  const bool do_x = FORM >= 2 ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
+  // FORM 1: x takes alpha_{k-1} p_{k-1} in every launch -- unless the post-smoother of the same iteration (FORM 3, launched just
+  // before with x and p_{k-1}) has applied it already: that kernel is instruction-bound and carries the 24 bytes per voxel for
+  // less than they cost here (xskip < 0 says so)
+  const bool x_elsewhere = FORM == 1 && xskip < 0;
+  if (FORM != 0) xskip = 0;
+  const bool do_x = FORM == 2 ? false : FORM == 3 ? (x != nullptr && k > 0) : x_elsewhere ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
   if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
 
   const int lane = threadIdx.x & 63;
@@ -2291,7 +2296,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       raw.r[rr_] = bld2(rb, raw.off[rr_]);
       if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2(qb, raw.off[rr_]);
       else raw.q[rr_] = make_double2(0.0, 0.0);
-      if (FORM < 2) raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
+      if (FORM < 2 || (FORM == 3 && with_x)) raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
       else raw.p[rr_] = PPair();
       raw.c[rr_] = 0.f;
       if (FORM == 3) raw.c[rr_] = corr_ld(p, (in_x && cn[rr_]) ? ((i >> 1) + C.cnx * (row_of(rr_) >> 1)) * 4 : kOob);
@@ -2340,6 +2345,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           if (cc >> 8) v1 += cr;
         }
         pn[rr_] = make_double2(v0, v1);
+        if (with_x && mode != 0)  // x_k = x_{k-1} + alpha_{k-1} p_{k-1}, the update the first kernel of this iteration leaves out
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(raw.xv[rr_].x + alpha_prev * pin.x,
+                                                                                       raw.xv[rr_].y + alpha_prev * pin.y)),
+                                                 xb, raw.xoff[rr_], 0, 0);
         continue;
       }
       if (FORM == 2) {  // what is staged is the first damped-Jacobi iterate v = omega r / c of the new residual
@@ -2859,7 +2868,8 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
 // v = omega b / c + scale * (coarse correction), partial sums of z.b per block (what launch_mg_fine mode 2 leaves, chunk for
 // chunk: same arithmetic in the same order).  Returns the number of blocks, -1 when the grid does not fit
 int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale, double* z,
-                   double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+                   double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
+                   double* x, const void* p_prev, int p_f32, const double* hist, int k) {
   const int by = kNW * 2;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
@@ -2867,15 +2877,20 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
   fused_chunks(g, cols, false, &zchunk, &nzc);
   if (!grid_fits(g, cols, nzc)) return -1;
   const int blocks = (int)(cols * nzc);
-  hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, b, z,
-                     (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, (double*)nullptr, 0, 0, zchunk,
-                     tiles_x, tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,
-                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, c, omega, scale);
+  // x != null: x += alpha_{k-1} p_{k-1} (alpha from hist) on the planes this launch writes -- what the first kernel of the
+  // two-kernel iteration otherwise does (launch_fused_a with x_elsewhere)
+#define OI_F3(PT)                                                                                                                    \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, b, z, (const double*)nullptr, \
+                     (double*)nullptr, (const PT*)p_prev, (PT*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc, \
+                     0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1,  \
+                     (float*)nullptr, c, omega, scale)
+  if (x && p_f32) OI_F3(float); else OI_F3(double);
+#undef OI_F3
   return blocks;
 }
 int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* r, const void* p_in, void* p_out,
                    int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
-                   const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+                   const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s, int x_elsewhere) {
   const int R = g.tune.fused_rows;
   if (R == 2 && !g.periodic) {
     const int by = kNW * R;
@@ -2889,7 +2904,7 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
     if (descr) {
 #define OI_FB(PT)                                                                                                              \
   hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
-                     (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, 0, zchunk, tiles_x,  \
+                     (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, x_elsewhere ? -1 : 0, zchunk, tiles_x,  \
                      tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,             \
                      (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0, 0.0)
       if (p_f32) OI_FB(float); else OI_FB(double);

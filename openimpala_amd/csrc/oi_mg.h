@@ -27,8 +27,13 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
 // update + pre-smoother + restriction in one kernel): where the block sums go (`prepare`s the target), then the rest of
 // the cycle -- coarse levels and the fine post-smoother, partial sums of z.r as mg_vcycle leaves them
 bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* omega, hipStream_t s);
+// xu != null (and mg_post_descr(...) true): the post-smoother also applies x += alpha_{k-1} p_{k-1}; the caller then launches the
+// first kernel of the iteration with x_elsewhere = 1
+struct MgXUpdate { double* x; const void* p_prev; int p_f32; const double* hist; int k; };
+bool mg_post_descr(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg);  // does the post-smoother run as k_cg1b FORM 3?
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
-                                const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s);
+                                const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
+                                const MgXUpdate* xu = nullptr);
 int mg_levels(const MgHierarchy* mg);
 int mg_replicated_from(const MgHierarchy* mg);  // first level (1 = first coarse) solved redundantly on every rank, -1 = none
 // partial sums of a.b over the owned planes; returns the number of partials

@@ -909,9 +909,11 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
 // the fine post-smoother with the partial sums of z.r: compacted vectors with their segment records at hand take the
 // descriptor-addressed form (k_cg1b FORM 3), everything else k_mg_fine<2, 2>; same chunks, same sums
 static int post_smooth(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, const MgCoarse& cref, double* z, double* partials,
-                       const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
-  if (!g.tune.mg_post_kernel && fused_descr_ok(g, lineoff, plane_first, seg, 0))
-    return launch_mg_post(g, code, r, cref, (double)mg->omega, (double)mg->scale, z, partials, ctrl, lineoff, plane_first, seg, s);
+                       const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
+                       const MgXUpdate* xu = nullptr) {
+  if (mg_post_descr(g, lineoff, plane_first, seg))
+    return launch_mg_post(g, code, r, cref, (double)mg->omega, (double)mg->scale, z, partials, ctrl, lineoff, plane_first, seg, s,
+                          xu ? xu->x : nullptr, xu ? xu->p_prev : nullptr, xu ? xu->p_f32 : 0, xu ? xu->hist : nullptr, xu ? xu->k : 0);
   return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
 }
 static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,
@@ -966,7 +968,8 @@ bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* ome
 // everything after the restriction: ghost planes / rank sum of the coarse right-hand side, the coarse cycle, and the fine
 // post-smoother z = x2 + w (r - A x2) / c with the partial sums of z.r (returns their number, -1 on a transport failure)
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
-                                const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
+                                const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
+                                const MgXUpdate* xu) {
   MgLevelHost& C = mg->levels[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   if (!finish_child_array(mg, C, false, C.b, s)) return -1;
@@ -977,7 +980,10 @@ int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* c
     if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
     cref.xc2 = C.xs;
   }
-  return post_smooth(mg, g, code, r, cref, z, partials, ctrl, lineoff, plane_first, seg, s);
+  return post_smooth(mg, g, code, r, cref, z, partials, ctrl, lineoff, plane_first, seg, s, xu);
+}
+bool mg_post_descr(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg) {
+  return !g.tune.mg_post_kernel && fused_descr_ok(g, lineoff, plane_first, seg, 0);
 }
 
 // (A hipGraph replay of the cycle's ~250 launches was measured in round 1: no gain on ROCm 7.2 -- back-to-back dependent

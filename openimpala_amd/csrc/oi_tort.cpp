@@ -1176,14 +1176,18 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
                                 h->plane_first_dev, h->seg, s);
     }
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * k + H_RR, true, k + 1));
-    { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s); }
+    // x += alpha_{k-1} p_{k-1}: in the post-smoother (instruction-bound, it carries the bytes for less) when that runs as k_cg1b FORM 3,
+    // else in the first kernel as in the unrotated iteration
+    const bool xpost = !g.tune.mg_xfirst && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg);
+    const MgXUpdate xu{h->x, p_in, h->p_f32 ? 1 : 0, h->hist, k};
+    { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s, xpost ? &xu : nullptr); }
     if (nb < 0) return OI_RCCL_ERROR;
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
     OIC(exchange_cg_vec(h, h->z, sizeof(double), s));
     {
       PROF(K_FUSED_A);
       nb = launch_fused_a(g, h->code, h->x, h->z, p_in, p_out, h->p_f32 ? 1 : 0, h->q, 0, h->hist, k, h->partials, h->ctrl, h->lineoff,
-                          h->plane_first_dev, h->seg, s);
+                          h->plane_first_dev, h->seg, s, xpost ? 1 : 0);
     }
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
     OIC(exchange_cg_vec(h, h->q, sizeof(double), s));  // (kernel A of the next iteration forms r on the ghost planes from r and q there)
@@ -2095,6 +2099,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "fused_kernel") t.fused_kernel = iv;
   else if (k == "mg_norot") t.mg_norot = iv != 0;
   else if (k == "mg_post_kernel") t.mg_post_kernel = iv != 0;
+  else if (k == "mg_xfirst") t.mg_xfirst = iv != 0;
   else if (k == "fused_zchunk") t.fused_zchunk = iv > 0 ? iv : 0;
   else if (k == "place_min_mb") t.place_min_mb = iv > 0 ? iv : 0;
   else if (k == "place_extent_gb") t.place_extent_gb = (float)value;
@@ -2114,7 +2119,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_compact = old.cg1_compact;
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
-  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst;
   t.force_comm = old.force_comm;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;

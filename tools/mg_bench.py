@@ -11,6 +11,7 @@ ap.add_argument("--nu", default="1", help="comma-separated mg_nu_coarse values, 
 ap.add_argument("--wmask", default="-1", help="comma-separated mg_wmask values (-1 = default)")
 ap.add_argument("--zchunk", default="0", help="comma-separated z-chunk lengths of the marching kernels (0 = automatic)")
 ap.add_argument("--scale", default="0", help="comma-separated mg_scale values (0 = default 1.5)")
+ap.add_argument("--reps", type=int, default=2, help="passes over the combinations")
 ap.add_argument("--opt", action="append", default=[], help="key=v1,v2,...: any oi_tort_set_option key, alternated like the others")
 a = ap.parse_args()
 n = a.size
@@ -18,7 +19,7 @@ buf, desc = bench.make_structure(oia, a, (n, n, n), 0, n)
 import itertools
 extra = [(o.split("=")[0], o.split("=")[1].split(",")) for o in a.opt]
 combos = list(itertools.product(a.nu.split(","), a.wmask.split(","), a.zchunk.split(","), a.scale.split(","), *[v for _, v in extra]))
-for rep in range(2 * len(combos)):
+for rep in range(a.reps * len(combos)):
     nu, wm, zc, sc = combos[rep % len(combos)][:4]
     ex = combos[rep % len(combos)][4:]
     for (key, _), v in zip(extra, ex):
