@@ -2972,14 +2972,25 @@ void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s) {
 // --------------------------------------------------------------------------------------
 // Deterministic final sums: one block adds the per-block partials in a fixed order.
 // --------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ partials, int nblocks, int ncomp,
-                                                   double* __restrict__ dst, Ctrl* ctrl, int check, int iter_done) {
+// (1024 threads, four independent running sums per thread: the descriptor-addressed kernels of the two-kernel iteration launch
+// 32768 blocks at 1024^3, and 256 threads with one running sum took 57 us over them, three times per multigrid-PCG iteration;
+// the order of summation depends on the number of blocks only)
+__global__ void __launch_bounds__(1024) k_finalize(const double* __restrict__ partials, int nblocks, int ncomp,
+                                                    double* __restrict__ dst, Ctrl* ctrl, int check, int iter_done) {
   if (ctrl && ctrl->done) return;
-  __shared__ double red[4];
+  __shared__ double red[16];
+  const int T = blockDim.x;
   for (int c = 0; c < ncomp; ++c) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += partials[(long long)b * ncomp + c];
-    const double t = block_sum(v, red);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = threadIdx.x;
+    for (; b + 3 * T < nblocks; b += 4 * T) {
+      a0 += partials[(long long)b * ncomp + c];
+      a1 += partials[(long long)(b + T) * ncomp + c];
+      a2 += partials[(long long)(b + 2 * T) * ncomp + c];
+      a3 += partials[(long long)(b + 3 * T) * ncomp + c];
+    }
+    for (; b < nblocks; b += T) a0 += partials[(long long)b * ncomp + c];
+    const double t = block_sum((a0 + a1) + (a2 + a3), red);
     if (threadIdx.x == 0) {
       dst[c] = t;
       if (check && c == 0 && t <= ctrl->tol2) ctrl->done = iter_done;
@@ -2989,7 +3000,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ par
 
 void launch_finalize(const double* partials, int nblocks, int ncomp, double* dst, Ctrl* ctrl, int check,
                      int iter_done, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partials, nblocks, ncomp, dst, ctrl, check, iter_done);
+  // (small grids: a block of 256 has the partials in flight just as well)
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(nblocks > 4096 ? 1024 : 256), 0, s, partials, nblocks, ncomp, dst, ctrl, check, iter_done);
 }
 
 __global__ void k_check_done(const double* __restrict__ rr, Ctrl* ctrl, int iter_done) {
