@@ -208,8 +208,10 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
                double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff, const long long* plane_first,
                const void* seg, hipStream_t s);
+constexpr int kFinSlices = 64, kFinScratch = 5 * kFinSlices + 2;
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
-                      hipStream_t s);
+                      hipStream_t s,
+                      double* scratch = nullptr /* kFinScratch doubles, zeroed once: large grids are summed by kFinSlices blocks */);
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s);
 void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const double* alpha_ptr, const int* lineoff,
                      hipStream_t s);

@@ -2957,12 +2957,57 @@ __global__ void __launch_bounds__(960) k_finalize1(const double* __restrict__ pa
   if (threadIdx.x == 0 && with_scalars) cg1_scalars(rk, ctrl, k);
 }
 
+// The same sums by kFinSlices blocks (large grids): block j adds the records of slice j -- wave c component c, four running sums
+// per lane -- and leaves five slice sums in `scratch`; the block that draws the last ticket adds the slices in slice order.  Which
+// block that is depends on timing, what it computes does not: the order of summation is fixed by (nblocks, kFinSlices).
+// scratch: 5 * kFinSlices doubles + the ticket (zero between launches: the last block resets it).
+__global__ void __launch_bounds__(320) k_finalize1_sliced(const double* __restrict__ partials, int nblocks, double* scratch, double* rk,
+                                                           Ctrl* ctrl, int k, int with_scalars) {
+  if (ctrl->done) return;  // (set by the CG kernel before this launch, or by the last block below after every block has passed here)
+  __shared__ int last;
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int S = (nblocks + kFinSlices - 1) / kFinSlices;
+  const int b0 = blockIdx.x * S, b1 = min(nblocks, b0 + S);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = b0 + lane;
+  for (; b + 192 < b1; b += 256) {
+    a0 += partials[(long long)b * 5 + c];
+    a1 += partials[(long long)(b + 64) * 5 + c];
+    a2 += partials[(long long)(b + 128) * 5 + c];
+    a3 += partials[(long long)(b + 192) * 5 + c];
+  }
+  for (; b < b1; b += 64) a0 += partials[(long long)b * 5 + c];
+  const double v = wave_sum((a0 + a1) + (a2 + a3));
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 5 * kFinSlices);
+  if (lane == 0) __hip_atomic_store(&scratch[blockIdx.x * 5 + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == (unsigned)kFinSlices - 1u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // (agent-scope loads: the slice sums come from other CUs)
+  const double sl = lane < kFinSlices ? __hip_atomic_load(&scratch[lane * 5 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  static_assert(kFinSlices <= 64, "one slice per lane");
+  const double t = wave_sum(sl);
+  if (lane == 0) rk[c] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ticket = 0u;
+    if (with_scalars) cg1_scalars(rk, ctrl, k);
+  }
+}
+
 __global__ void k_scalars1(double* rk, Ctrl* ctrl, int k) {
   if (!ctrl->done) cg1_scalars(rk, ctrl, k);
 }
 
 void launch_finalize1(const double* partials, int nblocks, double* rec_k, Ctrl* ctrl, int k, int with_scalars,
-                      hipStream_t s) {
+                      hipStream_t s, double* scratch) {
+  if (scratch && nblocks >= 4096) {
+    hipLaunchKernelGGL(k_finalize1_sliced, dim3(kFinSlices), dim3(320), 0, s, partials, nblocks, scratch, rec_k, ctrl, k, with_scalars);
+    return;
+  }
   hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(960), 0, s, partials, nblocks, rec_k, ctrl, k, with_scalars);
 }
 void launch_scalars1(double* rec_k, Ctrl* ctrl, int k, hipStream_t s) {

@@ -114,6 +114,7 @@ struct oi_tort {
   bool p_f32 = false;
   size_t p_elem = sizeof(double);
   double* partials = nullptr;
+  double* fin_scratch = nullptr;  // tail of `partials`: slice sums + ticket of the sliced final reduction (launch_finalize1)
   double* hist = nullptr;
   Ctrl* ctrl = nullptr;
   double* scal = nullptr;                // 8 doubles of scratch (flux sums)
@@ -694,6 +695,9 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->changed, 1));
   OIC(dmalloc(h, &h->scal, 8));
   OIC(dmalloc(h, &h->partials, (size_t)8 * g.tune.max_blocks));
+  // (the single-kernel iteration writes 5 doubles per block: the tail of the array is free -- slice sums + ticket of k_finalize1_sliced)
+  h->fin_scratch = h->partials + (size_t)8 * g.tune.max_blocks - kFinScratch;
+  HIPC(hipMemsetAsync(h->fin_scratch, 0, sizeof(double) * kFinScratch, h->stream));
   OIC(dmalloc(h, &h->ctrl, 1));
   HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
   HIPC(hipHostMalloc((void**)&h->h_counters, 8 * sizeof(unsigned long long)));
@@ -1130,7 +1134,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       }
       if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       // (alpha_k, beta_{k+1} and the stop test are formed in the prologue of kernel k + 1; cg_iterate closes the last record)
-      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 0, s); }
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 0, s, h->fin_scratch); }
     } else {
       // slab with neighbours: the two boundary chunks and the interior chunks are two launches on two streams that run
       // SIDE BY SIDE (neither depends on the other; back to back on one stream each pays its own ramp-up and tail: 1.18
@@ -1155,7 +1159,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
         HIPC(hipStreamWaitEvent(s, h->ev_interior, 0));
       }
       if (nb_b < 0 || nb_i < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
-      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s); }
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s, h->fin_scratch); }
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
       HIPC(hipStreamWaitEvent(s, h->ev_exchanged, 0));  // the next kernel reads the ghost planes of q
     }
