@@ -1134,7 +1134,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
       }
       if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
       // (alpha_k, beta_{k+1} and the stop test are formed in the prologue of kernel k + 1; cg_iterate closes the last record)
-      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 0, s, h->fin_scratch); }
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb, rk, h->ctrl, k, 0, s, g.tune.cg1_fin_sliced ? h->fin_scratch : nullptr); }
     } else {
       // slab with neighbours: the two boundary chunks and the interior chunks are two launches on two streams that run
       // SIDE BY SIDE (neither depends on the other; back to back on one stream each pays its own ramp-up and tail: 1.18
@@ -1159,7 +1159,7 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
         HIPC(hipStreamWaitEvent(s, h->ev_interior, 0));
       }
       if (nb_b < 0 || nb_i < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
-      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s, h->fin_scratch); }
+      { PROF(K_FINALIZE); launch_finalize1(h->partials, nb_b + nb_i, rk, h->ctrl, k, 0, s, g.tune.cg1_fin_sliced ? h->fin_scratch : nullptr); }
       OIC(h->comm->allreduce_sum_f64(rk, 5, s));
       HIPC(hipStreamWaitEvent(s, h->ev_exchanged, 0));  // the next kernel reads the ghost planes of q
     }
@@ -2104,6 +2104,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_norot") t.mg_norot = iv != 0;
   else if (k == "mg_post_kernel") t.mg_post_kernel = iv != 0;
   else if (k == "mg_xfirst") t.mg_xfirst = iv != 0;
+  else if (k == "cg1_fin_sliced") t.cg1_fin_sliced = iv != 0;
   else if (k == "fused_zchunk") t.fused_zchunk = iv > 0 ? iv : 0;
   else if (k == "place_min_mb") t.place_min_mb = iv > 0 ? iv : 0;
   else if (k == "place_extent_gb") t.place_extent_gb = (float)value;
@@ -2123,7 +2124,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_compact = old.cg1_compact;
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
-  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst; t.cg1_fin_sliced = old.cg1_fin_sliced;
   t.force_comm = old.force_comm;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;

@@ -121,6 +121,29 @@ def test_c5_share_4096x4096x512_porosity_02_jacobi_pcg():
     t.destroy(); buf.free()
 
 
+def test_final_sums_of_the_single_kernel_iteration_are_reproducible(oi_option):
+    """Large grids sum their per-block partials in 64 slices; the block that draws the last ticket adds the slice sums
+    (k_finalize1_sliced).  WHICH block that is depends on timing, what it computes must not: three runs of 40 iterations on a 512^3
+    volume (4096 blocks, the smallest grid that takes the sliced form) leave the same residual bit for bit, and the one-block sums
+    (`cg1_fin_sliced` = 0, another order of summation) agree to rounding."""
+    shape = (512, 512, 512)
+    buf = oia.gen_spheres_device(shape, 7, 24, 0.4)
+    oi_option("place_trials", 0, reset=48)
+    seen = []
+    for sliced in (1, 1, 1, 0):
+        oi_option("cg1_fin_sliced", sliced, reset=1)
+        t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, maxiter=5000, precond=oia.PRECOND_NONE, kernel=oia.KERNEL_FUSED1)
+        t.cg_begin(); t.cg_iterate(41); t.sync()
+        its, rel, conv = t.cg_state()
+        t.cg_finish()
+        assert its == 40 and not conv
+        seen.append(rel)
+        t.destroy()
+    buf.free()
+    assert seen[0] == seen[1] == seen[2]
+    assert seen[3] == pytest.approx(seen[0], rel=1e-10) and seen[0] < 1.0
+
+
 def test_vector_placement_search_leaves_the_iterates_alone(oi_option):
     """The single-kernel iteration allocates x and a set of vector-sized slots back to back, times a few placements of its six
     double-buffered vectors in them when the handle is built (on MI355X the iteration time depends on the distances between
