@@ -43,7 +43,9 @@ struct Tune {
   int mg_xfirst = 0;          // 1: x += alpha p stays in the first kernel of the rotated iteration (cross-check; default: in the post-smoother)
   int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)
   int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)
-  int mg_nu_coarse = 1;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (1 or 2; the fine level: 1)
+  int mg_nu_coarse = 0;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (the fine level: 1): 1, 2, or
+                         // 0 = by the structure -- 2 where fewer than 35 % of the 8-voxel lines hold a free voxel (low porosity: fewer
+                         // iterations pay for the dearer cycle, profiles/r03/mg_nu_blobs768.txt, c5_share_multigrid_pcg.txt), else 1
   int place_trials = 48; // single-kernel CG: vector placements (six of place_slots allocations made back to back) timed when
                          // the handle is built, the fastest kept; 0 = six slots in order, no search (env OI_PLACE_TRIALS)
   int place_slots = 12;  // slots allocated for the search (6 are kept, the others freed after it), memory permitting

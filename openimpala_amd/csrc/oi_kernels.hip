@@ -84,7 +84,7 @@ Tune default_tune() {
     if (const char* e = getenv("OI_MG_WMASK")) g_tune_defaults.mg_wmask = atoi(e);
     if (const char* e = getenv("OI_MG_SCALE")) g_tune_defaults.mg_scale = (float)atof(e);
     if (getenv("OI_FORCE_COMM")) g_tune_defaults.force_comm = 1;
-    if (const char* e = getenv("OI_MG_NU_COARSE")) g_tune_defaults.mg_nu_coarse = atoi(e) >= 2 ? 2 : 1;
+    if (const char* e = getenv("OI_MG_NU_COARSE")) g_tune_defaults.mg_nu_coarse = atoi(e) >= 2 ? 2 : (atoi(e) == 1 ? 1 : 0);
     if (const char* e = getenv("OI_PLACE_TRIALS")) g_tune_defaults.place_trials = atoi(e);
     if (const char* e = getenv("OI_PLACE_SLOTS")) g_tune_defaults.place_slots = atoi(e);
     if (const char* e = getenv("OI_PLACE_SPACER_GB")) g_tune_defaults.place_spacer_gb = (float)atof(e);

@@ -845,6 +845,12 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     h->rot = !cannot;
     if (h->rot) OIC(dmalloc(h, &h->r2, (size_t)h->nvec_cg));
   }
+  if (want_mg && g.tune.mg_nu_coarse == 0) {
+    // sweeps per coarse-level visit by the structure (every slab the same: the cycle has collectives inside)
+    int one = (h->lineoff && g.live_lines > 0.f && g.live_lines < 0.35f) ? 0 : 1;
+    if (h->comm) OIC(h->comm->allreduce_max_i32_host(&one, 1, s));
+    g.tune.mg_nu_coarse = one ? 1 : 2;
+  }
   if (want_mg) {
     OIC(dmalloc(h, &h->z, (size_t)h->nvec_cg));
     HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
@@ -2093,7 +2099,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_scale") t.mg_scale = (float)value;
   else if (k == "mg_omega") t.mg_omega = (float)value;
   else if (k == "mg_coarsest_plain") t.mg_coarsest_plain = iv != 0;
-  else if (k == "mg_nu_coarse") t.mg_nu_coarse = iv >= 2 ? 2 : 1;
+  else if (k == "mg_nu_coarse") t.mg_nu_coarse = iv >= 2 ? 2 : (iv == 1 ? 1 : 0);
   else if (k == "force_comm") t.force_comm = iv != 0;
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;

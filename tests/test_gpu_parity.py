@@ -285,7 +285,7 @@ def test_multigrid_two_coarse_sweeps(sample, goldens, oi_option):
     g = goldens["phases"]["1"]
     its, hist = {}, {}
     for nu, novec4 in ((1, 0), (2, 0), (2, 1)):
-        oi_option("mg_nu_coarse", nu, reset=1)
+        oi_option("mg_nu_coarse", nu, reset=0)
         oi_option("mg_novec4", novec4, reset=0)
         t = oia.TortuosityMI355(sample, 1, 0, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG)
         tau = t.value()
@@ -297,7 +297,21 @@ def test_multigrid_two_coarse_sweeps(sample, goldens, oi_option):
         t.destroy()
     assert its[(2, 0)] < its[(1, 0)] and its[(2, 0)] == its[(2, 1)]
     assert hist[(2, 0)] == hist[(2, 1)]      # bit-identical solves
-    oi_option("mg_nu_coarse", 2, reset=1)
+    # the default (0) chooses by the structure: two sweeps where fewer than 35 % of the 8-voxel lines hold a free voxel
+    shape = (96, 80, 112)
+    blobs = oia.gen_blobs_device(shape, 11, 10, 0.2)
+    got = {}
+    for nu in (0, 1, 2):
+        oi_option("mg_nu_coarse", nu, reset=0)
+        t = oia.TortuosityMI355(blobs, 1, 2, 0.0, 1.0, shape=shape, eps=1e-9, precond=oia.PRECOND_MG)
+        tau = t.value()
+        assert t.stats().converged
+        got[nu] = (t.stats().iterations, tau, t.live_fraction(8))
+        t.destroy()
+    blobs.free()
+    assert got[2][0] <= got[1][0] and got[1][1] == pytest.approx(got[2][1], rel=1e-7)
+    assert got[0][:2] == (got[2][:2] if got[0][2] < 0.35 else got[1][:2])
+    oi_option("mg_nu_coarse", 2, reset=0)
     oi_option("mg_novec4", 0, reset=0)
     phase = o.gen_spheres((37, 45, 51), 6, 5, 0.5)
     for d in range(3):

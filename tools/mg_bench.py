@@ -7,7 +7,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--structure", default="spheres")
-ap.add_argument("--nu", default="1", help="comma-separated mg_nu_coarse values, alternated")
+ap.add_argument("--nu", default="0", help="comma-separated mg_nu_coarse values, alternated (0 = by the structure)")
 ap.add_argument("--wmask", default="-1", help="comma-separated mg_wmask values (-1 = default)")
 ap.add_argument("--zchunk", default="0", help="comma-separated z-chunk lengths of the marching kernels (0 = automatic)")
 ap.add_argument("--scale", default="0", help="comma-separated mg_scale values (0 = default 1.5)")
