@@ -270,6 +270,14 @@ int oi_tort_line_voxels(void);
  *   "place_min_mb"  vectors below this size are not searched for (default 256: they sit in the Infinity Cache)
  *   "place_cache"   1 (default): a handle reuses the placement an earlier handle of this process found for the same set of
  *                   allocations after verifying it with one timed cycle
+ *   "mg_nu_coarse"  damped-Jacobi sweeps before / after the correction on the coarse levels: 1, 2, or 0 (default) = by the structure
+ *                   (two where fewer than 35 % of the stored lines hold a free voxel, i.e. at low porosity)
+ *   "mg_omega"      Jacobi damping of the cycle's smoothers (default 0.9)
+ *   cross-checks of the multigrid-preconditioned iteration, same iterates bit for bit: "mg_norot" (1: residual update and
+ *                   pre-smoother as two kernels), "fused_kernel" (1: k_fused_a as first kernel), "mg_post_kernel" (1: the fine
+ *                   post-smoother as k_mg_fine), "mg_xfirst" (1: x += alpha p in the first kernel, not in the post-smoother),
+ *                   "mg_coarsest_plain" (1: the coarsest level's sweeps as separate launches); of the single-kernel iteration:
+ *                   "cg1_seg" (0: per-line slot table instead of segment records), "cg1_fin_sliced" (0: final sums by one block)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
  * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM, OI_PLACE_TRIALS, OI_PLACE_SLOTS, OI_PLACE_SPACER_GB, OI_PLACE_EXTENT_GB, OI_PLACE_MIN_MB, OI_PLACE_CACHE seed the same defaults, read ONCE per process.
  * OI_BAD_ARG for an unknown key. */
