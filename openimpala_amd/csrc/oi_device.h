@@ -38,7 +38,8 @@ struct Tune {
   long long mg_replicate_cells = 0;  // > 0: levels with at most this many cells are replicated on every slab (tests)
   int mg_wmask = -1;     // >= 0: levels visited twice per parent visit (cycle-shape experiments)
   float mg_scale = 0.f;  // > 0: scale of the coarse correction
-  float mg_omega = 0.f;  // in (0, 1): Jacobi damping of the cycle (default 0.9)
+  float mg_omega = 0.f;  // in (0, 1]: Jacobi damping of the cycle (default 0.9)
+  float mg_omega_coarse = 0.f;  // in (0, 1]: damping on the coarse levels, if it is to differ from the fine level's (experiments)
   int cg1_fin_sliced = 1;     // 0: the final sums of the single-kernel iteration by one block (cross-check of k_finalize1_sliced)
   int mg_xfirst = 0;          // 1: x += alpha p stays in the first kernel of the rotated iteration (cross-check; default: in the post-smoother)
   int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)

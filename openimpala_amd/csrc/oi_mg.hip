@@ -735,7 +735,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   if (g.tune.mg_replicate_cells > 0) replicate_cells = g.tune.mg_replicate_cells;  // tests: distribute small levels too
   if (g.tune.mg_wmask >= 0) mg->wmask = (unsigned)g.tune.mg_wmask;                   // experiments with the cycle shape
   if (g.tune.mg_scale > 0.f) mg->scale = g.tune.mg_scale;
-  if (g.tune.mg_omega > 0.f && g.tune.mg_omega < 1.f) mg->omega = g.tune.mg_omega;
+  if (g.tune.mg_omega > 0.f && g.tune.mg_omega <= 1.f) mg->omega = g.tune.mg_omega;
   mg->novec4 = g.tune.mg_novec4 != 0;
   mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
   mg->coarsest_plain = g.tune.mg_coarsest_plain != 0;
@@ -745,7 +745,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
     L.d.sz = (long long)L.d.nx * L.d.ny;
     L.d.nzg = L.nz;
     L.d.periodic = periodic ? 1 : 0;
-    L.d.omega = mg->omega;
+    L.d.omega = (g.tune.mg_omega_coarse > 0.f && g.tune.mg_omega_coarse <= 1.f) ? g.tune.mg_omega_coarse : mg->omega;
     L.compact = l < kCompactLevels;
     // keep the slab partition while every rank's slab starts on an even plane, holds at least two
     // planes and the level is worth distributing; otherwise this and all deeper levels are replicated
