@@ -288,7 +288,9 @@ bool fheap_open(const H5& h, uint64_t hdr, FHeap& fh, std::string& why) {
   if (fh.width == 0 || fh.start_size == 0 || (fh.start_size & (fh.start_size - 1)) || (fh.max_direct & (fh.max_direct - 1)) || fh.max_heap_bits < 8 ||
       fh.max_heap_bits > 64 || fh.max_direct < fh.start_size) { why = "fractal heap header out of range"; return false; }
   fh.off_bytes = (fh.max_heap_bits + 7) / 8;
-  fh.len_bytes = std::min(limit_enc_size(fh.max_direct), limit_enc_size(max_managed));  // (H5HF_hdr_finish_init: the smaller encoding)
+  // (H5HF_hdr_finish_init: the smaller of the direct-block OFFSET length -- (log2(max direct size) + 7) / 8 bytes, 2 for 65536 -- and
+  // the encoded size of the largest managed object)
+  fh.len_bytes = std::min((log2u(fh.max_direct) + 7) / 8, limit_enc_size(max_managed));
   fh.dblock_hdr = 5 + (uint64_t)h.so + fh.off_bytes + ((fh.flags & 0x02) ? 4 : 0);
   return true;
 }

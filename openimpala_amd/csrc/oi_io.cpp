@@ -228,7 +228,9 @@ bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& f
       while (o < sl) {
         const int pq = s[o] >> 4, tq = s[o] & 15;
         ++o;
-        if (tq > 3 || pq > 1 || o + (pq ? 128 : 64) > sl) { why = "bad quantisation table"; return false; }
+        // (8-bit baseline frames -- the only ones decoded here -- take 8-bit tables: Pq = 1 belongs to 12-bit precision, and a 16-bit
+        // quantiser times a coefficient would leave the int range the dequantisation works in)
+        if (tq > 3 || pq > 0 || o + 64 > sl) { why = pq ? "16-bit quantisation table in an 8-bit JPEG stream" : "bad quantisation table"; return false; }
         for (int z = 0; z < 64; ++z) {
           t.q[tq][kZigzag[z]] = pq ? (uint16_t)(s[o] << 8 | s[o + 1]) : s[o];
           o += pq ? 2 : 1;
@@ -410,6 +412,8 @@ bool unjpeg(const uint8_t* src, size_t n, const std::vector<uint8_t>& tables, st
       const int s = decode(t.dc[fr.td]);
       if (s < 0 || s > 11) { why = "corrupt JPEG data (DC)"; return false; }
       pred += extend(getbits(s), s);
+      // (an 8-bit sample's DC term lies within +-2^10 * 8; libjpeg range-limits, here a predictor that has run away is an error)
+      if (pred < -32768 || pred > 32767) { why = "corrupt JPEG data (DC predictor out of range)"; return false; }
       blk[0] = pred * t.q[fr.tq][0];
       for (int k = 1; k < 64;) {
         const int rs = decode(t.ac[fr.ta]);
@@ -422,6 +426,7 @@ bool unjpeg(const uint8_t* src, size_t n, const std::vector<uint8_t>& tables, st
         }
         k += r;
         if (k > 63) { why = "corrupt JPEG data (run)"; return false; }
+        if (sz > 10) { why = "corrupt JPEG data (AC magnitude category above 10 at 8-bit precision)"; return false; }
         blk[kZigzag[k]] = extend(getbits(sz), sz) * t.q[fr.tq][kZigzag[k]];
         ++k;
       }

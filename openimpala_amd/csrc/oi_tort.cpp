@@ -114,7 +114,7 @@ struct oi_tort {
   bool p_f32 = false;
   size_t p_elem = sizeof(double);
   double* partials = nullptr;
-  double* fin_scratch = nullptr;  // tail of `partials`: slice sums + ticket of the sliced final reduction (launch_finalize1)
+  double* fin_scratch = nullptr;  // kFinScratch doubles: slice sums + ticket of the sliced final reduction (launch_finalize1)
   double* hist = nullptr;
   Ctrl* ctrl = nullptr;
   double* scal = nullptr;                // 8 doubles of scratch (flux sums)
@@ -240,7 +240,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
     vecset_free(h->vs);
   }
   void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->seg, h->plane_first_dev,
-                 h->partials, h->hist, h->ctrl, h->scal, h->counters, h->changed};
+                 h->partials, h->fin_scratch, h->hist, h->ctrl, h->scal, h->counters, h->changed};
   for (void* d : dev)
     if (d) (void)hipFree(d);
   void* pin[] = {h->h_ctrl, h->h_counters, h->h_changed, h->h_scal};
@@ -364,9 +364,13 @@ namespace {
 struct PlaceKey {
   int device, nslots, nfront;
   size_t slot_bytes, x_bytes, spacer_bytes;
+  // everything else that sets the time of the kernel being placed: element size of p, Jacobi, tile shape, chunk length,
+  // launch order, pairwise x update, kernel form.  One entry per configuration -- a faster configuration of the same
+  // shape must not pass another one's `<= 1.04 * ms_best` check unsearched, a slower one must not overwrite its entry.
+  unsigned long long cfg;
   bool operator<(const PlaceKey& o) const {
-    return std::tie(device, nslots, nfront, slot_bytes, x_bytes, spacer_bytes) <
-           std::tie(o.device, o.nslots, o.nfront, o.slot_bytes, o.x_bytes, o.spacer_bytes);
+    return std::tie(device, nslots, nfront, slot_bytes, x_bytes, spacer_bytes, cfg) <
+           std::tie(o.device, o.nslots, o.nfront, o.slot_bytes, o.x_bytes, o.spacer_bytes, o.cfg);
   }
 };
 struct PlaceEntry { int pl[6]; double ms_first, ms_best; };
@@ -516,7 +520,13 @@ static oi_status place_search(oi_tort* h) {
   hipEvent_t a = nullptr, b = nullptr;
   HIPC(hipEventCreate(&a)); HIPC(hipEventCreate(&b));
   oi_status rc = OI_OK;
-  const PlaceKey key{h->device, ns, v.nfront, h->slot_bytes, h->x_bytes, h->place_spacer_bytes};
+  const oi::Tune& tu = h->g.tune;
+  const unsigned long long cfg = (unsigned long long)(h->p_f32 ? 1 : 0) | (unsigned long long)(h->jacobi ? 2 : 0) |
+                                 (unsigned long long)(tu.cg1_xskip ? 4 : 0) | (unsigned long long)(tu.cg1_fullline ? 8 : 0) |
+                                 (unsigned long long)(tu.cg1_seg ? 16 : 0) | ((unsigned long long)(tu.cg1_kernel & 3) << 5) |
+                                 ((unsigned long long)(tu.tile_map & 7) << 7) | ((unsigned long long)(tu.cg1_rows & 15) << 10) |
+                                 ((unsigned long long)(tu.cg1_waves & 63) << 14) | ((unsigned long long)(tu.zchunk & 0xffff) << 20);
+  const PlaceKey key{h->device, ns, v.nfront, h->slot_bytes, h->x_bytes, h->place_spacer_bytes, cfg};
   int best[6] = {0, 1, 2, 3, 4, 5};
   double best_ms = 0.0, per_iter = 0.0;
   bool done = false;
@@ -615,7 +625,10 @@ static oi_status place_search(oi_tort* h) {
 // second set is allocated while the chosen seven arrays of the first are still held (so that it lands elsewhere),
 // searched, and the better set kept.  Costs a second search in that one case only.
 static oi_status place_vectors(oi_tort* h) {
-  if (!h->vs.x || h->g.tune.place_trials <= 0 || h->hist_cap < 4) return OI_OK;
+  if (!h->vs.x || h->g.tune.place_trials <= 0 || h->hist_cap < 4) {
+    release_unchosen(h);  // (a set allocated for a search that is not going to run keeps its six slots in order, nothing else)
+    return OI_OK;
+  }
   const double t0 = now_s();
   OIC(place_search(h));
   release_unchosen(h);
@@ -644,13 +657,20 @@ static oi_status place_vectors(oi_tort* h) {
     h->bytes_device += old.v.bytes;  // (held during the second search: the peak figure counts it)
     oi_status rc = vecset_alloc(h, true);
     h->bytes_device -= old.v.bytes;
+    // (from here to the end of this block nothing returns early: until one of the two sets has been freed and the other is
+    // h->vs again, `old.v` is owned by this frame only -- an error is carried in `rc` to the branch that puts the first set back)
     int failed = rc == OI_OK ? 0 : 1;
-    if (h->comm) OIC(h->comm->allreduce_max_i32_host(&failed, 1, s));
+    oi_status rc_comm = OI_OK;
+    if (h->comm) rc_comm = h->comm->allreduce_max_i32_host(&failed, 1, s);
+    if (rc_comm != OI_OK) failed = 1;
     const int cache = h->g.tune.place_cache;
     h->g.tune.place_cache = 0;  // (the entry of this shape describes the FIRST set)
     if (!failed) rc = place_search(h);
     h->g.tune.place_cache = cache;
-    HIPC(hipStreamSynchronize(s));
+    if (hipStreamSynchronize(s) != hipSuccess && rc == OI_OK && !failed) {
+      oi::set_error("HIP error after the second placement search: %s", hipGetErrorString(hipGetLastError()));
+      rc = OI_HIP_ERROR;
+    }
     if (!failed && rc == OI_OK && h->placement_ms_best < old.best) {
       release_unchosen(h);
       vecset_free(old.v);
@@ -667,6 +687,7 @@ static oi_status place_vectors(oi_tort* h) {
       h->placement_tried = old.tried + tried2;
       h->placement_ms_first = old.first; h->placement_ms_best = old.best;
       if (failed) (void)hipGetLastError();
+      if (rc_comm != OI_OK) return rc_comm;
       if (!(rc == OI_OK || failed)) return rc;
     }
   }
@@ -695,8 +716,9 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   OIC(dmalloc(h, &h->changed, 1));
   OIC(dmalloc(h, &h->scal, 8));
   OIC(dmalloc(h, &h->partials, (size_t)8 * g.tune.max_blocks));
-  // (the single-kernel iteration writes 5 doubles per block: the tail of the array is free -- slice sums + ticket of k_finalize1_sliced)
-  h->fin_scratch = h->partials + (size_t)8 * g.tune.max_blocks - kFinScratch;
+  // slice sums + ticket of k_finalize1_sliced: their own array (the ticket must stay zero between launches, so nothing else may
+  // ever write there -- round 3 carved it out of the tail of `partials`, safe only while no kernel used the full stride)
+  OIC(dmalloc(h, &h->fin_scratch, (size_t)kFinScratch));
   HIPC(hipMemsetAsync(h->fin_scratch, 0, sizeof(double) * kFinScratch, h->stream));
   OIC(dmalloc(h, &h->ctrl, 1));
   HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
@@ -823,7 +845,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   if (h->cg1) {
     OIC(dmalloc(h, &h->rec, (size_t)kRec1Stride * h->hist_cap));
     // (on slabs every rank must take the same decision: the search runs iterations, and those have collectives inside)
-    int no_search = (g.tune.place_trials > 0 && (size_t)h->nvec_cg * sizeof(double) >= ((size_t)g.tune.place_min_mb << 20)) ? 0 : 1;
+    int no_search = (g.tune.place_trials > 0 && h->hist_cap >= 4 && (size_t)h->nvec_cg * sizeof(double) >= ((size_t)g.tune.place_min_mb << 20)) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&no_search, 1, s));
     OIC(vecset_alloc(h, !no_search));
     const int first[6] = {0, 1, 2, 3, 4, 5};

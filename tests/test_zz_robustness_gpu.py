@@ -148,7 +148,7 @@ def test_handles_release_their_device_memory(sample):
     assert drop < (ncycles - 5) << 20, (drop >> 20, [f >> 20 for f in free], report)
 
 
-def test_searching_single_kernel_handles_release_their_arenas():
+def test_searching_single_kernel_handles_release_their_arenas(oi_option):
     """A single-kernel CG handle whose vectors exceed the placement threshold builds slot arenas (and, for the search, maps
     spare slots and a distance between the two arena halves): all of it is given back -- also the spare slots the search
     did not choose, while the handle is still alive."""
@@ -156,7 +156,7 @@ def test_searching_single_kernel_handles_release_their_arenas():
     ph = oia.gen_bernoulli_device(shape, 7, 0.75)
     free = []
     held = []
-    oia.set_option("place_alloc_budget_s", 1e9)   # (spare slots whatever the driver's clearing of them costs)
+    oi_option("place_alloc_budget_s", 1e9, reset=0.5)   # (spare slots whatever the driver's clearing of them costs)
     for n in range(5):
         t = oia.TortuosityMI355(ph, 1, 0, shape=shape, kernel=oia.KERNEL_FUSED1, eps=1e-3, maxiter=50)
         pl = t.placement()
@@ -168,7 +168,6 @@ def test_searching_single_kernel_handles_release_their_arenas():
         held.append((oia.device_memory()[0], t.stats().bytes_device))
         t.destroy()
         free.append(oia.device_memory()[0])
-    oia.set_option("place_alloc_budget_s", 0.5)
     ph.free()
     # (a reading right after a destroy may lag by a whole handle -- the driver reports freed arrays a little later, see
     # test_handles_release_their_device_memory -- so the test is on the highest readings: no handle left memory behind for good)
