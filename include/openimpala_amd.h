@@ -278,6 +278,8 @@ int oi_tort_line_voxels(void);
  *                   post-smoother as k_mg_fine), "mg_xfirst" (1: x += alpha p in the first kernel, not in the post-smoother),
  *                   "mg_coarsest_plain" (1: the coarsest level's sweeps as separate launches); of the single-kernel iteration:
  *                   "cg1_seg" (0: per-line slot table instead of segment records), "cg1_fin_sliced" (0: final sums by one block)
+ *   "cg1_nt"        1 (default): the streamed vectors of the descriptor-addressed kernels take nontemporal stores / loads (same
+ *                   arithmetic, other cache policy); 0 = the default policy everywhere (A/B)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
  * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM, OI_PLACE_TRIALS, OI_PLACE_SLOTS, OI_PLACE_SPACER_GB, OI_PLACE_EXTENT_GB, OI_PLACE_MIN_MB, OI_PLACE_CACHE seed the same defaults, read ONCE per process.
  * OI_BAD_ARG for an unknown key. */

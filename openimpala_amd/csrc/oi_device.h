@@ -32,6 +32,8 @@ struct Tune {
   int cg1_fullline = 1;  // compacted layout: stored lines read and written whole
   int cg1_compact = 1;   // single-kernel variant: r, q, p stored as compacted live lines
   int cg1_seg = 1;       // k_cg1b: line slots from per-row segment records (scalar loads) instead of the per-line table
+  int cg1_nt = 1;        // k_cg1b (all forms): 1 = the streamed vectors take nontemporal accesses (which ones: kNtSt* / kNtLd* in
+                         // oi_kernels.hip, chosen by in-process A/B, profiles/r04/k_cg1b_cache_policies_*.txt); 0 = default policy
   int cg1_kernel = 0;    // compacted layout: 0 = k_cg1b (descriptor-addressed, all loads of a plane in one burst), 1 = k_cg1
   int apply_kernel = 0;  // stand-alone apply: 0 = wave-autonomous k_apply7, 1 = LDS-tiled k_fused_a<PURE>
   int mg_plain = 0, mg_novec4 = 0, mg_debug = 0;  // multigrid cross-check switches (env OI_MG_PLAIN / _NOVEC4 / _DEBUG)

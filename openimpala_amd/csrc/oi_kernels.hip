@@ -2058,14 +2058,17 @@ constexpr long long kBufMax = 0x7fff0000;  // largest range (bytes) a descriptor
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* p, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+template <int AUX = 0>
 __device__ __forceinline__ double2 bld2(__amdgpu_buffer_rsrc_t r, int off) {
-  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));
 }
 __device__ __forceinline__ double bld1(__amdgpu_buffer_rsrc_t r, int off) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
 }
+// AUX = the store's cache policy (the instruction's aux operand): 0 default, 2 nontemporal
+template <int AUX = 0>
 __device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, int off, double a, double b) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(a, b)), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(a, b)), r, off, 0, AUX);
 }
 // the search direction through a descriptor; `off` is the byte offset the fp64 vectors use (fp32 storage: half of it).
 // Loads return the bits as they were stored (Pair / One); they are widened when they are used, not when they are issued,
@@ -2075,29 +2078,42 @@ template <> struct PBuf<double> {
   typedef double2 Pair;
   typedef double One;
   static constexpr int kLineBytes = 8 * kLV;
-  static __device__ __forceinline__ Pair ld_pair(__amdgpu_buffer_rsrc_t r, int off) { return bld2(r, off); }
+  template <int AUX = 0>
+  static __device__ __forceinline__ Pair ld_pair(__amdgpu_buffer_rsrc_t r, int off) { return bld2<AUX>(r, off); }
   static __device__ __forceinline__ One ld_one(__amdgpu_buffer_rsrc_t r, int off) { return bld1(r, off); }
   static __device__ __forceinline__ double2 wide(Pair v) { return v; }
   static __device__ __forceinline__ double wide1(One v) { return v; }
-  static __device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t r, int off, double a, double b) { bst2(r, off, a, b); }
+  template <int AUX = 0>
+  static __device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t r, int off, double a, double b) { bst2<AUX>(r, off, a, b); }
 };
 template <> struct PBuf<float> {
   typedef float2 Pair;
   typedef float One;
   static constexpr int kLineBytes = 4 * kLV;
+  template <int AUX = 0>
   static __device__ __forceinline__ Pair ld_pair(__amdgpu_buffer_rsrc_t r, int off) {
-    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off >> 1, 0, 0));
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off >> 1, 0, AUX));
   }
   static __device__ __forceinline__ One ld_one(__amdgpu_buffer_rsrc_t r, int off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off >> 1, 0, 0));
   }
   static __device__ __forceinline__ double2 wide(Pair f) { return make_double2((double)f.x, (double)f.y); }
   static __device__ __forceinline__ double wide1(One f) { return (double)f; }
+  template <int AUX = 0>
   static __device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t r, int off, double a, double b) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, make_float2((float)a, (float)b)), r, off >> 1, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, make_float2((float)a, (float)b)), r, off >> 1, 0, AUX);
   }
 };
 
+// STAUX / LDAUX: which vectors leave / arrive with NONTEMPORAL accesses (bit masks; stores: 1 r_out, 2 q_out (FORM 3: z), 4 p_out,
+// 8 x; loads of the tile's own rows: 1 r_in, 2 q_in, 4 p_in, 8 x, 16 p_{k-2}; the halo and the code bytes always take the default
+// policy: they are what the L2 is for).  Chosen per form by in-process A/B on one handle (tools/pol_ab.py, profiles/r04/
+// k_cg1b_cache_policies_*.txt): r, p and x written nontemporally and x, p_{k-2} read nontemporally take 7.6 % off FORM 0, while
+// nontemporal loads of r, q, p (re-read by the neighbouring tiles' halos) cost 10 %.
+constexpr int kNtSt0 = 13, kNtLd0 = 24;
+// (the light forms are instruction-bound and gain less: FORM 1 p_out 1.9 %, FORM 2 r_out 0.7 %, FORM 3 x written and x, p_{k-1} read 1.4 %
+// of the cycle; q_out / z nontemporal is a loss everywhere: the next kernel of the same iteration reads it first)
+constexpr int kNtSt1 = 4, kNtLd1 = 0, kNtSt2 = 1, kNtLd2 = 0, kNtSt3 = 8, kNtLd3 = 12;
 // FORM 0: the single-kernel CG iteration described above.
 // FORM 1: the first kernel of the TWO-kernel iteration (what k_fused_a<.., compacted> computes, for the multigrid-preconditioned
 // solve: x += alpha_{k-1} p_{k-1}; p_k = z_k + beta_k p_{k-1}; q_k = A p_k; partial p_k.q_k) on the same memory side --
@@ -2108,7 +2124,7 @@ template <> struct PBuf<float> {
 // stored to r_out -- double-buffered, the halo ring recomputes it from the inputs), partial r_k.r_k, v = omega r_k / c staged,
 // res = r_k - A v, and the 2x2x2 block sums of res as the fp32 right-hand side of the first coarse level (`bcoarse`, `C`).
 // Chunks hold whole z pairs (even first plane, even length).  Same arithmetic in the same order as the two kernels it replaces.
-template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0>
+template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0, int STAUX = 0, int LDAUX = 0>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     const double* __restrict__ r_in, double* __restrict__ r_out,
                                                     const double* __restrict__ q_in, double* __restrict__ q_out,
@@ -2293,10 +2309,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
 #else
       raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
 #endif
-      raw.r[rr_] = bld2(rb, raw.off[rr_]);
-      if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2(qb, raw.off[rr_]);
+      raw.r[rr_] = bld2<(LDAUX & 1) ? 2 : 0>(rb, raw.off[rr_]);
+      if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2<(LDAUX & 2) ? 2 : 0>(qb, raw.off[rr_]);
       else raw.q[rr_] = make_double2(0.0, 0.0);
-      if (FORM < 2 || (FORM == 3 && with_x)) raw.p[rr_] = PBuf<PT>::ld_pair(pb, raw.off[rr_]);
+      if (FORM < 2 || (FORM == 3 && with_x)) raw.p[rr_] = PBuf<PT>::template ld_pair<(LDAUX & 4) ? 2 : 0>(pb, raw.off[rr_]);
       else raw.p[rr_] = PPair();
       raw.c[rr_] = 0.f;
       if (FORM == 3) raw.c[rr_] = corr_ld(p, (in_x && cn[rr_]) ? ((i >> 1) + C.cnx * (row_of(rr_) >> 1)) * 4 : kOob);
@@ -2315,9 +2331,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
 #endif
 #else
         raw.xoff[rr_] = raw.off[rr_] == kOob ? kOob : ivox8 + row_of(rr_) * g.pitch * 8;
-        raw.xv[rr_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(xb, raw.xoff[rr_], 0, 0));
+        raw.xv[rr_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(xb, raw.xoff[rr_], 0, (LDAUX & 8) ? 2 : 0));
 #endif
-        if (xskip) raw.pold[rr_] = PBuf<PT>::ld_pair(ob, raw.off[rr_]);  // p_{k-2}
+        if (xskip) raw.pold[rr_] = PBuf<PT>::template ld_pair<(LDAUX & 16) ? 2 : 0>(ob, raw.off[rr_]);  // p_{k-2}
       }
     }
   };
@@ -2348,13 +2364,13 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         if (with_x && mode != 0)  // x_k = x_{k-1} + alpha_{k-1} p_{k-1}, the update the first kernel of this iteration leaves out
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(raw.xv[rr_].x + alpha_prev * pin.x,
                                                                                        raw.xv[rr_].y + alpha_prev * pin.y)),
-                                                 xb, raw.xoff[rr_], 0, 0);
+                                                 xb, raw.xoff[rr_], 0, (STAUX & 8) ? 2 : 0);
         continue;
       }
       if (FORM == 2) {  // what is staged is the first damped-Jacobi iterate v = omega r / c of the new residual
         const unsigned short cc = cn[rr_];
         pn[rr_] = make_double2(r0 * wtab[cc & 0xffu], r1 * wtab[cc >> 8]);
-        if (mode != 0) bst2(rob, raw.off[rr_], r0, r1);
+        if (mode != 0) bst2<(STAUX & 1) ? 2 : 0>(rob, raw.off[rr_], r0, r1);
         continue;
       }
       double z0 = r0, z1 = r1;
@@ -2365,7 +2381,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       }
       pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
       if (mode != 0) {
-        if (FORM == 0) bst2(rob, raw.off[rr_], r0, r1);
+        if (FORM == 0) bst2<(STAUX & 1) ? 2 : 0>(rob, raw.off[rr_], r0, r1);
         if (with_x) {
           const double2 xv = raw.xv[rr_];
 #ifdef OI_DEBUG_X
@@ -2389,10 +2405,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
 #endif
 #else
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(xv.x + a0, xv.y + a1)), xb,
-                                                 raw.xoff[rr_], 0, 0);
+                                                 raw.xoff[rr_], 0, (STAUX & 8) ? 2 : 0);
 #endif
         }
-        PBuf<PT>::st_pair(pob, raw.off[rr_], pn[rr_].x, pn[rr_].y);
+        PBuf<PT>::template st_pair<(STAUX & 4) ? 2 : 0>(pob, raw.off[rr_], pn[rr_].x, pn[rr_].y);
       }
     }
   };
@@ -2417,9 +2433,9 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
       const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
       if (wu < 2) {
-        h.r = bld2(rb, off);
-        if (FORM < 2) h.p = PBuf<PT>::ld_pair(pb, off);
-        if (FORM == 0 || FORM == 2) h.q = bld2(qb, off);
+        h.r = bld2<0>(rb, off);
+        if (FORM < 2) h.p = PBuf<PT>::template ld_pair<0>(pb, off);
+        if (FORM == 0 || FORM == 2) h.q = bld2<0>(qb, off);
       } else {
         h.r.x = bld1(rb, off);
         if (FORM < 2) h.p1 = PBuf<PT>::ld_one(pb, off);
@@ -2558,7 +2574,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       const int qoff = (lo_cur[rr_] - (int)pf0) * (8 * kLV) + sub;
 #endif
       xsum[rr_] = 0.0;
-      if (FORM != 2 && fullline && !cc && stored) bst2(qob, qoff, 0.0, 0.0);  // whole lines
+      if (FORM != 2 && fullline && !cc && stored) bst2<(STAUX & 2) ? 2 : 0>(qob, qoff, 0.0, 0.0);  // whole lines
       if (cc) {  // q and every partial sum vanish where both voxels are non-free
         const int base = (wu + rr_ * NW + 1) * kLP + 2 + 2 * lane;
 #if OI_TIMING_KNOCK & 2  // TIMING BUILDS ONLY (wrong results): the stencil without its LDS reads
@@ -2586,11 +2602,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         }
         if (FORM == 3) {  // z = v + omega (b - A v) / c and the partial sum of z.b
           const double o0 = c0 ? pc.x + (rc.x - q0) * wtab[c0] : 0.0, o1 = c1 ? pc.y + (rc.y - q1) * wtab[c1] : 0.0;
-          bst2(qob, qoff, o0, o1);
+          bst2<(STAUX & 2) ? 2 : 0>(qob, qoff, o0, o1);
           s_pq += o0 * rc.x; s_pq += o1 * rc.y;
           continue;
         }
-        bst2(qob, qoff, q0, q1);
+        bst2<(STAUX & 2) ? 2 : 0>(qob, qoff, q0, q1);
         double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
         if (JACOBI) {
           if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
@@ -2729,7 +2745,29 @@ static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double
                           const double* q_in, double* q_out, const void* p_in, void* p_out, double* rec, int k,
                           int zchunk, int tiles_x, int tiles_y, int nzc, int part, int partial_base, double* partials,
                           Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s) {
-  if (seg && g.tune.cg1_seg)
+#ifdef OI_EXP_CACHEPOL  // EXPERIMENT BUILDS: cg1_nt selects a (load, store) cache-policy pair of the default shape
+  if constexpr (R == 2 && NW == 8 && !JAC && std::is_same<PT, double>::value) {
+    if (seg && g.tune.cg1_seg && g.tune.cg1_nt >= 2) {
+#define OI_POL(ID, LD, ST)                                                                                                     \
+  if (g.tune.cg1_nt == ID) {                                                                                                   \
+    hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true, 0, ST, LD>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out, \
+                       (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base, \
+                       partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline, \
+                       (float*)nullptr, MgCoarse{}, 0.0, 0.0);                                                                 \
+    return;                                                                                                                    \
+  }
+      OI_POL(2, 8, 5) OI_POL(3, 8, 13) OI_POL(4, 8, 1) OI_POL(5, 8, 7) OI_POL(6, 24, 5) OI_POL(7, 8, 15) OI_POL(8, 0, 5) OI_POL(9, 8, 9)
+      OI_POL(10, 8, 4) OI_POL(11, 8, 0) OI_POL(12, 8, 12) OI_POL(13, 24, 13) OI_POL(14, 16, 5)
+#undef OI_POL
+    }
+  }
+#endif
+  if (seg && g.tune.cg1_seg && g.tune.cg1_nt)
+    hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true, 0, kNtSt0, kNtLd0>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
+                       (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
+                       partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline,
+                       (float*)nullptr, MgCoarse{}, 0.0, 0.0);
+  else if (seg && g.tune.cg1_seg)
     hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out,
                        (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base,
                        partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline,
@@ -2858,10 +2896,19 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
   fused_chunks(g, cols, true, &zchunk, &nzc);
   if (!grid_fits(g, cols, nzc)) return -1;
   const int blocks = (int)(cols * nzc);
-  hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 2>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r_in, r_out, q,
-                     (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc,
-                     0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1, bcoarse, c,
-                     omega, 0.0);
+#define OI_F2(LD, ST)                                                                                                                     \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 2, ST, LD>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r_in, r_out, q, \
+                     (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc, \
+                     0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1, bcoarse, c, \
+                     omega, 0.0)
+#ifdef OI_EXP_CACHEPOL
+  switch (g.tune.cg1_nt) {
+    case 1: OI_F2(0, 1); return blocks;  case 2: OI_F2(2, 1); return blocks;  case 3: OI_F2(1, 1); return blocks;  case 4: OI_F2(3, 1); return blocks;
+    case 5: OI_F2(2, 0); return blocks;  case 6: OI_F2(3, 0); return blocks;  case 7: OI_F2(1, 0); return blocks;  default: OI_F2(0, 0); return blocks;
+  }
+#endif
+  if (g.tune.cg1_nt) OI_F2(kNtLd2, kNtSt2); else OI_F2(0, 0);
+#undef OI_F2
   return blocks;
 }
 // k_cg1b FORM 3, the fine post-smoother of the cycle on compacted vectors: z = v + omega (b - A v) / c with
@@ -2879,12 +2926,20 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
   const int blocks = (int)(cols * nzc);
   // x != null: x += alpha_{k-1} p_{k-1} (alpha from hist) on the planes this launch writes -- what the first kernel of the
   // two-kernel iteration otherwise does (launch_fused_a with x_elsewhere)
-#define OI_F3(PT)                                                                                                                    \
-  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 3>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, b, z, (const double*)nullptr, \
+#define OI_F3(PT, LD, ST)                                                                                                            \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 3, ST, LD>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, b, z, (const double*)nullptr, \
                      (double*)nullptr, (const PT*)p_prev, (PT*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc, \
                      0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1,  \
                      (float*)nullptr, c, omega, scale)
-  if (x && p_f32) OI_F3(float); else OI_F3(double);
+#ifdef OI_EXP_CACHEPOL
+  if (!(x && p_f32)) switch (g.tune.cg1_nt) {
+    case 1: OI_F3(double, 0, 2); return blocks;   case 2: OI_F3(double, 0, 8); return blocks;   case 3: OI_F3(double, 0, 10); return blocks;
+    case 4: OI_F3(double, 8, 10); return blocks;  case 5: OI_F3(double, 12, 10); return blocks; case 6: OI_F3(double, 12, 8); return blocks;
+    case 7: OI_F3(double, 12, 0); return blocks;  default: OI_F3(double, 0, 0); return blocks;
+  }
+#endif
+  if (g.tune.cg1_nt) { if (x && p_f32) OI_F3(float, kNtLd3, kNtSt3); else OI_F3(double, kNtLd3, kNtSt3); }
+  else { if (x && p_f32) OI_F3(float, 0, 0); else OI_F3(double, 0, 0); }
 #undef OI_F3
   return blocks;
 }
@@ -2902,12 +2957,20 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
     const int blocks = (int)(cols * nzc);
     const bool descr = fused_descr_ok(g, lineoff, plane_first, seg, jacobi);
     if (descr) {
-#define OI_FB(PT)                                                                                                              \
-  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
+#define OI_FB(PT, LD, ST)                                                                                                      \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1, ST, LD>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
                      (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, x_elsewhere ? -1 : 0, zchunk, tiles_x,  \
                      tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,             \
                      (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0, 0.0)
-      if (p_f32) OI_FB(float); else OI_FB(double);
+#ifdef OI_EXP_CACHEPOL
+      if (!p_f32) switch (g.tune.cg1_nt) {
+        case 1: OI_FB(double, 0, 4); return blocks;  case 2: OI_FB(double, 0, 2); return blocks;  case 3: OI_FB(double, 0, 6); return blocks;
+        case 4: OI_FB(double, 1, 6); return blocks;  case 5: OI_FB(double, 1, 4); return blocks;  case 6: OI_FB(double, 1, 0); return blocks;
+        case 7: OI_FB(double, 4, 4); return blocks;  default: OI_FB(double, 0, 0); return blocks;
+      }
+#endif
+      if (g.tune.cg1_nt) { if (p_f32) OI_FB(float, kNtLd1, kNtSt1); else OI_FB(double, kNtLd1, kNtSt1); }
+      else { if (p_f32) OI_FB(float, 0, 0); else OI_FB(double, 0, 0); }
 #undef OI_FB
       return blocks;
     }

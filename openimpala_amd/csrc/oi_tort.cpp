@@ -2111,6 +2111,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   const std::string k(key);
   const int iv = (int)value;
   if (k == "tile_map") t.tile_map = iv;
+  else if (k == "cg1_nt") t.cg1_nt = iv;
   else if (k == "zchunk") t.zchunk = iv > 0 ? iv : 0;
   else if (k == "apply_kernel") t.apply_kernel = iv;
   else if (k == "mg_plain") t.mg_plain = iv != 0;
