@@ -25,7 +25,8 @@ struct Tune {
   int fused_rows = 2;    // rows per thread of k_fused_a (tile height 8 x rows)
   int fused_kernel = 0;  // first kernel of the two-kernel iteration on compacted vectors: 0 = k_cg1b<FORM 1> (descriptor-addressed), 1 = k_fused_a
   int mg_norot = 0;      // 1: keep k_update_r_lines + the pre-smoother as two kernels (cross-check of the rotated iteration)
-  int fused_zchunk = 16; // its planes per block on large volumes (both kernels and both layouts: same partial sums)
+  int fused_zchunk = 32; // its planes per block on large volumes (both kernels and both layouts: same partial sums); 16 until the
+                         // nontemporal policy of round 4: 32 takes 2.2 % off the multigrid-PCG iteration (profiles/r04/mg_forms_chunk_length.txt)
   int pure_rows = 4;     // the same for the LDS-tiled stand-alone apply
   int cg1_rows = 2, cg1_waves = 8, cg1_auto = 1;  // k_cg1 tile: rows per thread, waves per block; auto = by plane size
   int cg1_xskip = 1;     // k_cg1: x touched every second iteration

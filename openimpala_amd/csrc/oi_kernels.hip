@@ -2124,7 +2124,7 @@ constexpr int kNtSt1 = 4, kNtLd1 = 0, kNtSt2 = 1, kNtLd2 = 0, kNtSt3 = 8, kNtLd3
 // stored to r_out -- double-buffered, the halo ring recomputes it from the inputs), partial r_k.r_k, v = omega r_k / c staged,
 // res = r_k - A v, and the 2x2x2 block sums of res as the fp32 right-hand side of the first coarse level (`bcoarse`, `C`).
 // Chunks hold whole z pairs (even first plane, even length).  Same arithmetic in the same order as the two kernels it replaces.
-template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0, int STAUX = 0, int LDAUX = 0>
+template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0, int STAUX = 0, int LDAUX = 0, int VAR = 0>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     const double* __restrict__ r_in, double* __restrict__ r_out,
                                                     const double* __restrict__ q_in, double* __restrict__ q_out,
@@ -2133,9 +2133,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
                                                     int tiles_x, int tiles_y, int nzc, int part, int partial_base,
                                                     double* __restrict__ partials, Ctrl* ctrl,
                                                     const int* __restrict__ lineoff, const long long* __restrict__ plane_first,
-                                                    const uint2* __restrict__ seg, int LW, int fullline,
+                                                    const uint2* __restrict__ seg, int LW, int fullline_arg,
                                                     float* __restrict__ bcoarse, MgCoarse C, double omega, double scale) {
   constexpr int BY = NW * R;
+  const int fullline = (VAR & 1) ? 1 : fullline_arg;  // (VAR: EXPERIMENT instantiations only -- 1 whole lines as a compile-time fact, 2 / 4 no halo reads)
   constexpr int TS = (BY + 2) * kLP;  // doubles per staged plane
   static_assert(2 * BY <= 64, "wave 2 loads the 2*BY x-halo values with one lane each");
   if (!(OI_TIMING_KNOCK & 8) && ctrl && ctrl->done) return;
@@ -2309,11 +2310,22 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
 #else
       raw.off[rr_] = st ? (ln[rr_] - (int)pfa) * (8 * kLV) + sub : kOob;
 #endif
+      // LDAUX & 32: the tile's INTERIOR rows arrive nontemporally (no neighbouring tile reads them as its halo rows); the
+      // first and last row keep the default policy.  (wave-uniform choice between two instructions: the policy is an immediate)
+      const bool inner = (LDAUX & 32) && !((wu == 0 && rr_ == 0) || (wu == NW - 1 && rr_ == R - 1));
+      if (inner) {
+        raw.r[rr_] = bld2<2>(rb, raw.off[rr_]);
+        if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2<2>(qb, raw.off[rr_]);
+        else raw.q[rr_] = make_double2(0.0, 0.0);
+        if (FORM < 2 || (FORM == 3 && with_x)) raw.p[rr_] = PBuf<PT>::template ld_pair<2>(pb, raw.off[rr_]);
+        else raw.p[rr_] = PPair();
+      } else {
       raw.r[rr_] = bld2<(LDAUX & 1) ? 2 : 0>(rb, raw.off[rr_]);
       if (FORM == 0 || FORM == 2) raw.q[rr_] = bld2<(LDAUX & 2) ? 2 : 0>(qb, raw.off[rr_]);
       else raw.q[rr_] = make_double2(0.0, 0.0);
       if (FORM < 2 || (FORM == 3 && with_x)) raw.p[rr_] = PBuf<PT>::template ld_pair<(LDAUX & 4) ? 2 : 0>(pb, raw.off[rr_]);
       else raw.p[rr_] = PPair();
+      }
       raw.c[rr_] = 0.f;
       if (FORM == 3) raw.c[rr_] = corr_ld(p, (in_x && cn[rr_]) ? ((i >> 1) + C.cnx * (row_of(rr_) >> 1)) * 4 : kOob);
     }
@@ -2421,7 +2433,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob;
   };
 #else
-  auto halo_offset = [&](long long pfa) { return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob; };
+  // (VAR & 2 / VAR & 4, EXPERIMENT instantiations with wrong results: what the vector reads of the halo rows / columns cost)
+  auto halo_offset = [&](long long pfa) {
+    if (((VAR & 2) && wu < 2) || ((VAR & 4) && wu == 2)) return kOob;
+    return (is_halo && hcode) ? (hslot - (int)pfa) * (8 * kLV) + hsub : kOob;
+  };
 #endif
   auto halo_issue = [&](int hp, long long pfa, long long pfb, int off, HRaw& h) {
     h.r = h.q = make_double2(0.0, 0.0);
@@ -2615,7 +2631,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         s_pq += pc.x * q0; s_pq += pc.y * q1;
         if (FORM == 0) {
           s_rr += rc.x * rc.x; s_rr += rc.y * rc.y;
-          s_rz += rc.x * z0; s_rz += rc.y * z1;
+          if (JACOBI) { s_rz += rc.x * z0; s_rz += rc.y * z1; }  // (without Jacobi z = r: the same products in the same order as s_rr)
           s_zq += z0 * q0; s_zq += z1 * q1;
           s_qdq += q0 * d0; s_qdq += q1 * d1;
         }
@@ -2711,7 +2727,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     return;
   }
   const double t0 = block_sum(s_rr, red);
-  const double t1 = block_sum(s_rz, red);
+  const double t1 = JACOBI ? block_sum(s_rz, red) : t0;
   const double t2 = block_sum(s_pq, red);
   const double t3 = block_sum(s_zq, red);
   const double t4 = block_sum(s_qdq, red);
@@ -2748,16 +2764,15 @@ static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double
 #ifdef OI_EXP_CACHEPOL  // EXPERIMENT BUILDS: cg1_nt selects a (load, store) cache-policy pair of the default shape
   if constexpr (R == 2 && NW == 8 && !JAC && std::is_same<PT, double>::value) {
     if (seg && g.tune.cg1_seg && g.tune.cg1_nt >= 2) {
-#define OI_POL(ID, LD, ST)                                                                                                     \
+#define OI_POL(ID, LD, ST, VR)                                                                                                    \
   if (g.tune.cg1_nt == ID) {                                                                                                   \
-    hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true, 0, ST, LD>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out, \
+    hipLaunchKernelGGL((k_cg1b<R, NW, PT, JAC, true, 0, ST, LD, VR>), dim3(blocks), dim3(64 * NW), 0, s, g, code, x, r_in, r_out, q_in, q_out, \
                        (const PT*)p_in, (PT*)p_out, rec, k, g.tune.cg1_xskip, zchunk, tiles_x, tiles_y, nzc, part, partial_base, \
                        partials, ctrl, lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, g.tune.cg1_fullline, \
                        (float*)nullptr, MgCoarse{}, 0.0, 0.0);                                                                 \
     return;                                                                                                                    \
   }
-      OI_POL(2, 8, 5) OI_POL(3, 8, 13) OI_POL(4, 8, 1) OI_POL(5, 8, 7) OI_POL(6, 24, 5) OI_POL(7, 8, 15) OI_POL(8, 0, 5) OI_POL(9, 8, 9)
-      OI_POL(10, 8, 4) OI_POL(11, 8, 0) OI_POL(12, 8, 12) OI_POL(13, 24, 13) OI_POL(14, 16, 5)
+      OI_POL(2, 24, 13, 0) OI_POL(3, 24, 13, 1) OI_POL(4, 24, 13, 2) OI_POL(5, 24, 13, 4) OI_POL(6, 24, 13, 6)
 #undef OI_POL
     }
   }
@@ -2821,7 +2836,10 @@ Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part) {
     // sparse structures (a quarter of the lines stored: config 5's porosity 0.2) do better with long chunks -- little to
     // overlap per plane, and the chunk-end planes cost the same (profiles/r02/k_cg1b_sweep.txt: 46.8 vs 49.0 ms on
     // config 5's share, 4.94 vs 5.07 ms at 1024^3); the sphere pack (half of the lines) with 16 planes
-    gs_.tune.zchunk = (g.live_lines > 0.f && g.live_lines < 0.35f) ? 64 : 16;
+    // (round 4, with the nontemporal policy -- the written vectors no longer push the chunk's own planes out of the L2 --:
+    // 24 / 32 / 48 planes 6.05 ms against 6.11 with 16 and 6.13 with 64, same handle, alternating:
+    // profiles/r04/k_cg1b_chunk_length_tile_map_blobs_with_nontemporal.txt)
+    gs_.tune.zchunk = (g.live_lines > 0.f && g.live_lines < 0.35f) ? 64 : (g.tune.cg1_nt ? 32 : 16);
     pick_chunks(gs_, cols, false, &o.zchunk, &o.nzc);
   } else if (split && g.tune.zchunk <= 0) {
     Geom gs_ = g;
