@@ -2773,6 +2773,7 @@ static void launch_cg1b_k(int blocks, const Geom& g, const uint8_t* code, double
     return;                                                                                                                    \
   }
       OI_POL(2, 24, 13, 0) OI_POL(3, 24, 13, 1) OI_POL(4, 24, 13, 2) OI_POL(5, 24, 13, 4) OI_POL(6, 24, 13, 6)
+      OI_POL(7, 24 + 1, 13, 0) OI_POL(8, 24 + 2, 13, 0) OI_POL(9, 24 + 4, 13, 0)
 #undef OI_POL
     }
   }
