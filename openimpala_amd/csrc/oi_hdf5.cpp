@@ -18,14 +18,18 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/openimpala_amd.h"
+#include "oi_hostpar.h"
 
 namespace oi {
 void set_error(const char* fmt, ...);
@@ -509,20 +513,12 @@ bool parse_dataset(const H5& h, uint64_t addr, Dataset& d, std::string& why) {
   return true;
 }
 
-double elem_as_double(const uint8_t* p, const Dataset& d) {
-  uint8_t b[8];
-  for (int i = 0; i < d.type_size; ++i) b[i] = d.big_endian ? p[d.type_size - 1 - i] : p[i];
-  if (d.type_class == 1) {
-    if (d.type_size == 4) { float v; memcpy(&v, b, 4); return v; }
-    double v; memcpy(&v, b, 8); return v;
-  }
-  switch (d.type_size) {
-    case 1: return d.is_signed ? (double)(int8_t)b[0] : (double)b[0];
-    case 2: { uint16_t v; memcpy(&v, b, 2); return d.is_signed ? (double)(int16_t)v : (double)v; }
-    case 4: { uint32_t v; memcpy(&v, b, 4); return d.is_signed ? (double)(int32_t)v : (double)v; }
-    default: { uint64_t v; memcpy(&v, b, 8); return d.is_signed ? (double)(int64_t)v : (double)v; }
-  }
+bool host_le() {
+  const uint16_t one = 1;
+  return *reinterpret_cast<const uint8_t*>(&one) == 1;
 }
+// the dataset's element type in the terms of oi::threshold_run (a sample is swapped when the file's byte order is not the host's)
+int sample_class(const Dataset& d) { return d.type_class == 1 ? oi::kSampleFloat : (d.is_signed ? oi::kSampleSigned : oi::kSampleUnsigned); }
 
 // walks the v1 chunk B-tree and hands every chunk to `fn(offsets, addr, nbytes)`
 template <typename F>
@@ -835,8 +831,13 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
       for (uint64_t v = 0; v < n; ++v) out[v] = 0.0 > threshold ? 1 : 0;
     } else {
       if (!h.ok(src, X * Y * Z * es)) return fail("raw data outside the file");
-      const uint64_t first = X * Y * za;
-      for (uint64_t v = 0; v < n; ++v) out[v] = elem_as_double(&h.f[src + (first + v) * es], d) > threshold ? 1 : 0;
+      // plane by plane on the host cores this process may use, compared in the sample's own type where that gives the same
+      // bits as the double compare (oi_hostpar.h)
+      const uint8_t* base = &h.f[src + X * Y * za * es];
+      const uint64_t plane = X * Y;
+      oi::parallel_for((size_t)(zb - za), [&](size_t k) {
+        (void)oi::threshold_run(base + k * plane * es, (size_t)plane, (int)es, sample_class(d), d.big_endian == host_le(), threshold, out + k * plane);
+      });
     }
   } else if (d.layout == 2) {
     if (d.chunk_rank != 4) return fail("chunk rank does not match the dataset rank");
@@ -846,38 +847,64 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
       return fail("chunk dimensions out of range");
     const uint64_t cbytes = cz * cy * cx * es;
     if (0.0 > threshold) memset(out, 1, n);  // chunks that were never written hold the fill value 0
-    std::vector<uint8_t> raw(cbytes), tmp(cbytes);
     bool good = true;
     std::string cerr;
+    // first the index walk (sequential: B-tree / array pages), then the chunks themselves -- inflate, un-shuffle, threshold --
+    // on the host cores this process may use: every chunk writes its own box of `out`
+    struct ChunkRec { uint64_t offs[3], addr, nbytes; };
+    std::vector<ChunkRec> chunks;
     auto take_chunk = [&](const uint64_t* offs, uint64_t addr, uint64_t nbytes) {
         if (offs[0] >= zb || offs[0] + cz <= za) return true;  // chunk outside the requested planes
+        if (offs[1] >= Y || offs[2] >= X) return true;          // (a corrupted index: nothing of it lies inside the dataset)
         if (!h.ok(addr, nbytes)) { cerr = "chunk outside the file"; return false; }
-        const uint8_t* src = &h.f[addr];
-        if (d.f_deflate) {
-          uLongf dl = (uLongf)cbytes;
-          if (uncompress(raw.data(), &dl, src, (uLong)nbytes) != Z_OK || dl != cbytes) { cerr = "deflate failed"; return false; }
-          src = raw.data();
-        } else if (nbytes < cbytes) { cerr = "short chunk"; return false; }
-        if (d.f_shuffle && es > 1) {  // un-shuffle: byte planes -> elements
-          const uint64_t ne = cbytes / es;
-          for (uint64_t e = 0; e < ne; ++e)
-            for (uint64_t b = 0; b < es; ++b) tmp[e * es + b] = src[b * ne + e];
-          src = tmp.data();
-        }
-        for (uint64_t k = 0; k < cz && offs[0] + k < zb; ++k) {
-          if (offs[0] + k < za) continue;
-          for (uint64_t j = 0; j < cy && offs[1] + j < Y; ++j)
-            for (uint64_t i = 0; i < cx && offs[2] + i < X; ++i) {
-              const uint64_t se = (k * cy + j) * cx + i;
-              out[((offs[0] + k - za) * Y + offs[1] + j) * X + offs[2] + i] = elem_as_double(src + se * es, d) > threshold ? 1 : 0;
-            }
-        }
+        if (!d.f_deflate && nbytes < cbytes) { cerr = "short chunk"; return false; }
+        chunks.push_back(ChunkRec{{offs[0], offs[1], offs[2]}, addr, nbytes});
         return true;
     };
     if (d.chunk_index != 0) {
       good = for_each_chunk_v4(h, d, za, zb, take_chunk, cerr);
     } else if (d.chunk_btree != kUndef) {
       good = for_each_chunk(h, d, h.base + d.chunk_btree, take_chunk);
+    }
+    if (good) {
+      std::mutex mu;
+      std::atomic<int> bad{0};
+      const int cls = sample_class(d);
+      const bool swap = d.big_endian == host_le();
+      oi::parallel_for(chunks.size(), [&](size_t ci) {
+        if (bad.load()) return;
+        thread_local std::vector<uint8_t> raw, tmp, row;
+        const ChunkRec& c = chunks[ci];
+        const uint8_t* src = &h.f[c.addr];
+        if (d.f_deflate) {
+          raw.resize(cbytes);
+          uLongf dl = (uLongf)cbytes;
+          if (uncompress(raw.data(), &dl, src, (uLong)c.nbytes) != Z_OK || dl != cbytes) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!bad.exchange(1)) cerr = "deflate failed";
+            return;
+          }
+          src = raw.data();
+        }
+        if (d.f_shuffle && es > 1) {  // un-shuffle: byte planes -> elements
+          tmp.resize(cbytes);
+          const uint64_t ne = cbytes / es;
+          for (uint64_t b = 0; b < es; ++b) {
+            const uint8_t* sp = src + b * ne;
+            uint8_t* dp = tmp.data() + b;
+            for (uint64_t e = 0; e < ne; ++e) dp[e * es] = sp[e];
+          }
+          src = tmp.data();
+        }
+        const uint64_t nxr = std::min<uint64_t>(cx, X - c.offs[2]);  // (offs[2] < X: take_chunk)
+        for (uint64_t k = 0; k < cz && c.offs[0] + k < zb; ++k) {
+          if (c.offs[0] + k < za) continue;
+          for (uint64_t j = 0; j < cy && c.offs[1] + j < Y; ++j)
+            (void)oi::threshold_run(src + ((k * cy + j) * cx) * es, (size_t)nxr, (int)es, cls, swap, threshold,
+                                    out + ((c.offs[0] + k - za) * Y + c.offs[1] + j) * X + c.offs[2]);
+        }
+      });
+      if (bad.load()) good = false;
     }
     if (!good) return fail(cerr.empty() ? "corrupt chunk index" : cerr.c_str());
   } else {

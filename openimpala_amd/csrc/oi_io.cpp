@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/openimpala_amd.h"
+#include "oi_hostpar.h"
 
 namespace oi {
 void set_error(const char* fmt, ...);
@@ -580,18 +581,6 @@ bool host_is_le() {
   return *reinterpret_cast<const uint8_t*>(&one) == 1;
 }
 
-// host cores this process may use (cgroup / affinity aware enough: sched_getaffinity)
-unsigned host_threads() {
-  cpu_set_t set;
-  CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-    const int n = CPU_COUNT(&set);
-    if (n > 0) return (unsigned)n;
-  }
-  const unsigned h = std::thread::hardware_concurrency();
-  return h ? h : 1;
-}
-
 // header + directory chain of one file
 oi_status open_tiff(const char* path, File& f, std::vector<Ifd>& pages) {
   if (!f.d.open(path) || f.d.size() < 8) {
@@ -781,25 +770,16 @@ extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int
   // pages are independent: decode them on the host cores this process may use
   std::string first_error;
   std::mutex mu;
-  std::atomic<size_t> next{0};
   std::atomic<int> failed{0};
-  auto worker = [&]() {
-    std::vector<uint8_t> buf;
-    for (;;) {
-      const size_t k = next.fetch_add(1);
-      if (k >= (size_t)nz_local || failed.load()) return;
-      const oi_status s1 = decode_page(path, f, pages[z0 + k], p0, z0 + k, threshold, out + k * W * H, buf);
-      if (s1 != OI_OK) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!failed.exchange((int)s1)) first_error = oi::last_error();  // (the message is thread-local)
-      }
+  oi::parallel_for((size_t)nz_local, [&](size_t k) {
+    if (failed.load()) return;
+    thread_local std::vector<uint8_t> buf;
+    const oi_status s1 = decode_page(path, f, pages[z0 + k], p0, z0 + k, threshold, out + k * W * H, buf);
+    if (s1 != OI_OK) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failed.exchange((int)s1)) first_error = oi::last_error();  // (the message is thread-local)
     }
-  };
-  const unsigned nthreads = std::max(1u, std::min<unsigned>({host_threads(), 16u, (unsigned)nz_local}));
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto& t : pool) t.join();
+  });
   if (failed.load()) {
     oi_free_host(out);
     oi::set_error("%s", first_error.c_str());
@@ -885,21 +865,19 @@ extern "C" oi_status oi_read_raw_planes(const char* path, int nx, int ny, int nz
   uint8_t* out = (uint8_t*)oi::host_alloc(n, false);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   const bool swap = bpv > 1 && le != host_is_le();
-  for (size_t v = 0; v < n; ++v) {
-    const uint8_t* p = d.data() + (first + v) * bpv;
-    double val = 0.0;
-    switch (dtype) {
-      case OI_RAW_UINT8: val = (double)p[0]; break;
-      case OI_RAW_INT8: val = (double)(int8_t)p[0]; break;
-      case OI_RAW_UINT16_LE: case OI_RAW_UINT16_BE: val = (double)load_swapped<uint16_t>(p, swap); break;
-      case OI_RAW_INT16_LE: case OI_RAW_INT16_BE: val = (double)load_swapped<int16_t>(p, swap); break;
-      case OI_RAW_UINT32_LE: case OI_RAW_UINT32_BE: val = (double)load_swapped<uint32_t>(p, swap); break;
-      case OI_RAW_INT32_LE: case OI_RAW_INT32_BE: val = (double)load_swapped<int32_t>(p, swap); break;
-      case OI_RAW_FLOAT32_LE: case OI_RAW_FLOAT32_BE: val = (double)load_swapped<float>(p, swap); break;
-      default: val = load_swapped<double>(p, swap); break;
-    }
-    out[v] = val > threshold ? 1 : 0;  // strictly greater (RawReader.H:214)
+  // `(double)sample > threshold`, strictly greater (RawReader.H:214), plane by plane on the host cores this process may use;
+  // integers of up to 32 bits are compared in their own type (oi_hostpar.h: the same bits as the double compare)
+  int cls = oi::kSampleUnsigned;
+  switch (dtype) {
+    case OI_RAW_INT8: case OI_RAW_INT16_LE: case OI_RAW_INT16_BE: case OI_RAW_INT32_LE: case OI_RAW_INT32_BE: cls = oi::kSampleSigned; break;
+    case OI_RAW_FLOAT32_LE: case OI_RAW_FLOAT32_BE: case OI_RAW_FLOAT64_LE: case OI_RAW_FLOAT64_BE: cls = oi::kSampleFloat; break;
+    default: break;
   }
+  const size_t plane = (size_t)nx * ny;
+  const uint8_t* base = d.data() + first * bpv;
+  oi::parallel_for((size_t)nz_local, [&](size_t k) {
+    (void)oi::threshold_run(base + k * plane * bpv, plane, (int)bpv, cls, swap, threshold, out + k * plane);
+  });
   *phase = out;
   return OI_OK;
 }
@@ -926,7 +904,13 @@ extern "C" oi_status oi_read_dat(const char* path, double threshold, uint8_t** p
   uint8_t* out = (uint8_t*)oi::host_alloc(n, false);
   if (!out) { oi::set_error("out of memory"); return OI_IO_ERROR; }
   const uint16_t thr = (uint16_t)threshold;  // DatReader::threshold takes the raw type (uint16)
-  for (size_t v = 0; v < n; ++v) out[v] = load_swapped<uint16_t>(d.data() + 12 + 2 * v, swap) > thr ? 1 : 0;
+  const size_t plane = (size_t)w * h;
+  const uint8_t* vox = d.data() + 12;
+  oi::parallel_for((size_t)dep, [&](size_t k) {
+    const uint8_t* sp = vox + 2 * k * plane;
+    uint8_t* dp = out + k * plane;
+    for (size_t v = 0; v < plane; ++v) dp[v] = oi::load_sample<uint16_t>(sp + 2 * v, swap) > thr ? 1 : 0;
+  });
   *phase = out; *nx = w; *ny = h; *nz = dep;
   return OI_OK;
 }

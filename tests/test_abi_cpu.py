@@ -72,6 +72,36 @@ def test_raw_reader_types(tmp_path):
         oia.RawReader(str(p), 5, 4, 4, "UINT8").threshold(1.0)  # size mismatch
 
 
+def test_raw_reader_thresholds_equal_the_double_compare_for_every_type(tmp_path):
+    """The readers compare integer samples of up to 32 bits in their own type (v > floor(t), vectorised, plane by plane on several
+    threads): the result must be what the reference's `(double)value > threshold` gives for EVERY sample type, byte order and
+    threshold -- fractional, negative, at and beyond the type's range, infinite, NaN -- including the type's extreme values."""
+    rng = np.random.default_rng(5)
+    shape = (9, 7, 33)   # (planes, rows, columns): more planes than one thread takes
+    types = {"UINT8": "u1", "INT8": "i1", "INT16_LE": "<i2", "INT16_BE": ">i2", "UINT16_LE": "<u2", "UINT16_BE": ">u2", "INT32_LE": "<i4",
+             "INT32_BE": ">i4", "UINT32_LE": "<u4", "UINT32_BE": ">u4", "FLOAT32_LE": "<f4", "FLOAT32_BE": ">f4", "FLOAT64_LE": "<f8",
+             "FLOAT64_BE": ">f8"}
+    for name, dt in types.items():
+        d = np.dtype(dt)
+        if d.kind in "iu":
+            info = np.iinfo(d)
+            a = rng.integers(info.min, info.max, size=shape, dtype=np.int64, endpoint=True).astype(d)
+            a.flat[:4] = [info.min, info.max, 0 if info.min < 0 else 1, info.max - 1]
+            thresholds = [0.0, 0.5, -0.5, -1.0, 100.0, 100.999, float(info.min), float(info.min) - 1.0, float(info.min) + 0.5, float(info.max),
+                          float(info.max) - 0.5, float(info.max) - 1.0, float(info.max) + 1.0, 1e30, -1e30, float("inf"), float("-inf"), float("nan")]
+        else:
+            a = (rng.standard_normal(shape) * 100).astype(d)
+            a.flat[:3] = [0.0, -0.0, 100.0]
+            thresholds = [0.0, 100.0, -3.25, float("inf"), float("-inf"), float("nan")]
+        p = tmp_path / f"{name}.raw"
+        a.tofile(p)
+        r = oia.RawReader(str(p), shape[2], shape[1], shape[0], name)
+        for t in thresholds:
+            want = (a.astype(np.float64) > t).astype(np.uint8)
+            assert np.array_equal(r.threshold(t), want), (name, t)
+            assert np.array_equal(r.threshold(t, z0=2, nz_local=5), want[2:7]), (name, t)
+
+
 def test_remspot_needs_the_device():
     """remspot runs on the GPU like every other compute step: no CPU path to fall back to."""
     with pytest.raises(oia.OpenImpalaError):
@@ -343,8 +373,9 @@ def test_launch_geometry_never_exceeds_the_partial_sum_array(descr):
                 assert 0 <= blocks <= cap, (nx, ny, nzl, split, part, blocks, cap)
                 total += blocks
             assert total <= cap and total >= 1
-    # the default of the descriptor-addressed kernel at the bench size: 16-row tiles, 16-plane chunks
-    assert oia.cg1_grid(1024, 1024, 1024, descr=1)[:3] == (16, 16, 8 * 64 * 64)
+    # the default of the descriptor-addressed kernel at the bench size: 16-row tiles, 32-plane chunks (16 until the nontemporal
+    # policy of round 4, profiles/r04/k_cg1b_chunk_length_tile_map_blobs_with_nontemporal.txt)
+    assert oia.cg1_grid(1024, 1024, 1024, descr=1)[:3] == (16, 32, 8 * 64 * 32)
     assert oia.cg1_grid(1024, 1024, 1024, descr=0)[0] == 32
 
 
