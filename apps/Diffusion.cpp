@@ -152,9 +152,14 @@ int main(int argc, char* argv[]) {
     const std::filesystem::path input_path = std::filesystem::path(data_path) / filename;
     if (verbose >= 1) std::cout << "Reading full domain data from: " << input_path.string() << std::endl;
     Volume vol;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     try {
+      const auto t_read = std::chrono::steady_clock::now();
       oi_read_set_pinned(1);  // (pageable memory when no device is visible: the error is reported where a device is needed)
       vol = load_volume(input_path, threshold, in);
+      if (verbose >= 1)
+        std::cout << "  Read + threshold: " << vol.nx << " x " << vol.ny << " x " << vol.nz << " voxels in " << std::defaultfloat
+                  << std::setprecision(4) << since(t_read) << " s (incl. the first use of the device when the buffer is page-locked)\n";
     } catch (const std::exception& e) {
       std::cout << "Error loading full domain data: " << e.what() << std::endl;
       std::cerr << "Full domain data loading failed." << std::endl;
@@ -401,9 +406,11 @@ int main(int argc, char* argv[]) {
     } dev_phase;
     const bool share_upload = opts.device <= 0 && ngpus == 1;  // oi_dev_malloc allocates on the current (= default) device
     if (!dirs.empty() && share_upload) {
+      const auto t_up = std::chrono::steady_clock::now();
       oi_status ds = oi_dev_malloc(&dev_phase.p, vol.phase.size());
       if (ds == OI_OK) ds = oi_dev_upload(dev_phase.p, vol.phase.data(), vol.phase.size());
       if (ds != OI_OK) throw std::runtime_error(std::string(oi_status_string(ds)) + ": " + oi_last_error());
+      if (verbose >= 1) std::cout << "  Upload of the phase bytes (once for all directions): " << std::defaultfloat << std::setprecision(4) << since(t_up) << " s\n";
     }
     for (const auto dir : dirs) {
       const std::string dc = dir == OpenImpala::Direction::X ? "X" : (dir == OpenImpala::Direction::Y ? "Y" : "Z");
@@ -413,6 +420,8 @@ int main(int argc, char* argv[]) {
       std::vector<double> phi;
       std::vector<std::uint8_t> mask;
       bool have_phi = false, have_mask = false;
+      const auto t_dir = std::chrono::steady_clock::now();
+      double t_create_s = 0.0, t_value_s = 0.0;
       if (ngpus == 1) {
         using TM = OpenImpala::TortuosityMI355;
         std::unique_ptr<TM> solver_ptr(
@@ -421,7 +430,10 @@ int main(int argc, char* argv[]) {
                                   write_plotfile != 0, &opts)
                          : new TM(vol.phase.data(), vol.nx, vol.ny, vol.nz, volume_fraction, phase_id, dir, solver_type,
                                   results_path, vlo, vhi, tverbose, write_plotfile != 0, &opts));
+        t_create_s = since(t_dir);
+        const auto t_val = std::chrono::steady_clock::now();
         tau = solver_ptr->value();
+        t_value_s = since(t_val);
         st = solver_ptr->stats();
         if (write_plotfile != 0 && st.converged) {
           phi.resize(vol.phase.size());
@@ -507,6 +519,9 @@ int main(int argc, char* argv[]) {
         std::cout << "    Flux Out = " << std::fixed << std::setprecision(8) << s_.flux_out << "\n";
         std::cout << "  Timings [s]: mask " << std::defaultfloat << s_.t_mask_s << ", solve " << s_.t_solve_s << ", flux "
                   << s_.t_flux_s << "\n";
+        if (ngpus == 1)
+          std::cout << "  Wall clock [s]: solver object (mask, codes, vectors, hierarchy) " << t_create_s << ", value() " << t_value_s
+                    << ", this direction incl. teardown " << since(t_dir) << "\n";
       }
       if (have_phi) {
         // the reference's plotfile (TortuosityHypre.cpp:710-749): solution_potential, phase_id, active_mask on the boxes of
