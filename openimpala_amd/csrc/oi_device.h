@@ -45,6 +45,7 @@ struct Tune {
   float mg_omega_coarse = 0.f;  // in (0, 1]: damping on the coarse levels, if it is to differ from the fine level's (experiments)
   int cg1_fin_sliced = 1;     // 0: the final sums of the single-kernel iteration by one block (cross-check of k_finalize1_sliced)
   int mg_xfirst = 0;          // 1: x += alpha p stays in the first kernel of the rotated iteration (cross-check; default: in the post-smoother)
+  int mg_xpair = 1;           // x update inside the post-smoother: 1 = every second iteration, two terms (round 4); 0 = every iteration (cross-check)
   int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)
   int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)
   int mg_nu_coarse = 0;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (the fine level: 1): 1, 2, or
@@ -201,7 +202,8 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
 // iteration then leaves out (launch_fused_a, x_elsewhere)
 int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale, double* z,
                    double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
-                   double* x = nullptr, const void* p_prev = nullptr, int p_f32 = 0, const double* hist = nullptr, int k = 0);
+                   double* x = nullptr, const void* p_prev = nullptr, int p_f32 = 0, const double* hist = nullptr, int k = 0,
+                   const void* p_prev2 = nullptr /* != null: the x update is pairwise -- even k >= 2 only, alpha_{k-2} p_{k-2} then alpha_{k-1} p_{k-1} */);
 // fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
 // (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)

@@ -2113,7 +2113,7 @@ template <> struct PBuf<float> {
 constexpr int kNtSt0 = 13, kNtLd0 = 24;
 // (the light forms are instruction-bound and gain less: FORM 1 p_out 1.9 %, FORM 2 r_out 0.7 %, FORM 3 x written and x, p_{k-1} read 1.4 %
 // of the cycle; q_out / z nontemporal is a loss everywhere: the next kernel of the same iteration reads it first)
-constexpr int kNtSt1 = 4, kNtLd1 = 0, kNtSt2 = 1, kNtLd2 = 0, kNtSt3 = 8, kNtLd3 = 12;
+constexpr int kNtSt1 = 4, kNtLd1 = 0, kNtSt2 = 1, kNtLd2 = 0, kNtSt3 = 8, kNtLd3 = 12 + 16;
 // FORM 0: the single-kernel CG iteration described above.
 // FORM 1: the first kernel of the TWO-kernel iteration (what k_fused_a<.., compacted> computes, for the multigrid-preconditioned
 // solve: x += alpha_{k-1} p_{k-1}; p_k = z_k + beta_k p_{k-1}; q_k = A p_k; partial p_k.q_k) on the same memory side --
@@ -2183,9 +2183,15 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   // before with x and p_{k-1}) has applied it already: that kernel is instruction-bound and carries the 24 bytes per voxel for
   // less than they cost here (xskip < 0 says so)
   const bool x_elsewhere = FORM == 1 && xskip < 0;
-  if (FORM != 0) xskip = 0;
-  const bool do_x = FORM == 2 ? false : FORM == 3 ? (x != nullptr && k > 0) : x_elsewhere ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
-  if (xskip && do_x) alpha_prev2 = rec[R1_STRIDE * (k - 2) + R1_ALPHA];
+  // FORM 3 (round 4): xskip = 1 makes its x update PAIRWISE as in FORM 0 -- every second launch x takes alpha_{k-2} p_{k-2} and then
+  // alpha_{k-1} p_{k-1} (p_{k-2} is what the other p buffer, `p_out`, still holds: the first kernel of THIS iteration overwrites it
+  // only after this kernel).  Two dependent additions in that order: the same bits as two launches that add one term each.
+  if (FORM != 0 && FORM != 3) xskip = 0;
+  const bool do_x = FORM == 2 ? false
+                    : FORM == 3 ? (x != nullptr && (xskip ? (k >= 2 && (k & 1) == 0) : k > 0))
+                    : x_elsewhere ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
+  if (xskip && do_x)
+    alpha_prev2 = FORM == 3 ? safe_div(rec[H_STRIDE * (k - 2) + H_RZ], rec[H_STRIDE * (k - 2) + H_PQ]) : rec[R1_STRIDE * (k - 2) + R1_ALPHA];
 
   const int lane = threadIdx.x & 63;
   const int wu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // the wave index as a SCALAR: rows are scalars too
@@ -2373,10 +2379,15 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           if (cc >> 8) v1 += cr;
         }
         pn[rr_] = make_double2(v0, v1);
-        if (with_x && mode != 0)  // x_k = x_{k-1} + alpha_{k-1} p_{k-1}, the update the first kernel of this iteration leaves out
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(raw.xv[rr_].x + alpha_prev * pin.x,
-                                                                                       raw.xv[rr_].y + alpha_prev * pin.y)),
+        if (with_x && mode != 0) {  // x_k = x_{k-1} + alpha_{k-1} p_{k-1}, the update the first kernel of this iteration leaves out
+          double x0 = raw.xv[rr_].x, x1 = raw.xv[rr_].y;
+          if (xskip) {  // (pairwise: x_{k-2} + alpha_{k-2} p_{k-2} first)
+            const double2 pold = PBuf<PT>::wide(raw.pold[rr_]);
+            x0 = x0 + alpha_prev2 * pold.x; x1 = x1 + alpha_prev2 * pold.y;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(x0 + alpha_prev * pin.x, x1 + alpha_prev * pin.y)),
                                                  xb, raw.xoff[rr_], 0, (STAUX & 8) ? 2 : 0);
+        }
         continue;
       }
       if (FORM == 2) {  // what is staged is the first damped-Jacobi iterate v = omega r / c of the new residual
@@ -2935,7 +2946,7 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
 // chunk: same arithmetic in the same order).  Returns the number of blocks, -1 when the grid does not fit
 int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale, double* z,
                    double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
-                   double* x, const void* p_prev, int p_f32, const double* hist, int k) {
+                   double* x, const void* p_prev, int p_f32, const double* hist, int k, const void* p_prev2) {
   const int by = kNW * 2;
   const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
   const long long cols = (long long)tiles_x * tiles_y;
@@ -2947,7 +2958,7 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
   // two-kernel iteration otherwise does (launch_fused_a with x_elsewhere)
 #define OI_F3(PT, LD, ST)                                                                                                            \
   hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 3, ST, LD>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, b, z, (const double*)nullptr, \
-                     (double*)nullptr, (const PT*)p_prev, (PT*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc, \
+                     (double*)nullptr, (const PT*)p_prev, (PT*)const_cast<void*>(p_prev2), const_cast<double*>(hist), k, (x && p_prev2) ? 1 : 0, zchunk, tiles_x, tiles_y, nzc, \
                      0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1,  \
                      (float*)nullptr, c, omega, scale)
 #ifdef OI_EXP_CACHEPOL

@@ -29,7 +29,7 @@ int mg_vcycle(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double*
 bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* omega, hipStream_t s);
 // xu != null (and mg_post_descr(...) true): the post-smoother also applies x += alpha_{k-1} p_{k-1}; the caller then launches the
 // first kernel of the iteration with x_elsewhere = 1
-struct MgXUpdate { double* x; const void* p_prev; int p_f32; const double* hist; int k; };
+struct MgXUpdate { double* x; const void* p_prev; int p_f32; const double* hist; int k; const void* p_prev2; /* != null: pairwise (launch_mg_post) */ };
 bool mg_post_descr(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg);  // does the post-smoother run as k_cg1b FORM 3?
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
                                 const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,

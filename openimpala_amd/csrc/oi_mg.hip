@@ -925,7 +925,8 @@ static int post_smooth(MgHierarchy* mg, const Geom& g, const uint8_t* code, cons
                        const MgXUpdate* xu = nullptr) {
   if (mg_post_descr(g, lineoff, plane_first, seg))
     return launch_mg_post(g, code, r, cref, (double)mg->omega, (double)mg->scale, z, partials, ctrl, lineoff, plane_first, seg, s,
-                          xu ? xu->x : nullptr, xu ? xu->p_prev : nullptr, xu ? xu->p_f32 : 0, xu ? xu->hist : nullptr, xu ? xu->k : 0);
+                          xu ? xu->x : nullptr, xu ? xu->p_prev : nullptr, xu ? xu->p_f32 : 0, xu ? xu->hist : nullptr, xu ? xu->k : 0,
+                          xu ? xu->p_prev2 : nullptr);
   return launch_mg_fine(2, g, code, r, cref, (double)mg->omega, (double)mg->scale, z, nullptr, partials, ctrl, lineoff, s);
 }
 static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* scratch, double* z,

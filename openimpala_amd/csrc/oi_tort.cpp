@@ -134,6 +134,7 @@ struct oi_tort {
   bool fused = true;   // fused two-kernel iteration or single-kernel iteration (double-buffered p)
   bool cg1 = false;    // single-kernel iteration
   int xskip = 0;       // cg1: x touched every second iteration (frozen at cg_begin)
+  int xpair = 0;       // rotated multigrid iteration with the x update in the post-smoother: that update is pairwise (frozen at cg_begin)
   bool jacobi = false;
   bool percolates = false;
   bool vectors_ready = false;
@@ -1124,6 +1125,7 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
   int nb;
   if (h->rot) HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * h->nvec_cg, s));
   h->xskip = h->cg1 ? g.tune.cg1_xskip : 0;
+  h->xpair = (h->rot && g.tune.mg_xpair && !g.tune.mg_xfirst && oi::mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg)) ? 1 : 0;
   if (h->cg1) {
     // kernel 0 reads buffer 1: r_{-1} := r_0 with alpha_{-1} = 0, q_{-1} = p_{-1} = 0
     HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * h->nvec_cg, s));
@@ -1210,8 +1212,9 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * k + H_RR, true, k + 1));
     // x += alpha_{k-1} p_{k-1}: in the post-smoother (instruction-bound, it carries the bytes for less) when that runs as k_cg1b FORM 3,
     // else in the first kernel as in the unrotated iteration
-    const bool xpost = !g.tune.mg_xfirst && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg);
-    const MgXUpdate xu{h->x, p_in, h->p_f32 ? 1 : 0, h->hist, k};
+    // (round 4: pairwise there -- launch k even adds alpha_{k-2} p_{k-2}, still in p_out, and alpha_{k-1} p_{k-1}; odd launches leave x alone)
+    const bool xpost = h->xpair || (!g.tune.mg_xfirst && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg));
+    const MgXUpdate xu{h->x, p_in, h->p_f32 ? 1 : 0, h->hist, k, h->xpair ? p_out : nullptr};
     { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s, xpost ? &xu : nullptr); }
     if (nb < 0) return OI_RCCL_ERROR;
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
@@ -1342,7 +1345,17 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
   // (rotated variant: stopped at convergence -- kernel A of launch K raised the flag, kernels B and C of that launch returned at
   // once -- x lacks alpha_{K-1} p_{K-1} like the plain fused variant; stopped for another reason, K = launches - 1 and kernel C
   // of the last launch has already added alpha_{K-1} p_{K-1}: x = x_K as it is)
-  if (h->fused && !h->cg1 && K > 0 && !(h->rot && !done)) {
+  if (h->rot && h->xpair) {
+    // pairwise x update in the post-smoother: after launch m, x = x_e with e the largest even number <= m.  Stopped at convergence
+    // (kernels B and C of launch K returned at once): m = K - 1; stopped otherwise: m = K.  What x still lacks, oldest term first
+    // (the same two dependent additions the kernel makes); p_j lives in p[j & 1] and neither buffer has been overwritten since
+    const int m = done ? K - 1 : K;
+    const int e = m < 0 ? 0 : (m & ~1);
+    for (int j = e; j < K; ++j) {
+      PROF(K_AXPY);
+      launch_axpy_hist(h->g, h->x, h->p[j & 1], h->p_f32 ? 1 : 0, h->hist, j, h->lineoff, h->stream);
+    }
+  } else if (h->fused && !h->cg1 && K > 0 && !(h->rot && !done)) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
     PROF(K_AXPY);
     launch_axpy_hist(h->g, h->x, h->p[(K - 1) & 1], h->p_f32 ? 1 : 0, h->hist, K - 1, h->lineoff, h->stream);
@@ -2132,6 +2145,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "cg1_seg") t.cg1_seg = iv != 0;
   else if (k == "fused_kernel") t.fused_kernel = iv;
   else if (k == "mg_norot") t.mg_norot = iv != 0;
+  else if (k == "mg_xpair") t.mg_xpair = iv != 0;
   else if (k == "mg_post_kernel") t.mg_post_kernel = iv != 0;
   else if (k == "mg_xfirst") t.mg_xfirst = iv != 0;
   else if (k == "cg1_fin_sliced") t.cg1_fin_sliced = iv != 0;
@@ -2154,7 +2168,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_compact = old.cg1_compact;
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
-  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_omega_coarse = old.mg_omega_coarse; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst; t.cg1_fin_sliced = old.cg1_fin_sliced;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_omega_coarse = old.mg_omega_coarse; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst; t.mg_xpair = old.mg_xpair; t.cg1_fin_sliced = old.cg1_fin_sliced;
   t.force_comm = old.force_comm;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;

@@ -329,12 +329,12 @@ def test_multigrid_rotated_iteration_and_its_cross_checks(sample, goldens, oi_op
     for bit: same iteration count, tau and solution, the same residual norm to summation order; and stepping n launches reports
     n - 1 complete iterations in the rotated form (launch k forms r_k first, like the single-kernel variant), n in the other."""
     g = goldens["phases"]["1"]
-    reset = {"mg_norot": 0, "fused_kernel": 0, "mg_coarsest_plain": 0, "mg_post_kernel": 0, "mg_xfirst": 0}
+    reset = {"mg_norot": 0, "fused_kernel": 0, "mg_coarsest_plain": 0, "mg_post_kernel": 0, "mg_xfirst": 0, "mg_xpair": 1}
     out = {}
     # (+ the coarsest level's sixteen sweeps as separate launches instead of the one-launch kernel k_mg_coarsest; + the fine
     # post-smoother as k_mg_fine<2, 2> instead of the descriptor-addressed k_cg1b FORM 3: the same sums chunk for chunk)
     for name, opts in (("default", {}), ("norot", {"mg_norot": 1}), ("fused_a", {"fused_kernel": 1}), ("coarsest", {"mg_coarsest_plain": 1}),
-                       ("post", {"mg_post_kernel": 1}), ("xfirst", {"mg_xfirst": 1})):
+                       ("post", {"mg_post_kernel": 1}), ("xfirst", {"mg_xfirst": 1}), ("xsingle", {"mg_xpair": 0})):
         for k_, v_ in opts.items():
             oi_option(k_, v_, reset=reset[k_])
         t = oia.TortuosityMI355(sample, 1, 1, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG, p_storage=p_storage)
@@ -349,14 +349,16 @@ def test_multigrid_rotated_iteration_and_its_cross_checks(sample, goldens, oi_op
         t.destroy()
         for k_ in opts:
             oia.set_option(k_, reset[k_])
-    # (+ x += alpha p in the first kernel of the iteration instead of in the post-smoother: the same update at another place)
-    for name in ("norot", "fused_a", "coarsest", "post", "xfirst"):
+    # (+ x += alpha p in the first kernel of the iteration instead of in the post-smoother: the same update at another place;
+    # + that update every iteration instead of two terms every second one, the default since round 4: the same additions in the same order)
+    for name in ("norot", "fused_a", "coarsest", "post", "xfirst", "xsingle"):
         assert out[name][0] == out["default"][0] and out[name][1] == out["default"][1], name
         assert out[name][2] == pytest.approx(out["default"][2], rel=1e-12), name   # (||r||^2 is summed tile-wise here, line-wise there)
         assert np.array_equal(out[name][3], out["default"][3]), name
-        assert out[name][4] == (6 if name in ("coarsest", "post", "xfirst") else 7) and out["default"][4] == 6
+        assert out[name][4] == (6 if name in ("coarsest", "post", "xfirst", "xsingle") else 7) and out["default"][4] == 6
     assert out["coarsest"][2] == out["default"][2] and out["post"][2] == out["default"][2] and out["post"][5] == out["default"][5]
     assert out["xfirst"][2] == out["default"][2] and out["xfirst"][5] == out["default"][5]
+    assert out["xsingle"][2] == out["default"][2] and out["xsingle"][5] == out["default"][5]
 
 
 def test_multigrid_rotated_iteration_when_the_budget_runs_out(sample, goldens, oi_option):
