@@ -2227,9 +2227,19 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     return slot_from(rec, bit, bit - 1u);
   };
   const long long seg_plane = (long long)g.ny * tiles_x;
-  auto code_buf = [&](int p) { return buf_of(code + (long long)p * g.plane, g.plane); };
-  auto slot_buf = [&](int p) { return buf_of(reinterpret_cast<const char*>(lineoff) + (long long)p * plane_lines4, plane_lines4); };
-  auto x_buf = [&](int p) { return buf_of(x + (long long)p * g.plane, 8ll * g.plane); };
+  // Code bytes, records and table entries are fetched two planes ahead of the march.  Inside the loop their bases RUN -- one 64-bit
+  // addition per step instead of a 64-bit product per use (round 4: the light forms are instruction-bound, a third of their
+  // ~280 scalar instructions per plane step was address arithmetic); the prologue's few calls form theirs from the plane number
+  const uint8_t* code_run = code;                                   // -> plane gz + 2 while the loop runs (set before it)
+  const uint2* seg_run = seg;                                       // -> its records of this tile column (+ tx)
+  const char* slot_run = reinterpret_cast<const char*>(lineoff);    // -> its table entries
+  auto code_buf = [&](int p, bool run) { return buf_of(run ? code_run : code + (long long)p * g.plane, g.plane); };
+  auto slot_buf = [&](int p, bool run) {
+    return buf_of(run ? slot_run : reinterpret_cast<const char*>(lineoff) + (long long)p * plane_lines4, plane_lines4);
+  };
+  auto seg_row = [&](int p, int j, bool run) { return run ? seg_run[(long long)j * tiles_x] : seg[(long long)p * seg_plane + (long long)j * tiles_x + tx]; };
+  auto x_buf = [&](const double* xplane) { return buf_of(xplane, 8ll * g.plane); };
+  auto x_plane = [&](int p) { return x + (long long)p * g.plane; };
   auto row_of = [&](int rr_) { return j0 + wu + rr_ * NW; };  // scalar
 
   // ---- code bytes and line slots of plane p (they arrive one iteration before they are used) ----
@@ -2243,7 +2253,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     if (defer) p = gs;
 #endif
     if (p <= g.nzl + 1) {
-      const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
+#if OI_TIMING_KNOCK & 16
+      const bool run = false;
+#else
+      const bool run = defer;  // (the loop's calls: plane gz + 2, where the running bases point)
+#endif
+      const __amdgpu_buffer_rsrc_t cb = code_buf(p, run), sb = slot_buf(p, run);
 #pragma unroll
       for (int rr_ = 0; rr_ < R; ++rr_) {
         const int j = row_of(rr_);
@@ -2255,7 +2270,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           // a lane outside the row reads 0 from the range check, which would be slot 0: such lanes have code 0 and the
           // slot is only looked at together with in_x
           if (SEG) {
-            rec_nn[rr_] = seg[(long long)p * seg_plane + (long long)j * tiles_x + tx];  // (uniform address: a scalar load)
+            rec_nn[rr_] = seg_row(p, j, run);  // (uniform address: a scalar load)
             if (!defer) ln[rr_] = slot_own(rec_nn[rr_]);
           } else {
             ln[rr_] = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, ilin + j * LW * 4, 0, 0);
@@ -2274,7 +2289,12 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     if (defer) p = gs;
 #endif
     if (p <= g.nzl + 1 && wu < 3) {
-      const __amdgpu_buffer_rsrc_t cb = code_buf(p), sb = slot_buf(p);
+#if OI_TIMING_KNOCK & 16
+      const bool run = false;
+#else
+      const bool run = defer;
+#endif
+      const __amdgpu_buffer_rsrc_t cb = code_buf(p, run), sb = slot_buf(p, run);
       if (wu < 2) hcode = __builtin_amdgcn_raw_buffer_load_b16(cb, hvox, 0, 0);
       else hcode = __builtin_amdgcn_raw_buffer_load_b8(cb, hvox, 0, 0);
       // SEG: the row above / below the tile has a record, read by the whole wave (the slot only matters where hcode != 0); the
@@ -2283,7 +2303,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         hslot = (int)__builtin_amdgcn_raw_buffer_load_b32(sb, hlin, 0, 0);
       } else {
         const int hr_ = min(max(hrow, 0), g.ny - 1);
-        hrec_s = seg[(long long)p * seg_plane + (long long)hr_ * tiles_x + tx];
+        hrec_s = seg_row(p, hr_, run);
         if (!defer) hslot = slot_own(hrec_s);
       }
     }
@@ -2303,7 +2323,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   const int hcoff = yhalo ? ((i >> 1) + C.cnx * (hrow >> 1)) * 4 : (xhalo ? ((xh_i >> 1) + C.cnx * (xh_row >> 1)) * 4 : kOob);
 
   // ---- issue every load of plane p: r, q, p of the tile rows; x and p_{k-2} where x is updated ----
-  auto plane_issue = [&](int p, const unsigned short (&cn)[R], const int (&ln)[R], long long pfa, long long pfb, Raw& raw, int mode) {
+  auto plane_issue = [&](int p, const unsigned short (&cn)[R], const int (&ln)[R], long long pfa, long long pfb, Raw& raw, int mode, const double* xpl) {
     const long long nb = (long long)(8 * kLV) * (pfb - pfa);
     const __amdgpu_buffer_rsrc_t rb = buf_of(r_in + kLV * pfa, nb), qb = buf_of(q_in + kLV * pfa, nb);
     const __amdgpu_buffer_rsrc_t pb = buf_of(p_in + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
@@ -2336,7 +2356,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       if (FORM == 3) raw.c[rr_] = corr_ld(p, (in_x && cn[rr_]) ? ((i >> 1) + C.cnx * (row_of(rr_) >> 1)) * 4 : kOob);
     }
     if (with_x) {
-      const __amdgpu_buffer_rsrc_t xb = x_buf(p);
+      const __amdgpu_buffer_rsrc_t xb = x_buf(xpl);
       const __amdgpu_buffer_rsrc_t ob = buf_of(p_out + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
 #pragma unroll
       for (int rr_ = 0; rr_ < R; ++rr_) {
@@ -2358,11 +2378,11 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   // mode 0: a halo plane owned by another block (nothing stored); 1: an output plane of this block (r_k, p_k stored, x
   // updated); 2: a ghost plane of the slab, kept current by the block that marches over it (r_k, p_k)
   auto plane_finish = [&](int p, const unsigned short (&cn)[R], long long pfa, long long pfb, const Raw& raw, double2 (&pn)[R],
-                          double2 (&rn)[R], int mode) {
+                          double2 (&rn)[R], int mode, const double* xpl) {
     const long long nb = (long long)(8 * kLV) * (pfb - pfa);
     const __amdgpu_buffer_rsrc_t rob = buf_of(r_out + kLV * pfa, nb);
     const __amdgpu_buffer_rsrc_t pob = buf_of(p_out + kLV * pfa, (long long)PBuf<PT>::kLineBytes * (pfb - pfa));
-    const __amdgpu_buffer_rsrc_t xb = x_buf(p);
+    const __amdgpu_buffer_rsrc_t xb = x_buf(xpl);
     const bool with_x = mode == 1 && do_x;
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
@@ -2541,24 +2561,28 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     codes_issue(gs - 1, cc_nn, lo_nn, false);
     codes_issue(gs, cc_cur, lo_cur, false);
     codes_issue(gs + 1, cc_nxt, lo_nxt, false);
-    plane_issue(gs - 1, cc_nn, lo_nn, pfm, pf0, raw, gs == 1 ? 2 : 0);
-    plane_finish(gs - 1, cc_nn, pfm, pf0, raw, pn_nxt, rn_nxt, gs == 1 ? 2 : 0);
+    plane_issue(gs - 1, cc_nn, lo_nn, pfm, pf0, raw, gs == 1 ? 2 : 0, x_plane(gs - 1));
+    plane_finish(gs - 1, cc_nn, pfm, pf0, raw, pn_nxt, rn_nxt, gs == 1 ? 2 : 0, x_plane(gs - 1));
     stage_rows(tile + b_prev, pn_nxt);
     const int hoff = halo_offset(pf0);
-    plane_issue(gs, cc_cur, lo_cur, pf0, pf1, raw, 1);
+    plane_issue(gs, cc_cur, lo_cur, pf0, pf1, raw, 1, x_plane(gs));
     halo_issue(gs, pf0, pf1, hoff, hr);
-    plane_finish(gs, cc_cur, pf0, pf1, raw, pn_nxt, rn_cur, 1);
+    plane_finish(gs, cc_cur, pf0, pf1, raw, pn_nxt, rn_cur, 1, x_plane(gs));
     stage_rows(tile + b_cur, pn_nxt);
     stage_halo(tile + b_cur, hr);
     halo_codes_issue(gs + 1, false);
     if (kEarly) {  // plane gs + 1 for the first iteration
       const int mode1 = gs + 1 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
       const int hoff1 = halo_offset(pf1);
-      plane_issue(gs + 1, cc_nxt, lo_nxt, pf1, pf2, raw_e, mode1);
+      plane_issue(gs + 1, cc_nxt, lo_nxt, pf1, pf2, raw_e, mode1, x_plane(gs + 1));
       if (gs + 1 < ge) halo_issue(gs + 1, pf1, pf2, hoff1, hr_e);
     }
   }
   __syncthreads();
+  code_run = code + (long long)(gs + 2) * g.plane;
+  if (SEG) seg_run = seg + (long long)(gs + 2) * seg_plane + tx;
+  slot_run = reinterpret_cast<const char*>(lineoff) + (long long)(gs + 2) * plane_lines4;
+  const double* x_run = x_plane(gs + 1);  // -> plane gz + 1 while the loop runs
 
   // FORM 2: even waves own the 2x2x2 block sums of the pre-smoothing residual; `own` = their x-pair sum of the plane just
   // finished, `acc` the running 2 x 2 x (1 or 2) sum; plane gzp is consumed one barrier after it was computed (k_mg_fine, MODE 3)
@@ -2668,7 +2692,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       // every load of this iteration, back to back: plane gz + 1's vectors and halo, plane gz + 2's codes and slots
       const int hoff = halo_offset(pf1);  // (first: the slot came with the previous iteration's loads, nothing newer is waited for)
       __builtin_amdgcn_sched_barrier(0);
-      plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode);
+      plane_issue(gz + 1, cc_nxt, lo_nxt, pf1, pf2, raw, mode, x_run);
       if (more) halo_issue(gz + 1, pf1, pf2, hoff, hr);
     } else {
       __builtin_amdgcn_sched_barrier(0);  // (plane gz + 1's vectors and halo were requested before the barrier)
@@ -2679,7 +2703,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
     const unsigned hcode_next = hcode;
     const int hslot_next = hslot;
     __builtin_amdgcn_sched_barrier(0);
-    plane_finish(gz + 1, cc_nxt, pf1, pf2, raw, pn_nxt, rn_nxt, mode);
+    plane_finish(gz + 1, cc_nxt, pf1, pf2, raw, pn_nxt, rn_nxt, mode, x_run);
 #if OI_TIMING_KNOCK & 4  // TIMING BUILDS ONLY: nothing staged in LDS
     if (more && hr.r.x == 1.2345e300) {
 #else
@@ -2704,12 +2728,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       lo_cur[rr_] = lo_nxt[rr_]; lo_nxt[rr_] = lo_nn[rr_];
     }
     pf0 = pf1; pf1 = pf2; pf2 = pf3;
+    code_run += g.plane; slot_run += plane_lines4; x_run += g.plane;
+    if (SEG) seg_run += seg_plane;
     { const int t = b_prev; b_prev = b_cur; b_cur = b_nxt; b_nxt = t; }
     if (kEarly && gz + 1 < ge) {  // the next iteration's plane (gz + 2): its code bytes and slots have arrived and been rotated into *_nxt
       const int mode2 = gz + 2 < ge ? 1 : (ge == g.nzl + 1 ? 2 : 0);
       const int hoff2 = halo_offset(pf1);
       __builtin_amdgcn_sched_barrier(0);
-      plane_issue(gz + 2, cc_nxt, lo_nxt, pf1, pf2, raw, mode2);
+      plane_issue(gz + 2, cc_nxt, lo_nxt, pf1, pf2, raw, mode2, x_run);  // (x_run has moved on to plane gz + 2)
       if (gz + 2 < ge) halo_issue(gz + 2, pf1, pf2, hoff2, hr);
       __builtin_amdgcn_sched_barrier(0);
     }
