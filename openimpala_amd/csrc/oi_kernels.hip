@@ -2876,8 +2876,9 @@ Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part) {
     // config 5's share, 4.94 vs 5.07 ms at 1024^3); the sphere pack (half of the lines) with 16 planes
     // (round 4, with the nontemporal policy -- the written vectors no longer push the chunk's own planes out of the L2 --:
     // 24 / 32 / 48 planes 6.05 ms against 6.11 with 16 and 6.13 with 64, same handle, alternating:
-    // profiles/r04/k_cg1b_chunk_length_tile_map_blobs_with_nontemporal.txt)
-    gs_.tune.zchunk = (g.live_lines > 0.f && g.live_lines < 0.35f) ? 64 : (g.tune.cg1_nt ? 32 : 16);
+    // profiles/r04/k_cg1b_chunk_length_tile_map_blobs_with_nontemporal.txt; 24 because the slabs of the strong-scaling
+    // runs prefer it to 32: 128 planes 0.933 vs 0.960 ms, 256: 1.622 vs 1.638, 512: 3.123 vs 3.140, slab_chunk_lengths.txt)
+    gs_.tune.zchunk = (g.live_lines > 0.f && g.live_lines < 0.35f) ? 64 : (g.tune.cg1_nt ? 24 : 16);
     pick_chunks(gs_, cols, false, &o.zchunk, &o.nzc);
   } else if (split && g.tune.zchunk <= 0) {
     Geom gs_ = g;

@@ -373,9 +373,9 @@ def test_launch_geometry_never_exceeds_the_partial_sum_array(descr):
                 assert 0 <= blocks <= cap, (nx, ny, nzl, split, part, blocks, cap)
                 total += blocks
             assert total <= cap and total >= 1
-    # the default of the descriptor-addressed kernel at the bench size: 16-row tiles, 32-plane chunks (16 until the nontemporal
-    # policy of round 4, profiles/r04/k_cg1b_chunk_length_tile_map_blobs_with_nontemporal.txt)
-    assert oia.cg1_grid(1024, 1024, 1024, descr=1)[:3] == (16, 32, 8 * 64 * 32)
+    # the default of the descriptor-addressed kernel at the bench size: 16-row tiles, 24-plane chunks (16 until the nontemporal
+    # policy of round 4, profiles/r04/k_cg1b_chunk_length_tile_map_blobs_with_nontemporal.txt, slab_chunk_lengths.txt)
+    assert oia.cg1_grid(1024, 1024, 1024, descr=1)[:3] == (16, 24, 8 * 64 * 43)
     assert oia.cg1_grid(1024, 1024, 1024, descr=0)[0] == 32
 
 
