@@ -433,6 +433,27 @@ def main():
     watchdog.daemon = True
     watchdog.start()
 
+    # ---- A/B on THIS handle (same vectors, same placement, one CG run): the default cache policy against the
+    # nontemporal accesses the kernel ships with (option cg1_nt, DESIGN.md section 4 "Round 4: cache policy") ----
+    if args.kernel == "fused1" and not args.no_variants and main_k == "cg1":
+        try:
+            ab = {}
+            t.cg_begin()
+            t.cg_iterate(args.warmup)
+            for pol in (0, 1):
+                oia.set_option("cg1_nt", pol); t.retune()
+                t.cg_iterate(4); t.sync(); t.reset_kernel_times()
+                t.cg_iterate(args.steps); t.sync()
+                kt = t.kernel_times()
+                ab[pol] = kt["cg1"][0] / max(1, kt["cg1"][1])
+            roofline["cache_policy_same_handle"] = {
+                "what": "ms per launch of the CG kernel on this handle, alternating: every access with the default cache policy / "
+                        "r, p, x written and x, p(k-2) read nontemporally (shipped)",
+                "default_policy_ms": ab[0], "nontemporal_ms": ab[1], "gain": 1.0 - ab[1] / ab[0]}
+            t.cg_finish()
+        finally:
+            oia.set_option("cg1_nt", 1); t.retune()
+
     # ---- wall time to relative residual 1e-6 (second half of the BASELINE metric) ----
     solve = None
     if not args.no_solve:

@@ -645,6 +645,33 @@ def test_single_kernel_iteration_two_kernels_are_bit_identical(sample, oi_option
     assert np.array_equal(out[0][2], out[1][2])
 
 
+def test_cache_policy_does_not_touch_the_arithmetic(sample, goldens, oi_option):
+    """Round 4: the streamed vectors of the descriptor-addressed kernels take nontemporal stores / loads (option cg1_nt, default 1).
+    A cache policy is not arithmetic: the single-kernel iteration after K launches and the multigrid-preconditioned solve give
+    the same bits with the policy off, and the policy can be switched on a live handle (oi_tort_retune) in mid-run."""
+    g = goldens["phases"]["1"]
+    out = {}
+    for nt in (1, 0):
+        oi_option("cg1_nt", nt, reset=1)
+        t = oia.TortuosityMI355(sample, 1, 2, 0.0, 1.0, kernel=oia.KERNEL_FUSED1, eps=1e-300, maxiter=500)
+        t.cg_begin(); t.cg_iterate(20); t.sync()
+        if nt == 1:   # switch in mid-run: the remaining launches take the other policy
+            oia.set_option("cg1_nt", 0); t.retune()
+        t.cg_iterate(17); t.sync()
+        its, rel, conv = t.cg_state()
+        t.cg_finish()
+        cg = (its, rel, t.solution().copy())
+        t.destroy()
+        oia.set_option("cg1_nt", nt)
+        tm = oia.TortuosityMI355(sample, 1, 1, g["vlo"], g["vhi"], eps=1e-10, precond=oia.PRECOND_MG)
+        tau = tm.value()
+        out[nt] = cg + (tau, tm.getSolverIterations(), tm.stats().final_relres, tm.solution().copy())
+        tm.destroy()
+    assert out[0][0] == out[1][0] == 36 and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3] and out[0][4] == out[1][4] and out[0][5] == out[1][5] and np.array_equal(out[0][6], out[1][6])
+    assert out[1][3] == pytest.approx(g["tau"][1], rel=1e-7)
+
+
 @pytest.mark.parametrize("p_storage", [oia.STORE_F64, oia.STORE_F32])
 def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_storage):
     """r, q, z, p of the multigrid-preconditioned two-kernel iteration as compacted lines (default) or dense:
