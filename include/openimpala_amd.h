@@ -277,7 +277,8 @@ int oi_tort_line_voxels(void);
  *                   pre-smoother as two kernels), "fused_kernel" (1: k_fused_a as first kernel), "mg_post_kernel" (1: the fine
  *                   post-smoother as k_mg_fine), "mg_xfirst" (1: x += alpha p in the first kernel, not in the post-smoother),
  *                   "mg_coarsest_plain" (1: the coarsest level's sweeps as separate launches), "mg_xpair" (0: the x update inside the
- *                   post-smoother every iteration instead of two terms every second one); of the single-kernel iteration:
+ *                   post-smoother every iteration instead of two terms every second one), "mg_blocked" (0: pre-smoothing residual and
+ *                   restriction of the coarse levels as two kernels instead of one); of the single-kernel iteration:
  *                   "cg1_seg" (0: per-line slot table instead of segment records), "cg1_fin_sliced" (0: final sums by one block)
  *   "cg1_nt"        1 (default): the streamed vectors of the descriptor-addressed kernels take nontemporal stores / loads (same
  *                   arithmetic, other cache policy); 0 = the default policy everywhere (A/B)

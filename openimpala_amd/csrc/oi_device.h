@@ -45,6 +45,7 @@ struct Tune {
   float mg_omega_coarse = 0.f;  // in (0, 1]: damping on the coarse levels, if it is to differ from the fine level's (experiments)
   int cg1_fin_sliced = 1;     // 0: the final sums of the single-kernel iteration by one block (cross-check of k_finalize1_sliced)
   int mg_xfirst = 0;          // 1: x += alpha p stays in the first kernel of the rotated iteration (cross-check; default: in the post-smoother)
+  int mg_blocked = 1;         // coarse levels: 4 x 2 x 2 cells per thread with the restriction in registers where a level allows it (round 4); 0: cross-check
   int mg_xpair = 1;           // x update inside the post-smoother: 1 = every second iteration, two terms (round 4); 0 = every iteration (cross-check)
   int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)
   int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)

@@ -456,6 +456,102 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
   *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- round 4: pre-smoothing residual + restriction on BLOCKS of 4 x 2 x 2 cells per thread (open problems on one rank, even extents) ----
+// A thread that owns rows 2J, 2J+1 of planes 2K, 2K+1 holds all eight children of its two coarse cells: the pre-smoothing residual is
+// restricted in registers -- no residual array, no restriction launch (0.22 ms of a 13.5 ms iteration at 1024^3; the stencil part itself
+// takes what k_mg_lin4 took: fewer loads per cell, a quarter of the threads).  Same arithmetic in the same order as k_mg_lin4<0, 0> +
+// k_mg_restrict (bit-identical; option mg_blocked = 0 keeps the pair as the cross-check).  The same blocking of the prolongation +
+// post-smoother was built and measured 10 % SLOWER than k_mg_post4 (132 registers, profiles/r04/mg_blocked_coarse_kernels.txt): not kept.
+#define OI_MG_BLOCK8(L)                                                                         \
+  int t_ = blockIdx.x;                                                                          \
+  if ((gridDim.x & 7) == 0) t_ = (t_ & 7) * (gridDim.x >> 3) + (t_ >> 3);                       \
+  const int gpr_ = L.nx >> 2, rows_ = L.ny >> 1;                                                \
+  const long long id_ = (long long)t_ * blockDim.x + threadIdx.x;                               \
+  const long long row_ = id_ / gpr_;                                                            \
+  const int i = (int)(id_ - row_ * gpr_) << 2, J = (int)(row_ % rows_), Kp = (int)(row_ / rows_); \
+  if (Kp >= (L.nzl >> 1)) return;                                                               \
+  const int j = 2 * J, k = 1 + 2 * Kp;                                                          \
+  const long long sy = L.nx, sz = L.sz;                                                         \
+  const long long m00 = (long long)i + sy * j + sz * k;
+
+// bc = P^T (b - A (w b / D)) on the coarse level C; L: open, nx % 4 == 0, ny and nzl even, z0 even
+template <class W, class D>
+__global__ void __launch_bounds__(256) k_mg_lin4r(LevelT<W, D> L, const float* __restrict__ b, Dims C, float* __restrict__ bc) {
+  OI_MG_BLOCK8(L)
+  auto xs1 = [&](float bb, float dd) -> float { return dd > 0.f ? L.omega * bb * rcp(dd) : 0.f; };
+  auto u4 = [&](long long mm, float (&o)[4]) {
+    float bb[4], dd[4];
+    ld4(b + mm, bb); ld4(L.diag + mm, dd);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = xs1(bb[c], dd[c]);
+  };
+  auto u1 = [&](long long mm) -> float { return xs1(b[mm], (float)L.diag[mm]); };
+  // own cells: segment s = 2 * c + bb  (plane k + c, row j + bb), the order the restriction sums them in
+  float dc[4][4], bcv[4][4], u[4][4];
+  bool any = false;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const long long m = m00 + sy * (s & 1) + sz * (s >> 1);
+    ld4(L.diag + m, dc[s]);
+    any = any || dc[s][0] > 0.f || dc[s][1] > 0.f || dc[s][2] > 0.f || dc[s][3] > 0.f;
+  }
+  const long long cm = (long long)(i >> 1) + (long long)C.nx * J + C.sz * (((L.z0 + k - 1) >> 1) - C.z0 + 1);
+  if (!any) {  // sixteen cells without an operator row: both block sums are sums of zeros
+    *reinterpret_cast<float2*>(bc + cm) = make_float2(0.f, 0.f);
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const long long m = m00 + sy * (s & 1) + sz * (s >> 1);
+    ld4(b + m, bcv[s]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[s][c] = xs1(bcv[s][c], dc[s][c]);
+  }
+  float res[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int bb = s & 1, cz = s >> 1;
+    const long long m = m00 + sy * bb + sz * cz;
+    // a row segment whose four cells have no operator row: zeros, none of its neighbour loads (k_mg_lin4's early return)
+    if (!(dc[s][0] > 0.f || dc[s][1] > 0.f || dc[s][2] > 0.f || dc[s][3] > 0.f)) {
+      res[s][0] = res[s][1] = res[s][2] = res[s][3] = 0.f;
+      continue;
+    }
+    float xym[4], xyp[4], xzm[4], xzp[4], wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
+    const float xl = u1(m - 1), xr = u1(m + 4);
+    // y and z neighbours: the other segment of the block where there is one, a load where the block ends
+    if (bb == 0) { u4(m - sy, xym); _Pragma("unroll") for (int c = 0; c < 4; ++c) xyp[c] = u[(s + 1) & 3][c]; }
+    else { _Pragma("unroll") for (int c = 0; c < 4; ++c) xym[c] = u[(s - 1) & 3][c]; u4(m + sy, xyp); }
+    if (cz == 0) { u4(m - sz, xzm); _Pragma("unroll") for (int c = 0; c < 4; ++c) xzp[c] = u[(s + 2) & 3][c]; }
+    else { _Pragma("unroll") for (int c = 0; c < 4; ++c) xzm[c] = u[(s - 2) & 3][c]; u4(m + sz, xzp); }
+    ld4(L.wx + m, wxc); ld4(L.wy + m, wyc); ld4(L.wy + (m - sy), wym); ld4(L.wz + m, wzc); ld4(L.wz + (m - sz), wzm);
+    const float wxl = (float)L.wx[m - 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      res[s][c] = 0.f;
+      if (dc[s][c] > 0.f) {
+        float t = (c == 0 ? wxl : wxc[c > 0 ? c - 1 : 0]) * (c == 0 ? xl : u[s][c > 0 ? c - 1 : 0]);
+        t += wxc[c] * (c == 3 ? xr : u[s][c < 3 ? c + 1 : 3]);
+        t += wym[c] * xym[c];
+        t += wyc[c] * xyp[c];
+        t += wzm[c] * xzm[c];
+        t += wzc[c] * xzp[c];
+        res[s][c] = bcv[s][c] - (dc[s][c] * u[s][c] - t);
+      }
+    }
+  }
+  // P^T: the eight children of a coarse cell in k_mg_restrict's order -- plane, row, x
+  float o[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { t += res[s][2 * e]; t += res[s][2 * e + 1]; }
+    o[e] = t;
+  }
+  *reinterpret_cast<float2*>(bc + cm) = make_float2(o[0], o[1]);
+}
+
 // coarsest level: x_out = x_in + w (b - A x_in) / D   (first = 1: x_in = 0)
 template <class W, class D>
 __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, const float* __restrict__ b,
@@ -643,6 +739,7 @@ struct MgHierarchy {
   float scale = kScale;
   float omega = kOmega;
   bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
+  bool blocked = true;  // round 4: pre-smoothing residual + restriction as k_mg_lin4r (4 x 2 x 2 cells per thread) where a level allows it; false: cross-check
   bool coarsest_plain = false;  // cross-check: one launch per sweep on the coarsest level instead of k_mg_coarsest
   int nu_coarse = 1;    // damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (1 or 2)
   bool failed = false;
@@ -737,6 +834,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   if (g.tune.mg_scale > 0.f) mg->scale = g.tune.mg_scale;
   if (g.tune.mg_omega > 0.f && g.tune.mg_omega <= 1.f) mg->omega = g.tune.mg_omega;
   mg->novec4 = g.tune.mg_novec4 != 0;
+  mg->blocked = g.tune.mg_blocked != 0;
   mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
   mg->coarsest_plain = g.tune.mg_coarsest_plain != 0;
   for (int l = 0; l < 24; ++l) {
@@ -870,10 +968,17 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   const bool vec4 = L.compact && (L.d.nx & 3) == 0 && L.d.nx >= 64 && !mg->novec4;
   const int blocks4 = (int)((((long long)(L.d.nx >> 2) * L.d.ny * L.d.nzl) + 255) / 256);
   const bool two = mg->nu_coarse > 1;  // two sweeps before and two after the correction
+  // blocks of 4 x 2 x 2 cells per thread, the restriction in registers: open problem, the whole level and its child on this rank,
+  // even extents (the blocks are the aggregates)
+  const bool blk = vec4 && !two && mg->blocked && !mg->comm && !mg->periodic && (L.d.ny & 1) == 0 && (L.d.nzl & 1) == 0 && (L.d.z0 & 1) == 0 &&
+                   !C.replicated && C.d.nx * 2 == L.d.nx && C.d.ny * 2 == L.d.ny && C.d.nzl * 2 == L.d.nzl && C.d.z0 * 2 == L.d.z0;
+  const int blocks8 = (int)((((long long)(L.d.nx >> 2) * (L.d.ny >> 1) * (L.d.nzl >> 1)) + 255) / 256);
 #define OI_MG_LIN4(SRC, OUT, B, X, DST)                                                                                      \
   hipLaunchKernelGGL((k_mg_lin4<uint8_t, uint16_t, SRC, OUT>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), \
                      kfirst, L.d.nzl, B, X, DST)
-  if (!two) {
+  if (blk) {  // pre-smoothing residual and its restriction in one launch; no residual array
+    hipLaunchKernelGGL((k_mg_lin4r<uint8_t, uint16_t>), dim3(blocks8), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.d, C.b);
+  } else if (!two) {
     if (vec4 && blocks4 > 0) OI_MG_LIN4(0, 0, rhs, (const float*)nullptr, L.r);
     else OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
   } else {
@@ -889,7 +994,8 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
     if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 0, rhs, (const float*)L.t, L.r);
     else OI_MG_LAUNCH(k_mg_resid, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t, L.r);
   }
-  if (!restrict_to(mg, nullptr, nullptr, nullptr, &L, C, C.b, s)) return false;
+  if (blk) { if (!finish_child_array(mg, C, false, C.b, s)) return false; }
+  else if (!restrict_to(mg, nullptr, nullptr, nullptr, &L, C, C.b, s)) return false;
   if (!coarse_cycle(mg, l + 1, C.b, C.x2, s)) return false;
   const float* second = nullptr;
   if ((mg->wmask >> (l + 1)) & 1u) {

@@ -693,6 +693,29 @@ def test_multigrid_iteration_layouts_compacted_and_dense(sample, goldens, p_stor
     assert out[1][3] < out[0][3]
 
 
+def test_multigrid_blocked_coarse_kernels_are_bit_identical(oi_option):
+    """Round 4: coarse levels with even extents (open problem, one rank) form the pre-smoothing residual on 4 x 2 x 2 cells per thread
+    and restrict it in registers (k_mg_lin4r: no residual array, no restriction launch).  Same arithmetic in the same order as
+    k_mg_lin4 + k_mg_restrict: the whole solve is bit-identical, on a volume whose first two coarse levels take the blocked kernel
+    and on one where only the first does."""
+    for shape, seed in (((48, 64, 256), 4), ((40, 72, 264), 9)):   # coarse levels 24 x 32 x 128, 12 x 16 x 64 | 20 x 36 x 132, 10 x 18 x 66 (x < 64: one-cell kernels)
+        ph = o.gen_spheres(shape, seed, 7, 0.45)
+        got = {}
+        for blocked in (1, 0):
+            oi_option("mg_blocked", blocked, reset=1)
+            for d in (0, 2):
+                t = oia.TortuosityMI355(ph, 1, d, -1.0, 1.0, eps=1e-10, precond=oia.PRECOND_MG)
+                tau = t.value()
+                assert t.stats().converged
+                got[(blocked, d)] = (tau, t.getSolverIterations(), t.stats().final_relres, t.solution().copy())
+                t.destroy()
+        for d in (0, 2):
+            a, b = got[(1, d)], got[(0, d)]
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3]), (shape, d)
+        ref = o.tortuosity(ph, 1, 0, -1.0, 1.0, eps=1e-10)
+        assert got[(1, 0)][0] == pytest.approx(ref["tau"], rel=1e-8)
+
+
 def test_multigrid_four_cells_per_thread_kernels_are_bit_identical(oi_option):
     """Coarse levels whose rows split into groups of four cells run k_mg_pre4 / k_mg_post4 (16-byte row loads, x
     neighbours in registers): same arithmetic in the same order as the one-cell kernels, so the whole solve is

@@ -1,18 +1,20 @@
-"""x update of the rotated multigrid-PCG iteration inside the post-smoother: pairwise (default) against every iteration (mg_xpair = 0).
-The option is frozen when a CG run begins, so: two handles, alternating batches; ms per launch of the cycle (coarse levels + FORM 3)."""
+"""A/B of an option that is frozen when a multigrid-PCG handle is built or its CG run begins (mg_xpair, mg_blocked, ...): two handles,
+value 1 against value 0, alternating batches; ms per launch of FORM 1 / FORM 2 / the cycle (coarse levels + FORM 3).
+usage: python tools/mg_two_handles_ab.py <option>"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import openimpala_amd as oia
+KEY = sys.argv[1]
 n = 1024
 shape = (n, n, n)
 buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
 hs = {}
 for v in (1, 0):
-    oia.set_option("mg_xpair", v)
+    oia.set_option(KEY, v)
     t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, precond=oia.PRECOND_MG, profile=1, maxiter=100000)
     t.cg_begin(); t.cg_iterate(4); t.sync()
     hs[v] = t
-oia.set_option("mg_xpair", 1)
+oia.set_option(KEY, 1)
 res = {1: [], 0: []}
 for rep in range(4):
     for v in (1, 0):
@@ -24,5 +26,5 @@ for rep in range(4):
 for v in (1, 0):
     for i, name in enumerate(("FORM 1", "FORM 2", "cycle ")):
         xs = [r[i] for r in res[v]]
-        print(f"{name}  mg_xpair = {v}: " + " ".join(f"{x:.3f}" for x in xs) + f"  | median {sorted(xs)[len(xs) // 2]:.3f} ms", flush=True)
+        print(f"{name}  {KEY} = {v}: " + " ".join(f"{x:.3f}" for x in xs) + f"  | median {sorted(xs)[len(xs) // 2]:.3f} ms", flush=True)
 for t in hs.values(): t.destroy()
