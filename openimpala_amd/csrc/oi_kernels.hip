@@ -2124,7 +2124,7 @@ constexpr int kNtSt1 = 4, kNtLd1 = 0, kNtSt2 = 1, kNtLd2 = 0, kNtSt3 = 8, kNtLd3
 // stored to r_out -- double-buffered, the halo ring recomputes it from the inputs), partial r_k.r_k, v = omega r_k / c staged,
 // res = r_k - A v, and the 2x2x2 block sums of res as the fp32 right-hand side of the first coarse level (`bcoarse`, `C`).
 // Chunks hold whole z pairs (even first plane, even length).  Same arithmetic in the same order as the two kernels it replaces.
-template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0, int STAUX = 0, int LDAUX = 0, int VAR = 0>
+template <int R, int NW, typename PT, bool JACOBI, bool SEG, int FORM = 0, int STAUX = 0, int LDAUX = 0, int VAR = 0, bool NOX = false>
 __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, const uint8_t* __restrict__ code, double* __restrict__ x,
                                                     const double* __restrict__ r_in, double* __restrict__ r_out,
                                                     const double* __restrict__ q_in, double* __restrict__ q_out,
@@ -2187,7 +2187,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   // alpha_{k-1} p_{k-1} (p_{k-2} is what the other p buffer, `p_out`, still holds: the first kernel of THIS iteration overwrites it
   // only after this kernel).  Two dependent additions in that order: the same bits as two launches that add one term each.
   if (FORM != 0 && FORM != 3) xskip = 0;
-  const bool do_x = FORM == 2 ? false
+  // NOX: a launch the HOST knows will not touch x (FORM 1 when the post-smoother carries the update, FORM 3 in the launches
+  // between two pairwise updates) is its own instantiation: x, p_{k-1} / p_{k-2} and the alphas are not even live -- the light
+  // forms are instruction-bound and FORM 3 reloaded 74 spilled scalars per plane step with the x path compiled in
+  const bool do_x = (NOX || FORM == 2) ? false
                     : FORM == 3 ? (x != nullptr && (xskip ? (k >= 2 && (k & 1) == 0) : k > 0))
                     : x_elsewhere ? false : (xskip ? (k >= 2 && (k & 1) == 0) : (k > 0));
   if (xskip && do_x)
@@ -2983,6 +2986,11 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
   const int blocks = (int)(cols * nzc);
   // x != null: x += alpha_{k-1} p_{k-1} (alpha from hist) on the planes this launch writes -- what the first kernel of the
   // two-kernel iteration otherwise does (launch_fused_a with x_elsewhere)
+#define OI_F3N(LD, ST)                                                                                                               \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 3, ST, LD, 0, true>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, b, z, \
+                     (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk,    \
+                     tiles_x, tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,                        \
+                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, c, omega, scale)
 #define OI_F3(PT, LD, ST)                                                                                                            \
   hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 3, ST, LD>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, b, z, (const double*)nullptr, \
                      (double*)nullptr, (const PT*)p_prev, (PT*)const_cast<void*>(p_prev2), const_cast<double*>(hist), k, (x && p_prev2) ? 1 : 0, zchunk, tiles_x, tiles_y, nzc, \
@@ -2995,8 +3003,12 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
     case 7: OI_F3(double, 12, 0); return blocks;  default: OI_F3(double, 0, 0); return blocks;
   }
 #endif
-  if (g.tune.cg1_nt) { if (x && p_f32) OI_F3(float, kNtLd3, kNtSt3); else OI_F3(double, kNtLd3, kNtSt3); }
-  else { if (x && p_f32) OI_F3(float, 0, 0); else OI_F3(double, 0, 0); }
+  // (does this launch touch x?  The kernel's own rule, evaluated here: an instantiation without the x path otherwise)
+  const bool touches_x = x != nullptr && (p_prev2 ? (k >= 2 && (k & 1) == 0) : k > 0);
+  if (!touches_x) { if (g.tune.cg1_nt) OI_F3N(kNtLd3, kNtSt3); else OI_F3N(0, 0); }
+  else if (g.tune.cg1_nt) { if (p_f32) OI_F3(float, kNtLd3, kNtSt3); else OI_F3(double, kNtLd3, kNtSt3); }
+  else { if (p_f32) OI_F3(float, 0, 0); else OI_F3(double, 0, 0); }
+#undef OI_F3N
 #undef OI_F3
   return blocks;
 }
@@ -3014,6 +3026,11 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
     const int blocks = (int)(cols * nzc);
     const bool descr = fused_descr_ok(g, lineoff, plane_first, seg, jacobi);
     if (descr) {
+#define OI_FBN(PT, LD, ST)                                                                                                     \
+  hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1, ST, LD, 0, true>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r, \
+                     (double*)nullptr, (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, -1, zchunk, tiles_x, \
+                     tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,             \
+                     (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0, 0.0)
 #define OI_FB(PT, LD, ST)                                                                                                      \
   hipLaunchKernelGGL((k_cg1b<2, kNW, PT, false, true, 1, ST, LD>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, r, (double*)nullptr,   \
                      (const double*)nullptr, q, (const PT*)p_in, (PT*)p_out, const_cast<double*>(hist), k, x_elsewhere ? -1 : 0, zchunk, tiles_x,  \
@@ -3026,8 +3043,12 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
         case 7: OI_FB(double, 4, 4); return blocks;  default: OI_FB(double, 0, 0); return blocks;
       }
 #endif
-      if (g.tune.cg1_nt) { if (p_f32) OI_FB(float, kNtLd1, kNtSt1); else OI_FB(double, kNtLd1, kNtSt1); }
+      if (x_elsewhere) {  // (the post-smoother of this iteration has taken the x update: the instantiation without the x path)
+        if (g.tune.cg1_nt) { if (p_f32) OI_FBN(float, kNtLd1, kNtSt1); else OI_FBN(double, kNtLd1, kNtSt1); }
+        else { if (p_f32) OI_FBN(float, 0, 0); else OI_FBN(double, 0, 0); }
+      } else if (g.tune.cg1_nt) { if (p_f32) OI_FB(float, kNtLd1, kNtSt1); else OI_FB(double, kNtLd1, kNtSt1); }
       else { if (p_f32) OI_FB(float, 0, 0); else OI_FB(double, 0, 0); }
+#undef OI_FBN
 #undef OI_FB
       return blocks;
     }
