@@ -574,7 +574,10 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
 // coarsest level, all sweeps in ONE launch: <= 512 cells, one thread per cell, weights and right-hand side in registers, the
 // iterate in two LDS planes, a barrier between sweeps (the per-sweep launches of k_mg_jacobi -- 16 sweeps x 8 visits per cycle --
 // were 0.9 ms of every cycle at 1024^3, all of it launch latency).  Same arithmetic in the same order as k_mg_jacobi: bit-identical.
-// Open (non-periodic) levels that live whole on this rank only.
+// Levels that live whole on this rank only.  Round 4: also the PERIODIC level of the homogenization cell problems -- x, y and z
+// neighbours wrap by index inside the LDS iterate (what the ghost planes of the per-sweep launches held: the images of the first /
+// last plane), which also saves the two plane copies after every sweep: 128 launches + 256 copies per cycle, 1.5 ms of a 19.7 ms
+// iteration at 1024^3.
 constexpr int kCoarsestLds = 512 + 2 * 512;
 template <class W, class D>
 __global__ void __launch_bounds__(512) k_mg_coarsest(LevelT<W, D> L, const float* __restrict__ b, float* __restrict__ out, int sweeps) {
@@ -584,10 +587,21 @@ __global__ void __launch_bounds__(512) k_mg_coarsest(LevelT<W, D> L, const float
   const int t = threadIdx.x;
   const bool act = t < cells;
   const int sz = (int)L.sz, sy = L.nx;
-  const int m = sz + t, mxm = m - 1, mxp = m + 1, mym = m - sy, myp = m + sy;
+  const int m = sz + t;
+  int mxm = m - 1, mxp = m + 1, mym = m - sy, myp = m + sy, mzm = m - sz, mzp = m + sz;
+  if (L.periodic && act) {  // (OI_MG_NBRS; z: the image planes 0 and nzl + 1 ARE planes nzl and 1)
+    const int i = t % L.nx, j = (t / L.nx) % L.ny, kk = t / sz;
+    if (i == 0) mxm = m + (L.nx - 1);
+    if (i == L.nx - 1) mxp = m - (L.nx - 1);
+    if (j == 0) mym = m + sy * (L.ny - 1);
+    if (j == L.ny - 1) myp = m - sy * (L.ny - 1);
+    if (kk == 0) mzm = m + sz * (L.nzl - 1);
+    if (kk == L.nzl - 1) mzp = m - sz * (L.nzl - 1);
+  }
   float d = 0.f, bb = 0.f, wxl = 0.f, wxc = 0.f, wyl = 0.f, wyc = 0.f, wzl = 0.f, wzc = 0.f;
   if (act) {
     d = (float)L.diag[m]; bb = b[m];
+    // (the weight of the -z link is read where k_mg_jacobi reads it: from the plane below, the ghost plane for the first one)
     wxl = (float)L.wx[mxm]; wxc = (float)L.wx[m]; wyl = (float)L.wy[mym]; wyc = (float)L.wy[m]; wzl = (float)L.wz[m - sz]; wzc = (float)L.wz[m];
   }
   __syncthreads();
@@ -603,8 +617,8 @@ __global__ void __launch_bounds__(512) k_mg_coarsest(LevelT<W, D> L, const float
       s_ += wxc * xi[mxp];
       s_ += wyl * xi[mym];
       s_ += wyc * xi[myp];
-      s_ += wzl * xi[m - sz];
-      s_ += wzc * xi[m + sz];
+      s_ += wzl * xi[mzm];
+      s_ += wzc * xi[mzp];
       o = c + L.omega * (bb - (d * c - s_)) * rcp(d);
     }
     if (act) xo[m] = o;
@@ -768,6 +782,18 @@ void mg_destroy(MgHierarchy* mg) {
     }                                                                                                                \
   } while (0)
 
+// periodic images of a level that lives whole on this rank, both in ONE launch: ghost plane 0 <- plane nzl, ghost plane nzl + 1 <-
+// plane 1 (round 4: two hipMemcpyAsync per exchange were ~150 blit launches per cycle of the homogenization solve)
+__global__ void __launch_bounds__(256) k_wrap_planes(uint32_t* __restrict__ p, long long plane_words, int nzl) {
+  const long long n = 2 * plane_words;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const bool hi = t >= plane_words;
+    const long long w = hi ? t - plane_words : t;
+    if (hi) p[plane_words * (nzl + 1) + w] = p[plane_words + w];
+    else p[w] = p[plane_words * nzl + w];
+  }
+}
+
 // ghost planes of a per-level array from the z-neighbours (no-op without neighbours / on replicated levels)
 static bool ghost_exchange(MgHierarchy* mg, const MgLevelHost& L, void* base, size_t elem, hipStream_t s) {
   char* p = (char*)base;
@@ -775,6 +801,11 @@ static bool ghost_exchange(MgHierarchy* mg, const MgLevelHost& L, void* base, si
   if (!mg->comm || L.replicated) {
     if (!mg->periodic) return true;
     // the whole level lives here: its first / last plane are each other's periodic images
+    if ((pb & 3) == 0 && L.d.nzl >= 2) {  // (one plane only: source and destination of the two copies are the same pair, keep the ordered copies)
+      const long long words = (long long)(pb >> 2);
+      hipLaunchKernelGGL(k_wrap_planes, dim3(nblk(2 * words, 1024)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words, L.d.nzl);
+      return true;
+    }
     if (hipMemcpyAsync(p, p + pb * (size_t)L.d.nzl, pb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(p + pb * (size_t)(L.d.nzl + 1), p + pb, pb, hipMemcpyDeviceToDevice, s) != hipSuccess) {
       mg->failed = true;
@@ -950,9 +981,10 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   MgLevelHost& L = Ls[l];
   const int kfirst = 1;
   if (l == (int)Ls.size() - 1) {  // coarsest: a fixed number of damped-Jacobi sweeps, the last one lands in `out`
-    if (!mg->periodic && (!mg->comm || L.replicated) && !L.compact && !mg->coarsest_plain && L.d.sz * L.d.nzl <= 512 && L.d.sz <= 512) {
+    // (periodic levels: on one rank only -- a ring of slabs exchanges the planes of a replicated level through the transport)
+    if ((mg->periodic ? !mg->comm : (!mg->comm || L.replicated)) && !L.compact && !mg->coarsest_plain && L.d.sz * L.d.nzl <= 512 && L.d.sz <= 512) {
       hipLaunchKernelGGL((k_mg_coarsest<float, float>), dim3(1), dim3(512), 0, s, L.dev<float, float>(), rhs, out, kCoarsestSweeps);
-      return true;
+      return mg->periodic ? ghost_exchange(mg, L, out, sizeof(float), s) : true;  // (the parent reads the image planes of the correction)
     }
     for (int it = 1; it <= kCoarsestSweeps; ++it) {
       const bool to_out = ((kCoarsestSweeps - it) & 1) == 0;

@@ -146,6 +146,32 @@ def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64, 64), (40, 36, 44), (25, 31, 33)])
+def test_gpu_homogenization_coarsest_level_in_one_launch(sample_phase, oi_option, shape):
+    """Round 4: the periodic coarsest level runs its sixteen sweeps in ONE launch too (k_mg_coarsest with x, y, z neighbours wrapped
+    by index inside the LDS iterate) instead of sixteen launches with two image-plane copies each: same arithmetic in the same
+    order -- the solves are bit-identical with `mg_coarsest_plain` = 1 (even and odd extents, single-cell wraps)."""
+    import openimpala_amd as oia
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
+
+    def run():
+        h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-10, precond=oia.PRECOND_MG)
+        res = [h.solve(k) for k in range(3)]
+        out = res, [h.getChiSolution(k).copy() for k in range(3)], h.tensor().copy()
+        h.destroy()
+        return out
+
+    one = run()
+    oi_option("mg_coarsest_plain", 1)
+    many = run()
+    for k in range(3):
+        assert one[0][k] == many[0][k] and one[0][k][0]
+        assert np.array_equal(one[1][k], many[1][k])
+    assert np.array_equal(one[2], many[2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nranks,nzs", [(2, 48), (3, 37), (4, 64)])
 def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, oi_option, nranks, nzs):
     """The same on a ring of z-slabs: slab-partitioned periodic levels (ring exchange of their ghost planes) and the
