@@ -4,8 +4,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import openimpala_amd as oia
 n = 1024
 shape = (n, n, n)
-names = {0: "st -", 1: "st r q p x", 2: "st r p, ld x", 3: "st r p x, ld x", 4: "st r, ld x", 5: "st r q p, ld x", 6: "st r p, ld x p(k-2)", 7: "st all, ld x", 8: "st r p",
-         9: "st r x, ld x", 10: "st p, ld x", 11: "st -, ld x", 12: "st p x, ld x", 13: "st r p x, ld x p(k-2)", 14: "st r p, ld p(k-2)"}
+# (ids of the table in launch_cg1b_k, oi_kernels.hip, as it stands at the end of round 4; the earlier sweeps -- every load / store policy,
+# per stored array, combinations -- used other tables: their records in profiles/r04/k_cg1b_cache_policies_sweep1..5*.txt name the entries)
+names = {0: "default policy everywhere", 1: "shipped: r p x stored nt, x p(k-2) loaded nt", 2: "shipped, own instantiation", 3: "VAR 1: whole-line flag constant",
+         4: "VAR 2: no halo ROW reads (wrong results)", 5: "VAR 4: no halo COLUMN reads (wrong results)", 6: "VAR 6: neither (wrong results)",
+         7: "shipped + r loaded nt", 8: "shipped + q loaded nt", 9: "shipped + p loaded nt"}
 vals = [int(v) for v in sys.argv[1:]] or sorted(names)
 buf = oia.gen_spheres_device(shape, 20251031, 24, 0.4)
 t = oia.TortuosityMI355(buf, 1, 0, shape=shape, eps=1e-300, kernel=oia.KERNEL_FUSED1, profile=1, maxiter=100000)
@@ -19,6 +22,6 @@ for rep in range(3):
         kt = t.kernel_times()
         res[v].append(kt["cg1"][0] / kt["cg1"][1])
 for v in vals:
-    print(f"{v:2d} {names[v]:24s} " + " ".join(f"{x:.3f}" for x in res[v]) + f"  | median {sorted(res[v])[1]:.3f} ms", flush=True)
+    print(f"{v:2d} {names[v]:48s} " + " ".join(f"{x:.3f}" for x in res[v]) + f"  | median {sorted(res[v])[1]:.3f} ms", flush=True)
 oia.set_option("cg1_nt", 0)
 t.destroy()
