@@ -156,6 +156,12 @@ int main(int argc, char* argv[]) {
     try {
       const auto t_read = std::chrono::steady_clock::now();
       oi_read_set_pinned(1);  // (pageable memory when no device is visible: the error is reported where a device is needed)
+      // this program builds solver object after solver object (one per direction, one per REV sample, as the reference does):
+      // the device arrays of a destroyed one are kept for the next instead of going back to the driver, whose clearing of
+      // recycled memory can cost seconds per allocation on MI355X (gpu.pool = 0 turns that off)
+      int use_pool = 1;
+      in.query("gpu.pool", use_pool);
+      oi_dev_pool(use_pool, 0.0);
       vol = load_volume(input_path, threshold, in);
       if (verbose >= 1)
         std::cout << "  Read + threshold: " << vol.nx << " x " << vol.ny << " x " << vol.nz << " voxels in " << std::defaultfloat

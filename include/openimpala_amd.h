@@ -338,6 +338,15 @@ oi_status oi_dev_malloc(void** ptr, size_t bytes);
 /* free / total memory of the current device (a volume needs 25-60 bytes per voxel) */
 oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 oi_status oi_dev_free(void* ptr);
+/* The process's POOL of released handle arrays (off by default).  A process that builds solver object after solver object of the
+ * same shape -- the reference's direction loop, Diffusion.cpp:655-706: a new TortuosityHypre per direction; its REV study, :317-502 --
+ * pays the driver's clearing of recycled memory again and again on this hardware (one hipMalloc of a few GB: 0.2 ms or seconds).
+ * With the pool on, the device arrays of a destroyed handle are kept and the next request of that size on that device takes one
+ * back, zeroed; the vectors of the placement search never come from it.  cap_gb > 0 bounds what is kept (0: everything, given back
+ * when an allocation fails).  oi_dev_pool(0, 0) and oi_dev_pool_trim return the pooled blocks to the driver (trim: bytes released). */
+oi_status oi_dev_pool(int enable, double cap_gb);
+double oi_dev_pool_trim(void);
+oi_status oi_dev_pool_stats(double* held_bytes, long long* held_blocks, long long* hits, long long* misses, int* enabled);
 /* measurement aid: ms per launch of the library's reference copy stream (linear, 16-byte nontemporal accesses) between
  * two scratch arrays of `bytes` each -- what a 1 read : 1 write stream reaches on this box; bench.py reports it beside
  * the stencil apply */

@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_placement_cost oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
-    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_upload oi_dev_download oi_device_count "
+    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_pool oi_dev_pool_trim oi_dev_pool_stats oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host oi_read_set_pinned"
 ).split()
 
@@ -171,6 +171,9 @@ def lib():
     L.oi_dev_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.oi_dev_stream_copy_bench.argtypes = [C.c_size_t, i, C.POINTER(C.c_double)]
     L.oi_dev_free.argtypes = [vp]
+    L.oi_dev_pool.argtypes = [i, d]
+    L.oi_dev_pool_trim.restype = d
+    L.oi_dev_pool_stats.argtypes = [C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(i)]
     L.oi_dev_upload.argtypes = [vp, vp, C.c_size_t]
     L.oi_dev_download.argtypes = [vp, vp, C.c_size_t]
     L.oi_device_count.restype = i
@@ -374,6 +377,23 @@ def device_memory():
     f, t = C.c_size_t(), C.c_size_t()
     _check(lib().oi_dev_mem_info(C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+def dev_pool(enable, cap_gb=0.0):
+    """The process's pool of released handle arrays (include/openimpala_amd.h: oi_dev_pool): on for a loop over handles of one
+    shape (directions, a REV study), off (the default) to hand a destroyed handle's memory back to the driver at once."""
+    _check(lib().oi_dev_pool(1 if enable else 0, float(cap_gb)))
+
+
+def dev_pool_trim():
+    """Pooled blocks back to the driver; returns the bytes released."""
+    return int(lib().oi_dev_pool_trim())
+
+
+def dev_pool_stats():
+    held, blocks, hits, misses, on = C.c_double(), C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_int()
+    _check(lib().oi_dev_pool_stats(C.byref(held), C.byref(blocks), C.byref(hits), C.byref(misses), C.byref(on)))
+    return {"held_bytes": int(held.value), "held_blocks": blocks.value, "hits": hits.value, "misses": misses.value, "enabled": bool(on.value)}
 
 
 def line_voxels():

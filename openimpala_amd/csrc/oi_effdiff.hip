@@ -26,6 +26,7 @@
 
 #include "oi_comm.h"
 #include "oi_device.h"
+#include "oi_pool.h"
 #include "oi_mg.h"
 
 using namespace oi;
@@ -208,7 +209,7 @@ extern "C" void oi_effdiff_destroy(oi_effdiff* h) {
   if (h->mg) oi::mg_destroy(h->mg);
   void* dev[] = {h->code, h->chi[0], h->chi[1], h->chi[2], h->r, h->p, h->p2, h->q, h->z, h->partials, h->hist, h->scal, h->ctrl, h->counter};
   for (void* d : dev)
-    if (d) (void)hipFree(d);
+    if (d) (void)oi::dev_free(d);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -274,16 +275,16 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   h->maxiter = o.maxiter > 0 ? o.maxiter : 1000 + 4 * (nx + ny + nz);
   HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   hipStream_t s = h->stream;
-  HIPC(hipMalloc((void**)&h->code, (size_t)g.nvec));
-  for (int k = 0; k < 3; ++k) HIPC(hipMalloc((void**)&h->chi[k], sizeof(double) * g.nvec));
-  HIPC(hipMalloc((void**)&h->r, sizeof(double) * g.nvec));
-  HIPC(hipMalloc((void**)&h->p, sizeof(double) * g.nvec));
-  HIPC(hipMalloc((void**)&h->q, sizeof(double) * g.nvec));
-  HIPC(hipMalloc((void**)&h->partials, sizeof(double) * 9 * g.tune.max_blocks));
-  HIPC(hipMalloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
-  HIPC(hipMalloc((void**)&h->scal, sizeof(double) * 16));
-  HIPC(hipMalloc((void**)&h->ctrl, sizeof(Ctrl)));
-  HIPC(hipMalloc((void**)&h->counter, sizeof(unsigned long long)));
+  HIPC(oi::dev_malloc((void**)&h->code, (size_t)g.nvec));
+  for (int k = 0; k < 3; ++k) HIPC(oi::dev_malloc((void**)&h->chi[k], sizeof(double) * g.nvec));
+  HIPC(oi::dev_malloc((void**)&h->r, sizeof(double) * g.nvec));
+  HIPC(oi::dev_malloc((void**)&h->p, sizeof(double) * g.nvec));
+  HIPC(oi::dev_malloc((void**)&h->q, sizeof(double) * g.nvec));
+  HIPC(oi::dev_malloc((void**)&h->partials, sizeof(double) * 9 * g.tune.max_blocks));
+  HIPC(oi::dev_malloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
+  HIPC(oi::dev_malloc((void**)&h->scal, sizeof(double) * 16));
+  HIPC(oi::dev_malloc((void**)&h->ctrl, sizeof(Ctrl)));
+  HIPC(oi::dev_malloc((void**)&h->counter, sizeof(unsigned long long)));
   HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
   HIPC(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), s));
   for (int k = 0; k < 3; ++k) HIPC(hipMemsetAsync(h->chi[k], 0, sizeof(double) * g.nvec, s));
@@ -291,7 +292,7 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   uint8_t* tmp = nullptr;
   const uint8_t* dphase = phase;
   if (!on_device) {
-    HIPC(hipMalloc((void**)&tmp, n));
+    HIPC(oi::dev_malloc((void**)&tmp, n));
     HIPC(hipMemcpyAsync(tmp, phase, n, hipMemcpyHostToDevice, s));
     dphase = tmp;
   }
@@ -300,13 +301,13 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   unsigned long long cnt = 0;
   HIPC(hipMemcpyAsync(&cnt, h->counter, sizeof(cnt), hipMemcpyDeviceToHost, s));
   HIPC(hipStreamSynchronize(s));
-  if (tmp) HIPC(hipFree(tmp));
+  if (tmp) HIPC(oi::dev_free(tmp));
   if (h->comm) OIC(h->comm->allreduce_sum_u64_host(&cnt, 1, s));
   h->n_active = (long long)cnt;
   // one multigrid cycle per PCG iteration (what PFMG is to the reference's FlexGMRES, EffectiveDiffusivityHypre.cpp:
   // 578-600); tiny or empty volumes keep plain CG
   if ((o.precond == OI_PRECOND_MG || o.precond == OI_PRECOND_DEFAULT) && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4) {
-    HIPC(hipMalloc((void**)&h->z, sizeof(double) * g.nvec));
+    HIPC(oi::dev_malloc((void**)&h->z, sizeof(double) * g.nvec));
     HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
     size_t mg_bytes = 0;
     h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);
@@ -320,7 +321,7 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
     h->fused = true;
   }
   if (h->fused) {
-    HIPC(hipMalloc((void**)&h->p2, sizeof(double) * g.nvec));
+    HIPC(oi::dev_malloc((void**)&h->p2, sizeof(double) * g.nvec));
     HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * g.nvec, s));
   }
   *out = h.release();
@@ -451,11 +452,11 @@ extern "C" oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi_ou
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
   double* dense = nullptr;
-  HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
+  HIPC(oi::dev_malloc((void**)&dense, n * sizeof(double)));
   launch_pitch_copy_out(g, h->chi[dir_k], dense, h->stream);
   hipError_t e = hipMemcpyAsync(chi_out, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(dense);
+  (void)oi::dev_free(dense);
   HIPC(e);
   return OI_OK;
 }

@@ -9,6 +9,7 @@
 // Compiled with -ffp-contract=off: every product/sum is rounded exactly as in the
 // CPU oracle, so single-kernel outputs are bit-identical to it.
 #include "oi_device.h"
+#include "oi_pool.h"
 
 
 #include <algorithm>
@@ -553,11 +554,11 @@ hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, 
   if (n >= (1ll << 31)) return hipErrorInvalidValue;
   int* flags = nullptr;
   int* tmp = nullptr;
-  hipError_t e = hipMalloc((void**)&flags, sizeof(int) * n);
+  hipError_t e = oi::dev_malloc((void**)&flags, sizeof(int) * n);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_line_flags, dim3(cap_blocks(n, 256, 8192)), dim3(256), 0, s, g, code, LW, flags);
   const int sblocks = (int)((n + kScanBlock - 1) / kScanBlock);
-  e = hipMalloc((void**)&tmp, sizeof(int) * (size_t)(sblocks > 0 ? sblocks : 1));
+  e = oi::dev_malloc((void**)&tmp, sizeof(int) * (size_t)(sblocks > 0 ? sblocks : 1));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_scan_totals, dim3(sblocks), dim3(256), 0, s, n, flags, tmp);
     hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(256), 0, s, sblocks, tmp);
@@ -569,8 +570,8 @@ hipError_t launch_build_lines(const Geom& g, const uint8_t* code, int* lineoff, 
                        plane_first_dev, (uint2*)seg);
     e = hipStreamSynchronize(s);
   }
-  if (tmp) (void)hipFree(tmp);
-  (void)hipFree(flags);
+  if (tmp) (void)oi::dev_free(tmp);
+  (void)oi::dev_free(flags);
   return e;
 }
 

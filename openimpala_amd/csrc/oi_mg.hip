@@ -39,6 +39,7 @@
 
 #include "oi_comm.h"
 #include "oi_device.h"
+#include "oi_pool.h"
 #include "oi_mg.h"
 
 namespace oi {
@@ -764,7 +765,7 @@ void mg_destroy(MgHierarchy* mg) {
   for (auto& L : mg->levels) {
     void* p[] = {L.wx, L.wy, L.wz, L.diag, L.b, L.b2, L.r, L.x2, L.xs, L.t, L.t2};
     for (void* q : p)
-      if (q) (void)hipFree(q);
+      if (q) (void)oi::dev_free(q);
   }
   delete mg;
 }
@@ -893,18 +894,18 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
     }
     L.n = L.d.sz * (L.d.nzl + 2);
     const size_t wb = L.compact ? 1 : 4, db = L.compact ? 2 : 4;
-    MGC(hipMalloc(&L.wx, wb * L.n)); MGC(hipMalloc(&L.wy, wb * L.n)); MGC(hipMalloc(&L.wz, wb * L.n));
-    MGC(hipMalloc(&L.diag, db * L.n));
+    MGC(oi::dev_malloc(&L.wx, wb * L.n)); MGC(oi::dev_malloc(&L.wy, wb * L.n)); MGC(oi::dev_malloc(&L.wz, wb * L.n));
+    MGC(oi::dev_malloc(&L.diag, db * L.n));
     float** vecs[] = {&L.b, &L.b2, &L.r, &L.x2, &L.xs};
     for (float** v : vecs) {
-      MGC(hipMalloc((void**)v, sizeof(float) * L.n));
+      MGC(oi::dev_malloc((void**)v, sizeof(float) * L.n));
       MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
     }
     mg->bytes += (size_t)L.n * (3 * wb + db + 5 * sizeof(float));
     if (mg->nu_coarse > 1) {
       float** more[] = {&L.t, &L.t2};
       for (float** v : more) {
-        MGC(hipMalloc((void**)v, sizeof(float) * L.n));
+        MGC(oi::dev_malloc((void**)v, sizeof(float) * L.n));
         MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
       }
       mg->bytes += (size_t)L.n * 2 * sizeof(float);
@@ -912,7 +913,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
     // operator: owned contributions into float arrays, summed / exchanged, then (compact levels) narrowed
     float* t[4] = {nullptr, nullptr, nullptr, nullptr};
     if (L.compact) {
-      for (auto& p : t) MGC(hipMalloc((void**)&p, sizeof(float) * L.n));
+      for (auto& p : t) MGC(oi::dev_malloc((void**)&p, sizeof(float) * L.n));
     } else {
       t[0] = (float*)L.wx; t[1] = (float*)L.wy; t[2] = (float*)L.wz; t[3] = (float*)L.diag;
     }
@@ -943,7 +944,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
         hipLaunchKernelGGL(k_mg_compact, dim3(nblk(L.n)), dim3(256), 0, s, L.n, t[0], t[1], t[2], t[3], (uint8_t*)L.wx,
                            (uint8_t*)L.wy, (uint8_t*)L.wz, (uint16_t*)L.diag);
       (void)hipStreamSynchronize(s);
-      for (auto p : t) (void)hipFree(p);
+      for (auto p : t) (void)oi::dev_free(p);
     }
     mg->levels.push_back(L);
     if (!ok) { mg_destroy(mg); return nullptr; }

@@ -27,6 +27,7 @@
 #include "oi_comm.h"
 #include "oi_device.h"
 #include "oi_mg.h"
+#include "oi_pool.h"
 
 namespace oi {
 const char* last_error();
@@ -207,7 +208,7 @@ struct ProfScope {
 // ---- small helpers ---------------------------------------------------------------------
 template <typename T>
 static oi_status dmalloc(oi_tort* h, T** p, size_t count) {
-  HIPC(hipMalloc((void**)p, count * sizeof(T)));
+  HIPC(oi::dev_malloc((void**)p, count * sizeof(T)));  // (hipMalloc, or a block of the process's pool: oi_pool.h)
   h->bytes_device += count * sizeof(T);
   return OI_OK;
 }
@@ -224,8 +225,8 @@ static oi_status ensure_device(int device, int* out_device) {
 }
 
 static void free_setup_buffers(oi_tort* h) {
-  if (h->open) { (void)hipFree(h->open); h->bytes_device -= sizeof(uint64_t) * h->g.nwords; h->open = nullptr; }
-  if (h->rhi) { (void)hipFree(h->rhi); h->bytes_device -= sizeof(uint64_t) * h->g.nwords; h->rhi = nullptr; }
+  if (h->open) { (void)oi::dev_free(h->open); h->bytes_device -= sizeof(uint64_t) * h->g.nwords; h->open = nullptr; }
+  if (h->rhi) { (void)oi::dev_free(h->rhi); h->bytes_device -= sizeof(uint64_t) * h->g.nwords; h->rhi = nullptr; }
 }
 
 static void vecset_free(VecSet& v);
@@ -243,7 +244,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   void* dev[] = {h->open, h->active, h->rhi, h->code, h->x, h->r, h->q, h->p[0], h->p[1], h->r2, h->q2, h->rec, h->lineoff, h->seg, h->plane_first_dev,
                  h->partials, h->fin_scratch, h->hist, h->ctrl, h->scal, h->counters, h->changed};
   for (void* d : dev)
-    if (d) (void)hipFree(d);
+    if (d) (void)oi::dev_free(d);  // (arrays of dmalloc; the vectors of a placement set were handed back above, to the driver)
   void* pin[] = {h->h_ctrl, h->h_counters, h->h_changed, h->h_scal};
   for (void* d : pin)
     if (d) (void)hipHostFree(d);
@@ -254,7 +255,7 @@ extern "C" void oi_tort_destroy(oi_tort* h) {
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_interior) (void)hipEventDestroy(h->ev_interior);
   if (h->mg) oi::mg_destroy(h->mg);
-  if (h->z) (void)hipFree(h->z);
+  if (h->z) (void)oi::dev_free(h->z);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -736,13 +737,13 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   const uint8_t* dphase = phase;
   uint8_t* tmp = nullptr;
   if (!on_device) {
-    HIPC(hipMalloc((void**)&tmp, nphase));
+    HIPC(oi::dev_malloc((void**)&tmp, nphase));
     HIPC(hipMemcpyAsync(tmp, phase, nphase, hipMemcpyHostToDevice, s));
     dphase = tmp;
   }
   { PROF(K_PACK); launch_pack_open(dphase, g, h->phase_id, h->open, &h->counters[3], s); }
   HIPC(hipStreamSynchronize(s));
-  if (tmp) HIPC(hipFree(tmp));
+  if (tmp) HIPC(oi::dev_free(tmp));
   h->st.t_upload_s = now_s() - t0;
 
   // flood fill from both faces (generateActivityMask, TortuosityHypre.cpp:394-558)
@@ -857,7 +858,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
     if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)h->nvec_cg));
     for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
-      HIPC(hipMalloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
+      HIPC(oi::dev_malloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
       h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
     }
   }
@@ -1993,6 +1994,22 @@ extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
   return OI_OK;
 }
 extern "C" oi_status oi_dev_free(void* ptr) { HIPC(hipFree(ptr)); return OI_OK; }
+
+// The process's pool of released handle arrays (oi_pool.h): OFF by default.
+extern "C" oi_status oi_dev_pool(int enable, double cap_gb) {
+  oi::dev_pool_set(enable != 0, cap_gb > 0.0 ? (size_t)(cap_gb * 1e9) : 0);
+  return OI_OK;
+}
+extern "C" double oi_dev_pool_trim(void) { return (double)oi::dev_pool_trim(); }
+extern "C" oi_status oi_dev_pool_stats(double* held_bytes, long long* held_blocks, long long* hits, long long* misses, int* enabled) {
+  const oi::DevPoolStats st = oi::dev_pool_stats();
+  if (held_bytes) *held_bytes = (double)st.held_bytes;
+  if (held_blocks) *held_blocks = (long long)st.held_blocks;
+  if (hits) *hits = (long long)st.hits;
+  if (misses) *misses = (long long)st.misses;
+  if (enabled) *enabled = st.on;
+  return OI_OK;
+}
 extern "C" oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
   if (!free_bytes || !total_bytes) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;

@@ -100,6 +100,46 @@ def test_out_of_memory_is_an_error_not_a_crash():
     t.destroy(); ph.free()
 
 
+def test_device_pool_keeps_and_returns_blocks(sample):
+    """oi_dev_pool (off by default): with it ON the device arrays of a destroyed handle are kept for the next handle of that
+    shape -- same results, zeroed blocks, hits counted -- and trim / switching it off hands everything back to the driver."""
+    sub = np.ascontiguousarray(sample[:64, :72, :80])
+
+    def solve_all():
+        out = []
+        for d in range(3):
+            t = oia.TortuosityMI355(sub, 1, d, -1.0, 1.0, eps=1e-10)
+            out.append((t.value(), t.getSolverIterations(), t.stats().final_relres, t.solution().copy()))
+            t.destroy()
+        h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-9, precond=oia.PRECOND_MG)
+        out.append(tuple(h.solve(k) for k in range(3)) + (h.tensor().copy(),))
+        h.destroy()
+        return out
+
+    assert not oia.dev_pool_stats()["enabled"]
+    plain = solve_all()
+    free_off = oia.device_memory()[0]
+    try:
+        oia.dev_pool(True)
+        first = solve_all()
+        st1 = oia.dev_pool_stats()
+        again = solve_all()   # every array of this pass comes out of the pool
+        st2 = oia.dev_pool_stats()
+        assert st1["enabled"] and st1["held_blocks"] > 10 and st2["hits"] > st1["hits"] + 30 and st2["misses"] - st1["misses"] < 10, (st1, st2)
+        assert oia.device_memory()[0] < free_off - (st2["held_bytes"] >> 1)   # (the pool holds what the driver does not have)
+        for a, b, c in zip(plain[:3], first[:3], again[:3]):
+            assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1] and a[2] == b[2] == c[2]
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], c[3])
+        assert plain[3][:3] == first[3][:3] == again[3][:3] and np.array_equal(plain[3][3], again[3][3])
+        released = oia.dev_pool_trim()
+        assert released == st2["held_bytes"] and oia.dev_pool_stats()["held_blocks"] == 0
+    finally:
+        oia.dev_pool(False)
+    import time
+    time.sleep(0.3)
+    assert oia.device_memory()[0] > free_off - (64 << 20)
+
+
 RELEASE_VARIANTS = (("mg", dict()), ("cg1", dict(kernel=oia.KERNEL_FUSED1)), ("lean_jacobi", dict(kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_JACOBI)),
                     ("fused", dict(kernel=oia.KERNEL_FUSED, precond=oia.PRECOND_NONE)), ("unfused_mg", dict(kernel=oia.KERNEL_UNFUSED, precond=oia.PRECOND_MG)))
 

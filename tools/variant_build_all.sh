@@ -15,5 +15,5 @@ for src in oi_kernels.hip oi_tort.cpp oi_mg.hip oi_effdiff.hip oi_comm.cpp; do
 done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/libopenimpala_amd_$tag.so $out/oi_kernels.o $out/oi_tort.o $out/oi_comm.o \
-    oi_io.o oi_hdf5.o $out/oi_effdiff.o $out/oi_mg.o -L/opt/rocm/lib -lrccl -lz -Wl,-rpath,/opt/rocm/lib
+    oi_io.o oi_hdf5.o $out/oi_effdiff.o $out/oi_mg.o oi_pool.o -L/opt/rocm/lib -lrccl -lz -Wl,-rpath,/opt/rocm/lib
 ls -la ../../tools/libopenimpala_amd_$tag.so
