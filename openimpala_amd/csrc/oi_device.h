@@ -132,7 +132,8 @@ void launch_pack_open(const uint8_t* phase /*nzl planes, no ghosts, row pitch nx
                       int phase_id, uint64_t* open, unsigned long long* n_phase, hipStream_t s);
 void launch_seed(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, hipStream_t s);
 void launch_flood_sweep(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, int* changed,
-                        hipStream_t s);
+                        hipStream_t s, int reverse = 0 /* 1: from the last plane down */);
+void launch_flood_zwalk(const Geom& g, const uint64_t* open, uint64_t* rlo, uint64_t* rhi, int* changed, hipStream_t s);
 void launch_mask_and(const Geom& g, uint64_t* rlo_to_active, const uint64_t* rhi,
                      unsigned long long* counts /*[0]=active,[1]=lo face,[2]=hi face*/, hipStream_t s);
 void launch_codes(const Geom& g, const uint64_t* active, uint8_t* code, unsigned long long* n_free,
