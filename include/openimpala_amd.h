@@ -280,6 +280,8 @@ int oi_tort_line_voxels(void);
  *                   post-smoother every iteration instead of two terms every second one), "mg_blocked" (0: pre-smoothing residual and
  *                   restriction of the coarse levels as two kernels instead of one); of the single-kernel iteration:
  *                   "cg1_seg" (0: per-line slot table instead of segment records), "cg1_fin_sliced" (0: final sums by one block)
+ *   "dense_nt"      bit mask (default 31): nontemporal stores of p (1), x (2), q (4), r (8) and the smoother's output (16) in the
+ *                   kernels of the dense layouts (homogenization, two-kernel and unfused variants); 0 = the default policy (A/B)
  *   "cg1_nt"        1 (default): the streamed vectors of the descriptor-addressed kernels take nontemporal stores / loads (same
  *                   arithmetic, other cache policy); 0 = the default policy everywhere (A/B)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,

@@ -35,6 +35,9 @@ struct Tune {
   int cg1_seg = 1;       // k_cg1b: line slots from per-row segment records (scalar loads) instead of the per-line table
   int cg1_nt = 1;        // k_cg1b (all forms): 1 = the streamed vectors take nontemporal accesses (which ones: kNtSt* / kNtLd* in
                          // oi_kernels.hip, chosen by in-process A/B, profiles/r04/k_cg1b_cache_policies_*.txt); 0 = default policy
+  int dense_nt = 31;     // LDS-tiled / flat kernels of the dense layouts (homogenization, two-kernel and unfused variants): nontemporal stores of
+                         // p_out (1), x (2), q (4), r (8), the smoother's output (16).  All on: -2 % on the homogenization iteration at 1024^3
+                         // (19.08 -> 18.7 ms, profiles/r04/homogenization_dense_kernels_nontemporal.txt; single bits within the noise); 0: A/B
   int cg1_kernel = 0;    // compacted layout: 0 = k_cg1b (descriptor-addressed, all loads of a plane in one burst), 1 = k_cg1
   int apply_kernel = 0;  // stand-alone apply: 0 = wave-autonomous k_apply7, 1 = LDS-tiled k_fused_a<PURE>
   int mg_plain = 0, mg_novec4 = 0, mg_debug = 0;  // multigrid cross-check switches (env OI_MG_PLAIN / _NOVEC4 / _DEBUG)

@@ -428,6 +428,12 @@ __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_ca
 __device__ __forceinline__ void st2(double* p, double a, double b) {
   *reinterpret_cast<double2*>(p) = make_double2(a, b);
 }
+// the same store with a cache policy chosen at run time (Tune::dense_nt, a wave-uniform flag): nontemporal for a streamed array
+typedef double v2dn_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st2p(double* p, double a, double b, bool nt) {
+  if (nt) { v2dn_t v = {a, b}; __builtin_nontemporal_store(v, reinterpret_cast<v2dn_t*>(p)); }
+  else st2(p, a, b);
+}
 
 // (A v) for the pair at element e = (gz, j, i..i+1); i even.  Needs the row/plane bounds.
 __device__ __forceinline__ Pair apply_pair(const Geom& g, const double* __restrict__ v, long long e, int i, int j,
@@ -704,10 +710,10 @@ __global__ void __launch_bounds__(256) k_update_xr(Geom g, const uint8_t* __rest
     const double2 rv = ld2(r + e), qv = ld2(q + e);
     if (WITH_X) {
       const double2 xv = ld2(x + e), pv = ld2(p + e);
-      st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+      st2p(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y, g.tune.dense_nt & 2);
     }
     const double r0 = rv.x - alpha * qv.x, r1 = rv.y - alpha * qv.y;
-    st2(r + e, r0, r1);
+    st2p(r + e, r0, r1, g.tune.dense_nt & 8);
     double z0 = r0, z1 = r1;
     if (JACOBI) {
       const unsigned short cc = *reinterpret_cast<const unsigned short*>(code + e);
@@ -1021,10 +1027,11 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
         }
         pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
         if (mode != 0) {
-          PIo<PT>::st_pair(p_out + ev, pn[rr_].x, pn[rr_].y);
+          if (std::is_same<PT, double>::value && (g.tune.dense_nt & 1)) st2p(reinterpret_cast<double*>(p_out) + ev, pn[rr_].x, pn[rr_].y, true);
+          else PIo<PT>::st_pair(p_out + ev, pn[rr_].x, pn[rr_].y);
           if (mode == 1 && k > 0) {
             const double2 xv = ld2(x + e);
-            st2(x + e, xv.x + alpha_prev * pin.x, xv.y + alpha_prev * pin.y);
+            st2p(x + e, xv.x + alpha_prev * pin.x, xv.y + alpha_prev * pin.y, g.tune.dense_nt & 2);
           }
         }
       }
@@ -1161,7 +1168,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_fused_a(Geom g, 
           pz += r0 * z0; pz += r1 * z1;
           continue;
         }
-        if (LEAN == 0 || LEAN == 3) st2(q + ev, q0, q1);
+        if (LEAN == 0 || LEAN == 3) st2p(q + ev, q0, q1, g.tune.dense_nt & 4);
         pq += pc.x * q0; pq += pc.y * q1;
       }
     }
@@ -1747,7 +1754,7 @@ __global__ void __launch_bounds__(64 * kNW, (R <= 2 ? 4 : 2)) k_mg_fine(Geom g, 
         if (c0) { const double av = (double)c0 * vc.x - s0; o0 = MODE != 2 ? bc.x - av : vc.x + (bc.x - av) * wtab[c0]; }
         if (c1) { const double av = (double)c1 * vc.y - s1; o1 = MODE != 2 ? bc.y - av : vc.y + (bc.y - av) * wtab[c1]; }
         if (MODE == 3) { xsum[rr_] = o0 + o1; continue; }
-        st2(out + (COMPACT ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e), o0, o1);
+        st2p(out + (COMPACT ? (long long)kLV * lo_cur[rr_] + (i & (kLV - 1)) : e), o0, o1, g.tune.dense_nt & 16);
         dot += o0 * bc.x; dot += o1 * bc.y;
       }
     }

@@ -2146,6 +2146,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   const int iv = (int)value;
   if (k == "tile_map") t.tile_map = iv;
   else if (k == "cg1_nt") t.cg1_nt = iv;
+  else if (k == "dense_nt") t.dense_nt = iv & 31;
   else if (k == "zchunk") t.zchunk = iv > 0 ? iv : 0;
   else if (k == "apply_kernel") t.apply_kernel = iv;
   else if (k == "mg_plain") t.mg_plain = iv != 0;
