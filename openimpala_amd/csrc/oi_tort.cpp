@@ -620,12 +620,11 @@ static oi_status place_search(oi_tort* h) {
   return OI_OK;
 }
 
-// About one process in fifteen gets allocations in which NO placement matters (all 48 trials within 1 % of the in-order
-// layout) and everything is slow -- a 3-read / 3-write stream of the vectors moves 5.3 TB/s there against 6.1-6.4
-// elsewhere (profiles/r02/placement/final_12_runs.txt, bench_r02f_flat_arena.json).  That is a property of where the
-// driver put those allocations, so the remedy is other allocations: when the landscape is flat AND the stream is slow, a
-// second set is allocated while the chosen seven arrays of the first are still held (so that it lands elsewhere),
-// searched, and the better set kept.  Costs a second search in that one case only.
+// About one process in ten to fifteen gets allocations in which everything is slow wherever the vectors lie -- a 3-read / 3-write
+// stream of the vectors moves 5.3-5.4 TB/s there against 6.05-6.4 elsewhere (profiles/r02/placement/final_12_runs.txt,
+// bench_r02f_flat_arena.json).  That is a property of where the driver put those allocations, so the remedy is other allocations:
+// when the stream of the kept vectors is slow, a second set is allocated while the chosen seven arrays of the first are still held
+// (so that it lands elsewhere), searched, and the better set kept.  Costs a second search in that one case only.
 static oi_status place_vectors(oi_tort* h) {
   if (!h->vs.x || h->g.tune.place_trials <= 0 || h->hist_cap < 4) {
     release_unchosen(h);  // (a set allocated for a search that is not going to run keeps its six slots in order, nothing else)
@@ -636,7 +635,10 @@ static oi_status place_vectors(oi_tort* h) {
   release_unchosen(h);
   hipStream_t s = h->stream;
   int again = 0;
-  if (h->placement_ms_best > 0.97 * h->placement_ms_first && !h->p_f32 && !h->place_cache_hit) {
+  // (round 4: no longer only when the search came back flat -- with the nontemporal policy EVERY landscape is nearly flat, a good set
+  // of allocations goes from 6.28 to 6.09 ms and a slow one from 7.03 to 6.79, profiles/r04/r04e_rocprof_summary_slow_placement_class.txt;
+  // what tells them apart is the stream of the kept vectors, 6.05-6.3 TB/s against 5.4)
+  if (!h->p_f32 && !h->place_cache_hit) {
     const long long nd = h->nvec_cg / 512 * 512;
     hipEvent_t a = nullptr, b = nullptr;
     HIPC(hipEventCreate(&a)); HIPC(hipEventCreate(&b));
