@@ -806,15 +806,18 @@ extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_fil
   *phase = nullptr;
   uint8_t* out = nullptr;
   Ifd p0;
-  std::vector<uint8_t> buf;
-  for (int k = 0; k < num_files; ++k) {
+  auto name_of = [&](int k) {
     char num[64];
     snprintf(num, sizeof(num), "%0*d", digits, start_index + k);
-    const std::string name = std::string(base_pattern) + num + (suffix ? suffix : "");
+    return std::string(base_pattern) + num + (suffix ? suffix : "");
+  };
+  // the first file fixes the slice size and type (and the output buffer) ...
+  {
+    const std::string name = name_of(0);
     File f;
     std::vector<Ifd> pages;
     oi_status st = open_tiff(name.c_str(), f, pages);
-    if (st == OI_OK && k == 0) {
+    if (st == OI_OK) {
       p0 = pages[0];
       st = check_first_page(name.c_str(), p0);
       if (st == OI_OK && (p0.w == 0 || p0.h == 0 || p0.w > (size_t)INT_MAX || p0.h > (size_t)INT_MAX ||
@@ -828,8 +831,33 @@ extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_fil
         if (!out) { oi::set_error("out of memory"); st = OI_IO_ERROR; }
       }
     }
-    if (st == OI_OK) st = decode_page(name.c_str(), f, pages[0], p0, (size_t)k, threshold, out + (size_t)k * p0.w * p0.h, buf);
+    std::vector<uint8_t> buf;
+    if (st == OI_OK) st = decode_page(name.c_str(), f, pages[0], p0, 0, threshold, out, buf);
     if (st != OI_OK) { oi_free_host(out); return st; }
+  }
+  // ... the others are independent files: opened, decoded and thresholded on the host cores this process may use (round 4; a
+  // tomogram stored as one TIFF per slice is the reference's readFileSequence case, TiffReader.cpp:209-285)
+  std::string first_error;
+  std::mutex mu;
+  std::atomic<int> failed{0};
+  oi::parallel_for((size_t)(num_files - 1), [&](size_t kk) {
+    if (failed.load()) return;
+    const int k = (int)kk + 1;
+    const std::string name = name_of(k);
+    File f;
+    std::vector<Ifd> pages;
+    thread_local std::vector<uint8_t> buf;
+    oi_status st = open_tiff(name.c_str(), f, pages);
+    if (st == OI_OK) st = decode_page(name.c_str(), f, pages[0], p0, (size_t)k, threshold, out + (size_t)k * p0.w * p0.h, buf);
+    if (st != OI_OK) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failed.exchange((int)st)) first_error = oi::last_error();  // (the message is thread-local)
+    }
+  });
+  if (failed.load()) {
+    oi_free_host(out);
+    oi::set_error("%s", first_error.c_str());
+    return (oi_status)failed.load();
   }
   *phase = out;
   *nx = (int)p0.w; *ny = (int)p0.h; *nz = num_files;
