@@ -141,6 +141,10 @@ int main(int argc, char* argv[]) {
     in.query("box_size", box_size);  // AMReX max grid size: only the remspot filter depends on it (it runs per box)
     in.query("verbose", verbose);
     in.query("write_plotfile", write_plotfile);
+    // debug.write_active_mask (TortuosityHypre.cpp:542-545: read there, its plotfile body elided in the reference's snapshot): here the
+    // percolation mask of every direction is written as raw bytes, x fastest, beside the results file
+    int write_active_mask = 0;
+    in.query("debug.write_active_mask", write_active_mask);
     in.query("calculation_method", method);
     in.query("output_filename", output_filename);
 
@@ -446,6 +450,18 @@ int main(int argc, char* argv[]) {
           mask.resize(vol.phase.size());
           have_phi = oi_tort_get_solution(solver_ptr->handle(), phi.data()) == OI_OK;
           have_mask = oi_tort_get_mask(solver_ptr->handle(), mask.data()) == OI_OK;
+        }
+        if (write_active_mask != 0) {
+          std::vector<std::uint8_t> am(vol.phase.size());
+          if (oi_tort_get_mask(solver_ptr->handle(), am.data()) == OI_OK) {
+            const auto mbase = results_dir / ("active_mask_" + dc);
+            std::ofstream(mbase.string() + ".raw", std::ios::binary).write(reinterpret_cast<const char*>(am.data()), static_cast<std::streamsize>(am.size()));
+            std::ofstream(mbase.string() + ".txt") << "active_mask uint8 nx=" << vol.nx << " ny=" << vol.ny << " nz=" << vol.nz << " x-fastest (1 = phase " << phase_id
+                                                  << " voxel connected to both faces of direction " << dc << ")\n";
+            if (verbose >= 1) std::cout << "  Active mask written to " << mbase.string() << ".raw\n";
+          } else {
+            std::cerr << "Warning: could not read the active mask back: " << oi_last_error() << "\n";
+          }
         }
       } else {
         // ---- z-slabs: slab boundaries on multiples of 16 planes where the volume allows it (keeps the

@@ -3,6 +3,7 @@ flow-through run and the results-file text on the GPU."""
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import ROOT, GOLDEN
@@ -82,6 +83,12 @@ solver_type = FlexGMRES
     assert r.returncode == 0, r.stderr
     lines = open(tmp_path / "res" / "p0.txt").read().splitlines()
     assert lines[4] == "VolumeFraction: 0.601691000" and lines[5].startswith("Tortuosity_Z: 1.69305")
+    # debug.write_active_mask (read by the reference, TortuosityHypre.cpp:542-545): the percolation mask of the direction, as raw bytes
+    r = subprocess.run([app, _inputs(tmp_path, text), "direction=Y", "debug.write_active_mask=1", "output_filename=m.txt", "verbose=0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    am = np.fromfile(tmp_path / "res" / "active_mask_Y.raw", dtype=np.uint8)
+    assert am.size == 100 ** 3 and set(np.unique(am)) <= {0, 1} and am.mean() == pytest.approx(0.397743, abs=1e-6)   # active VF of phase 1
 
 
 @pytest.mark.gpu
