@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "oi_tort_default_opts oi_tort_create oi_tort_create_device oi_tort_create_slab oi_tort_destroy "
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
-    "oi_effdiff_info oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
+    "oi_effdiff_info oi_effdiff_layout oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_placement_cost oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
@@ -120,6 +120,7 @@ def lib():
     L.oi_effdiff_get_chi.argtypes = [vp, i, vp]
     L.oi_effdiff_tensor.argtypes = [vp, C.POINTER(d)]
     L.oi_effdiff_info.argtypes = [vp, i64p, C.POINTER(i), C.POINTER(d)]
+    L.oi_effdiff_layout.argtypes = [vp, C.POINTER(i), i64p]
     L.oi_effdiff_destroy.argtypes = [vp]
     L.oi_effdiff_destroy.restype = None
     L.oi_tort_set_eps.argtypes = [vp, d]
@@ -667,6 +668,13 @@ class EffectiveDiffusivityMI355:
         D = (C.c_double * 9)()
         _check(lib().oi_effdiff_tensor(self._h, D))
         return np.array(D[:]).reshape(3, 3)
+
+    def layout(self):
+        """(compacted, doubles per CG vector): compacted = True when the solves run on line-compacted vectors with the rotated
+        multigrid iteration (whole-tile volumes on one GPU), False on dense vectors."""
+        c, n = C.c_int(), C.c_int64()
+        _check(lib().oi_effdiff_layout(self._h, C.byref(c), C.byref(n)))
+        return bool(c.value), n.value
 
     def destroy(self):
         if self._h:

@@ -115,6 +115,32 @@ __global__ void __launch_bounds__(256) k_ed_rhs(Geom g, const uint8_t* __restric
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = t; partials[2 * blockIdx.x + 1] = t; }  // {r.r, r.z}
 }
 
+// the same right-hand side into the COMPACTED line layout (launch_build_lines): r only -- the rotated iteration starts from
+// p = 0 and chi = 0 (memsets) -- and the partial sums {r.r, r.r}.  A line without an active cell is not stored and has b = 0.
+__global__ void __launch_bounds__(256) k_ed_rhs_lines(Geom g, const uint8_t* __restrict__ code, int dir_k, double* __restrict__ r,
+                                                       const int* __restrict__ lineoff, int LW, double* __restrict__ partials) {
+  const long long n = (long long)g.nzl * g.ny * g.nx;
+  double rr = 0.0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(v % g.nx), j = (int)((v / g.nx) % g.ny), gz = 1 + (int)(v / ((long long)g.nx * g.ny));
+    const int lo = lineoff[((long long)gz * g.ny + j) * LW + (i >> kLVs)];
+    if (lo < 0) continue;
+    const long long e = (long long)gz * g.plane + (long long)j * g.pitch + i;
+    double b = 0.0;
+    if (code[e]) {
+      const int di = dir_k == 0, dj = dir_k == 1, dk = dir_k == 2;
+      const double dm = code[eidx(g, gz - dk, j - dj, i - di)] ? 1.0 : 0.0;
+      const double dp = code[eidx(g, gz + dk, j + dj, i + di)] ? 1.0 : 0.0;
+      b = (dp - dm) * 0.5;
+    }
+    r[(long long)kLV * lo + (i & (kLV - 1))] = b;
+    rr += b * b;
+  }
+  __shared__ double red[4];
+  const double t = block_sum(rr, red);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = t; partials[2 * blockIdx.x + 1] = t; }
+}
+
 // q = A v (periodic), partial v.q; same summation order as the oracle
 __global__ void __launch_bounds__(256) k_ed_apply(Geom g, const uint8_t* __restrict__ code,
                                                    const double* __restrict__ v, double* __restrict__ q,
@@ -191,6 +217,15 @@ struct oi_effdiff {
   double* z = nullptr;              // preconditioned residual (OI_PRECOND_MG)
   double* p2 = nullptr;             // second search-direction buffer of the fused two-kernel iteration
   bool fused = false;               // multigrid PCG on the tiled kernels of the flow-through path (even extents)
+  // round 4: whole-tile volumes on one GPU take the flow-through path's COMPACTED vectors (r, q, p, z: only the 8-voxel lines
+  // that hold an active cell) and its rotated multigrid iteration on k_cg1b's forms (oi_tort.cpp: cg_one_iteration, h->rot)
+  bool rot = false;
+  int* lineoff = nullptr;
+  long long* plane_first_dev = nullptr;
+  void* seg = nullptr;
+  std::vector<long long> plane_first;
+  long long nvec_cg = 0;            // elements of r / q / p / z (= g.nvec on dense vectors)
+  double* r2 = nullptr;             // second residual buffer of the rotated iteration
   oi::MgHierarchy* mg = nullptr;    // periodic aggregation-multigrid hierarchy of the cell problems
   double *partials = nullptr, *hist = nullptr, *scal = nullptr;
   Ctrl* ctrl = nullptr;
@@ -207,7 +242,8 @@ extern "C" void oi_effdiff_destroy(oi_effdiff* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->mg) oi::mg_destroy(h->mg);
-  void* dev[] = {h->code, h->chi[0], h->chi[1], h->chi[2], h->r, h->p, h->p2, h->q, h->z, h->partials, h->hist, h->scal, h->ctrl, h->counter};
+  void* dev[] = {h->code, h->chi[0], h->chi[1], h->chi[2], h->r, h->r2, h->p, h->p2, h->q, h->z, h->partials, h->hist, h->scal, h->ctrl, h->counter,
+                 h->lineoff, h->plane_first_dev, h->seg};
   for (void* d : dev)
     if (d) (void)oi::dev_free(d);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -224,6 +260,16 @@ static oi_status wrap_z(oi_effdiff* h, void* base, size_t plane_bytes) {
                                   h->stream);
   HIPC(hipMemcpyAsync(b, b + plane_bytes * nzl, plane_bytes, hipMemcpyDeviceToDevice, h->stream));
   HIPC(hipMemcpyAsync(b + plane_bytes * (nzl + 1), b + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, h->stream));
+  return OI_OK;
+}
+
+// the same images for a COMPACTED vector: the stored lines of plane nzl are those of ghost plane 0 (same code bytes, same line
+// list), those of plane 1 are ghost plane nzl + 1's
+static oi_status wrap_lines(oi_effdiff* h, double* v) {
+  const std::vector<long long>& pf = h->plane_first;
+  const size_t nzl = (size_t)h->g.nzl, le = (size_t)kLV * sizeof(double);
+  HIPC(hipMemcpyAsync(v + kLV * pf[0], v + kLV * pf[nzl], le * (size_t)(pf[nzl + 1] - pf[nzl]), hipMemcpyDeviceToDevice, h->stream));
+  HIPC(hipMemcpyAsync(v + kLV * pf[nzl + 1], v + kLV * pf[1], le * (size_t)(pf[2] - pf[1]), hipMemcpyDeviceToDevice, h->stream));
   return OI_OK;
 }
 
@@ -277,9 +323,6 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   hipStream_t s = h->stream;
   HIPC(oi::dev_malloc((void**)&h->code, (size_t)g.nvec));
   for (int k = 0; k < 3; ++k) HIPC(oi::dev_malloc((void**)&h->chi[k], sizeof(double) * g.nvec));
-  HIPC(oi::dev_malloc((void**)&h->r, sizeof(double) * g.nvec));
-  HIPC(oi::dev_malloc((void**)&h->p, sizeof(double) * g.nvec));
-  HIPC(oi::dev_malloc((void**)&h->q, sizeof(double) * g.nvec));
   HIPC(oi::dev_malloc((void**)&h->partials, sizeof(double) * 9 * g.tune.max_blocks));
   HIPC(oi::dev_malloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
   HIPC(oi::dev_malloc((void**)&h->scal, sizeof(double) * 16));
@@ -306,9 +349,41 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   h->n_active = (long long)cnt;
   // one multigrid cycle per PCG iteration (what PFMG is to the reference's FlexGMRES, EffectiveDiffusivityHypre.cpp:
   // 578-600); tiny or empty volumes keep plain CG
-  if ((o.precond == OI_PRECOND_MG || o.precond == OI_PRECOND_DEFAULT) && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4) {
-    HIPC(oi::dev_malloc((void**)&h->z, sizeof(double) * g.nvec));
-    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * g.nvec, s));
+  const bool want_mg = (o.precond == OI_PRECOND_MG || o.precond == OI_PRECOND_DEFAULT) && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4;
+  h->nvec_cg = g.nvec;
+  // Compacted vectors + the rotated iteration of the flow-through path (k_cg1b FORM 2 -> coarse levels, FORM 3 -> FORM 1): one GPU,
+  // planes that are whole 128 x 16 tiles (the wrapped halo then sits where a halo always sits), whole z pairs
+  if (want_mg && !h->comm && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g)) {
+    const int LW = (g.pitch + kLV - 1) / kLV;
+    const long long nlines = (long long)(nzl + 2) * ny * LW;
+    if (nlines < (1ll << 31)) {
+      HIPC(oi::dev_malloc((void**)&h->lineoff, sizeof(int) * (size_t)nlines));
+      HIPC(oi::dev_malloc((void**)&h->plane_first_dev, sizeof(long long) * ((size_t)nzl + 3)));
+      HIPC(oi::dev_malloc(&h->seg, sizeof(uint2) * (size_t)(nzl + 2) * ny * ((g.pitch + 127) / 128)));
+      HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, h->seg, s));
+      h->plane_first.resize((size_t)nzl + 3);
+      HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (nzl + 3), hipMemcpyDeviceToHost));
+      const std::vector<long long>& pf = h->plane_first;
+      // (the ghost planes carry the code bytes of their images: the same line lists, or the layout is not what wrap_lines assumes)
+      const bool images = pf[1] - pf[0] == pf[nzl + 1] - pf[nzl] && pf[nzl + 2] - pf[nzl + 1] == pf[2] - pf[1];
+      g.live_lines = (float)((double)pf[nzl + 2] / (double)nlines);
+      h->rot = images && fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, 0) && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg);
+      if (h->rot) {
+        h->nvec_cg = std::max<long long>(16, (long long)kLV * pf[nzl + 2]);
+      } else {
+        (void)oi::dev_free(h->lineoff); (void)oi::dev_free(h->plane_first_dev); (void)oi::dev_free(h->seg);
+        h->lineoff = nullptr; h->plane_first_dev = nullptr; h->seg = nullptr;
+        g.live_lines = 0.f;
+      }
+    }
+  }
+  HIPC(oi::dev_malloc((void**)&h->r, sizeof(double) * h->nvec_cg));
+  HIPC(oi::dev_malloc((void**)&h->p, sizeof(double) * h->nvec_cg));
+  HIPC(oi::dev_malloc((void**)&h->q, sizeof(double) * h->nvec_cg));
+  if (h->rot) HIPC(oi::dev_malloc((void**)&h->r2, sizeof(double) * h->nvec_cg));
+  if (want_mg) {
+    HIPC(oi::dev_malloc((void**)&h->z, sizeof(double) * h->nvec_cg));
+    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
     size_t mg_bytes = 0;
     h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);
     if (!h->mg) return OI_HIP_ERROR;
@@ -321,8 +396,8 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
     h->fused = true;
   }
   if (h->fused) {
-    HIPC(oi::dev_malloc((void**)&h->p2, sizeof(double) * g.nvec));
-    HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * g.nvec, s));
+    HIPC(oi::dev_malloc((void**)&h->p2, sizeof(double) * h->nvec_cg));
+    HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
   }
   *out = h.release();
   return OI_OK;
@@ -359,14 +434,19 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
     return OI_OK;
   }
   HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * (h->maxiter + 2), s));
-  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * g.nvec, s));
-  HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * g.nvec, s));
-  if (h->p2) HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * g.nvec, s));
-  HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * g.nvec, s));
+  // (rotated iteration: r is written whole by k_ed_rhs_lines + its images, r2 and p by launch 0 before anything reads them; what
+  // launch 0 READS beside r -- q_{-1} and p_{-1}, multiplied by alpha = beta = 0 -- must be finite, so those two are cleared)
+  if (!h->rot) {
+    HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * h->nvec_cg, s));
+    HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * h->nvec_cg, s));
+  }
+  if (h->p2) HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
+  HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * h->nvec_cg, s));
   HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));
   const long long n = (long long)g.nzl * g.ny * g.nx;
   const int nb0 = nblocks(n, 2048);
-  hipLaunchKernelGGL(k_ed_rhs, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, chi, h->r, h->p, h->partials);
+  if (h->rot) hipLaunchKernelGGL(k_ed_rhs_lines, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, h->r, h->lineoff, (g.pitch + kLV - 1) / kLV, h->partials);
+  else hipLaunchKernelGGL(k_ed_rhs, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, chi, h->r, h->p, h->partials);
   Ctrl c;
   c.done = 0; c.pad = 0; c.tol2 = std::numeric_limits<double>::infinity();  // set once ||b|| is known
   HIPC(hipMemcpyAsync(h->ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice, s));
@@ -384,9 +464,40 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
     const int batch = h->opts.check_every > 0 ? h->opts.check_every : (h->mg ? 4 : 16);
     int issued = 0;
     Ctrl seen = c;
-    while (!seen.done && issued < h->maxiter) {
-      for (int b = 0; b < batch && issued < h->maxiter; ++b, ++issued) {
+    const int limit = h->maxiter + (h->rot ? 1 : 0);  // launch k of the rotated iteration completes iteration k - 1
+    if (h->rot) OIC(wrap_lines(h, h->r));
+    while (!seen.done && issued < limit) {
+      for (int b = 0; b < batch && issued < limit; ++b, ++issued) {
         const int k = issued;
+        if (h->rot) {
+          // oi_tort.cpp, cg_one_iteration (h->rot), with the plane exchange of a slab replaced by the periodic images.
+          // A: r_k = r_{k-1} - alpha_{k-1} q_{k-1}, ||r_k||^2 and the stop test, pre-smoother + restriction; B: the rest of the
+          // cycle, z_k, r_k.z_k and (even launches) chi += alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}; C: p_k, q_k, p_k.q_k
+          double* pbuf[2] = {h->p, h->p2};
+          double* p_in = pbuf[(k + 1) & 1];
+          double* p_out = pbuf[k & 1];
+          const double* r_in = (k & 1) ? h->r2 : h->r;
+          double* r_out = (k & 1) ? h->r : h->r2;
+          MgCoarse cref{};
+          float* bcoarse = nullptr;
+          double omega = 0.0;
+          if (!oi::mg_coarse_target(h->mg, &cref, &bcoarse, &omega, s)) return OI_HIP_ERROR;
+          int nb = launch_mg_pre_update(g, h->code, r_in, r_out, h->q, h->hist, k, cref, bcoarse, omega, h->partials, h->ctrl, h->lineoff,
+                                        h->plane_first_dev, h->seg, s);
+          if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
+          OIC(reduce_to(h, nb, 2, h->hist + H_STRIDE * k + H_RR, true, k + 1));
+          const oi::MgXUpdate xu{chi, p_in, 0, h->hist, k, p_out};
+          nb = oi::mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s, &xu);
+          if (nb < 0) return OI_RCCL_ERROR;
+          OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
+          OIC(wrap_lines(h, h->z));
+          nb = launch_fused_a(g, h->code, chi, h->z, p_in, p_out, 0, h->q, 0, h->hist, k, h->partials, h->ctrl, h->lineoff, h->plane_first_dev,
+                              h->seg, s, 1);
+          if (nb < 0) { oi::set_error("launch grid exceeds the handle's partial-sum capacity (%d blocks)", g.tune.max_blocks); return OI_BAD_ARG; }
+          OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_PQ, false, 0));
+          OIC(wrap_lines(h, h->q));  // (kernel A of the next launch forms r on the image planes from r and q there)
+          continue;
+        }
         if (h->fused) {
           // the flow-through path's fused two-kernel PCG iteration (k_fused_a wraps x / y by index):
           // z = M^-1 r; p_k = z + beta p_{k-1}, q = A p_k, p.q, chi += alpha_{k-1} p_{k-1}; r -= alpha q
@@ -424,8 +535,16 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
       HIPC(hipMemcpyAsync(&seen, h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
       HIPC(hipStreamSynchronize(s));
     }
-    K = seen.done ? seen.done - 1 : issued;
-    if (h->fused && K > 0) {  // the fused iteration applies chi += alpha_k p_k inside iteration k + 1: flush the last one
+    K = seen.done ? seen.done - 1 : (h->rot ? std::max(0, issued - 1) : issued);
+    if (h->rot) {
+      // pairwise update in the post-smoother (oi_tort_cg_finish): after launch m, chi = chi_e with e the largest even number <= m;
+      // stopped at convergence (kernels B and C of launch K returned at once) m = K - 1, else m = K.  What chi still lacks, oldest
+      // term first; p_j lives in buffer j & 1 and neither has been overwritten since
+      double* pbuf[2] = {h->p, h->p2};
+      const int m = seen.done ? K - 1 : K;
+      const int e = m < 0 ? 0 : (m & ~1);
+      for (int j = e; j < K; ++j) launch_axpy_hist(g, chi, pbuf[j & 1], 0, h->hist, j, h->lineoff, s);
+    } else if (h->fused && K > 0) {  // the fused iteration applies chi += alpha_k p_k inside iteration k + 1: flush the last one
       double* pbuf[2] = {h->p, h->p2};
       launch_axpy_hist(g, chi, pbuf[(K - 1) & 1], 0, h->hist, K - 1, nullptr, s);
     }
@@ -491,5 +610,14 @@ extern "C" oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int
     if (iterations3) iterations3[k] = h->iters[k];
     if (relres3) relres3[k] = h->relres[k];
   }
+  return OI_OK;
+}
+
+// which vectors the solves run on: *compacted = 1 when r, q, p, z hold only the 8-voxel lines with an active cell and the solves
+// take the rotated multigrid iteration (whole-tile volumes on one GPU); *vector_elements = doubles per such vector
+extern "C" oi_status oi_effdiff_layout(const oi_effdiff* h, int* compacted, int64_t* vector_elements) {
+  if (!h) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
+  if (compacted) *compacted = h->rot ? 1 : 0;
+  if (vector_elements) *vector_elements = h->nvec_cg;
   return OI_OK;
 }

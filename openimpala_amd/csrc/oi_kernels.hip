@@ -2257,10 +2257,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   const int ilin = in_x ? (i >> kLVs) * 4 : kOob;            // slot table
   const int sub = (i & (kLV - 1)) * 8;                       // this lane's pair inside its line (fp64 bytes)
   // halo lanes: waves 0 and 1 the rows below / above the tile (a voxel pair per lane), wave 2 the columns left / right
-  const int hrow = (wu == 0) ? j0 - 1 : j0 + BY;
+  // (g.periodic, the homogenization cell problem: the halo of the domain's first row / column is its last one and vice versa.  The
+  // host sends a periodic problem here only when nx and ny are whole tiles -- periodic_tiles_ok -- so the wrapped row / column
+  // takes the halo's usual place in the LDS plane; z wraps through the ghost planes, which then hold the images)
+  const bool per = g.periodic != 0;
+  const int hrow = (wu == 0) ? ((per && j0 == 0) ? g.ny - 1 : j0 - 1) : ((per && j0 + BY == g.ny) ? 0 : j0 + BY);
   const bool yhalo = (wu < 2) && in_x && hrow >= 0 && hrow < g.ny;
   const int xh_row = j0 + (lane >> 1);
-  const int xh_i = (lane & 1) ? tx * kBX + kBX : tx * kBX - 1;
+  const int xh_i = (lane & 1) ? ((per && tx * kBX + kBX == g.nx) ? 0 : tx * kBX + kBX) : ((per && tx == 0) ? g.nx - 1 : tx * kBX - 1);
   const bool xhalo = (wu == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
   const int hvox = yhalo ? hrow * g.pitch + i : (xhalo ? xh_row * g.pitch + xh_i : kOob);
   const int hlin = yhalo ? (hrow * LW + (i >> kLVs)) * 4 : (xhalo ? (xh_row * LW + (xh_i >> kLVs)) * 4 : kOob);
@@ -2985,13 +2989,20 @@ int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in
 // whichever kernel and layout runs (tests: ..._layouts_compacted_and_dense, ..._two_solver_paths_agree).
 static void fused_chunks(const Geom& g, long long cols, bool even, int* zchunk, int* nzc) {
   Geom gg = g;
-  if (g.tune.zchunk <= 0 && g.tune.fused_zchunk > 0 && !g.periodic && cols * ((g.nzl + g.tune.fused_zchunk - 1) / g.tune.fused_zchunk) >= 2048)
+  // (a periodic problem on dense vectors keeps the chunks it always had; on compacted vectors -- live_lines is set -- it takes these)
+  if (g.tune.zchunk <= 0 && g.tune.fused_zchunk > 0 && (!g.periodic || g.live_lines > 0.f) &&
+      cols * ((g.nzl + g.tune.fused_zchunk - 1) / g.tune.fused_zchunk) >= 2048)
     gg.tune.zchunk = g.tune.fused_zchunk;
   pick_chunks(gg, cols, even, zchunk, nzc);
 }
+// a periodic problem (g.periodic) on k_cg1b's forms: the planes are whole tiles (the wrapped row / column then sits where the halo
+// always sits), no pad column, whole z pairs
+bool periodic_tiles_ok(const Geom& g) {
+  return !g.periodic || (g.nx % kBX == 0 && g.pitch == g.nx && g.ny % (kNW * 2) == 0 && (g.nzl & 1) == 0 && (g.z0 & 1) == 0);
+}
 // can the descriptor-addressed forms of the two-kernel iteration (k_cg1b FORM 1 / FORM 2) run on this slab?
 bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi) {
-  return lineoff && plane_first && seg && !jacobi && g.tune.fused_kernel == 0 && g.tune.fused_rows == 2 && !g.periodic && 8ll * g.plane < kBufMax;
+  return lineoff && plane_first && seg && !jacobi && g.tune.fused_kernel == 0 && g.tune.fused_rows == 2 && periodic_tiles_ok(g) && 8ll * g.plane < kBufMax;
 }
 // k_cg1b FORM 2: r_out = r_in - alpha_{k-1} q (alpha from hist, 0 for k = 0), partials {r.r, r.r} per block, and the fp32
 // right-hand side of the first coarse level (owned planes) from the pre-smoothed residual.  Needs an even g.z0.  Returns the
@@ -3066,7 +3077,7 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
                    int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
                    const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s, int x_elsewhere) {
   const int R = g.tune.fused_rows;
-  if (R == 2 && !g.periodic) {
+  if (R == 2 && (!g.periodic || fused_descr_ok(g, lineoff, plane_first, seg, jacobi))) {
     const int by = kNW * R;
     const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
     const long long cols = (long long)tiles_x * tiles_y;

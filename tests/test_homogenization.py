@@ -235,3 +235,57 @@ def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, oi_optio
         assert tiled[0][k][0] and plain[0][k][0] and abs(tiled[0][k][1] - plain[0][k][1]) <= 1
         np.testing.assert_allclose(tiled[1][k], plain[1][k], rtol=0, atol=1e-9)
     np.testing.assert_allclose(tiled[2], plain[2], rtol=0, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,pid", [((12, 32, 128), 1), ((20, 16, 256), 0), ((6, 48, 128), 1), ((34, 64, 384), 1)])
+def test_gpu_homogenization_on_compacted_vectors_matches_oracle(sample_phase, shape, pid):
+    """Round 4: volumes whose planes are whole 128 x 16 tiles (nx % 128 == 0, ny % 16 == 0, nz even) on one GPU take the flow-through
+    path's compacted vectors and rotated multigrid iteration (k_cg1b FORM 2 -> coarse levels -> FORM 3 -> FORM 1) with the halo of
+    the first row / column wrapped to the last one inside the kernel and z wrapped through image copies of the line lists.  Same chi
+    and tensor as the oracle; one tile column / one tile row / several of each."""
+    import openimpala_amd as oia
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 4))[:nz, :ny, :nx])
+    want, its = o.effective_diffusivity(sub, pid, eps=1e-10)
+    h = oia.EffectiveDiffusivityMI355(sub, pid, eps=1e-10, precond=oia.PRECOND_MG)
+    compacted, nel = h.layout()
+    assert compacted and nel < (nz + 2) * ny * nx
+    for k in range(3):
+        conv, it, rel = h.solve(k)
+        assert conv and rel <= 1e-10 and it < max(12, its[k] // 2), (k, it, its[k])
+        chi, ok, _, _ = o.effdiff_solve(sub, pid, k, eps=1e-10)
+        np.testing.assert_allclose(h.getChiSolution(k), chi, rtol=0, atol=2e-9)
+    np.testing.assert_allclose(h.tensor(), want, rtol=0, atol=2e-9)
+    h.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 64, 256), (18, 32, 128), (64, 128, 128)])
+def test_gpu_homogenization_compacted_and_dense_vectors_agree(sample_phase, oi_option, shape):
+    """The same volumes on dense vectors with the unrotated iteration (`mg_norot` = 1, what every other shape runs): same iteration
+    counts to within one, chi equal to solver tolerance, and a solve that is repeated on one handle gives the same bits (every
+    buffer of the rotated iteration is re-initialised by solve())."""
+    import openimpala_amd as oia
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 2, 3))[:nz, :ny, :nx])
+
+    def run(expect):
+        h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-11, precond=oia.PRECOND_MG)
+        assert h.layout()[0] == expect
+        res = [h.solve(k) for k in range(3)]
+        chis = [h.getChiSolution(k) for k in range(3)]
+        again = h.solve(1)
+        assert again == res[1] and np.array_equal(h.getChiSolution(1), chis[1])
+        out = res, chis, h.tensor().copy()
+        h.destroy()
+        return out
+
+    lines = run(True)
+    oi_option("mg_norot", 1)
+    dense = run(False)
+    for k in range(3):
+        assert lines[0][k][0] and dense[0][k][0] and abs(lines[0][k][1] - dense[0][k][1]) <= 1
+        np.testing.assert_allclose(lines[1][k], dense[1][k], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(lines[2], dense[2], rtol=0, atol=1e-10)
+
