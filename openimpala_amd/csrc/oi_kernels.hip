@@ -2257,14 +2257,18 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   const int ilin = in_x ? (i >> kLVs) * 4 : kOob;            // slot table
   const int sub = (i & (kLV - 1)) * 8;                       // this lane's pair inside its line (fp64 bytes)
   // halo lanes: waves 0 and 1 the rows below / above the tile (a voxel pair per lane), wave 2 the columns left / right
-  // (g.periodic, the homogenization cell problem: the halo of the domain's first row / column is its last one and vice versa.  The
-  // host sends a periodic problem here only when nx and ny are whole tiles -- periodic_tiles_ok -- so the wrapped row / column
-  // takes the halo's usual place in the LDS plane; z wraps through the ghost planes, which then hold the images)
-  const bool per = g.periodic != 0;
-  const int hrow = (wu == 0) ? ((per && j0 == 0) ? g.ny - 1 : j0 - 1) : ((per && j0 + BY == g.ny) ? 0 : j0 + BY);
+  // VAR & 8: a PERIODIC problem (the homogenization cell problems, Geom::periodic; its own instantiations, nothing of it in the
+  // others).  The halo of the domain's first row / column is its last one and vice versa; where the domain ends INSIDE a tile
+  // the wrapped row / column is staged right behind the last one (hlds / xcol), in the slot of the first row / pair outside the
+  // domain, which stage_rows then leaves alone (k_fused_a does the same); z wraps through the ghost planes, which hold the images
+  constexpr bool per = (VAR & 8) != 0;
+  const bool ywrap_hi = per && j0 + BY >= g.ny, xwrap_hi = per && tx * kBX + kBX >= g.nx;
+  const int hrow = (wu == 0) ? ((per && j0 == 0) ? g.ny - 1 : j0 - 1) : (ywrap_hi ? 0 : j0 + BY);
+  const int hlds = (wu == 0) ? 0 : (ywrap_hi ? g.ny - j0 + 1 : BY + 1);   // LDS row of this wave's halo row (scalar)
+  const int xcol = xwrap_hi ? 2 + g.nx - tx * kBX : 2 + kBX;               // LDS column of the right halo column (scalar)
   const bool yhalo = (wu < 2) && in_x && hrow >= 0 && hrow < g.ny;
   const int xh_row = j0 + (lane >> 1);
-  const int xh_i = (lane & 1) ? ((per && tx * kBX + kBX == g.nx) ? 0 : tx * kBX + kBX) : ((per && tx == 0) ? g.nx - 1 : tx * kBX - 1);
+  const int xh_i = (lane & 1) ? (xwrap_hi ? 0 : tx * kBX + kBX) : ((per && tx == 0) ? g.nx - 1 : tx * kBX - 1);
   const bool xhalo = (wu == 2) && lane < 2 * BY && xh_row < g.ny && xh_i >= 0 && xh_i < g.pitch;
   const int hvox = yhalo ? hrow * g.pitch + i : (xhalo ? xh_row * g.pitch + xh_i : kOob);
   const int hlin = yhalo ? (hrow * LW + (i >> kLVs)) * 4 : (xhalo ? (xh_row * LW + (xh_i >> kLVs)) * 4 : kOob);
@@ -2550,8 +2554,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   };
   auto stage_rows = [&](double* T, const double2 (&pn)[R]) {
 #pragma unroll
-    for (int rr_ = 0; rr_ < R; ++rr_)
+    for (int rr_ = 0; rr_ < R; ++rr_) {
+      if (per && (i == g.nx || row_of(rr_) == g.ny)) continue;  // (that slot holds the wrapped column / row)
       *reinterpret_cast<double2*>(&T[(wu + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+    }
   };
   auto stage_halo = [&](double* T, const HRaw& hr) {
     // (the LDS addresses of the halo are formed from an opaque copy of the lane index: hoisted out of the loop they were
@@ -2580,7 +2586,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           h.x = PIo<PT>::rnd(z0 + beta * hp.x); h.y = PIo<PT>::rnd(z1 + beta * hp.y);
         }
       }
-      *reinterpret_cast<double2*>(&T[((wu == 0) ? 0 : BY + 1) * kLP + 2 + 2 * lane]) = h;
+      *reinterpret_cast<double2*>(&T[(per ? hlds : ((wu == 0) ? 0 : BY + 1)) * kLP + 2 + 2 * lane]) = h;
     } else if (wu == 2 && lane < 2 * BY) {
       double h = 0.0;
       if (hcode) {
@@ -2590,7 +2596,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         else if (FORM == 3) { h = z * wtab[hcode]; h += scale * (double)hr.c; }
         else h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
       }
-      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? 2 + kBX : 1)] = h;
+      T[((lane >> 1) + 1) * kLP + ((lane & 1) ? (per ? xcol : 2 + kBX) : 1)] = h;
     }
   };
 
@@ -2995,10 +3001,10 @@ static void fused_chunks(const Geom& g, long long cols, bool even, int* zchunk, 
     gg.tune.zchunk = g.tune.fused_zchunk;
   pick_chunks(gg, cols, even, zchunk, nzc);
 }
-// a periodic problem (g.periodic) on k_cg1b's forms: the planes are whole tiles (the wrapped row / column then sits where the halo
-// always sits), no pad column, whole z pairs
+// a periodic problem (g.periodic) on k_cg1b's forms (their VAR & 8 instantiations): even extents -- no pad column, no voxel pair,
+// row pair or plane pair that straddles the seam
 bool periodic_tiles_ok(const Geom& g) {
-  return !g.periodic || (g.nx % kBX == 0 && g.pitch == g.nx && g.ny % (kNW * 2) == 0 && (g.nzl & 1) == 0 && (g.z0 & 1) == 0);
+  return !g.periodic || ((g.nx & 1) == 0 && g.pitch == g.nx && (g.ny & 1) == 0 && (g.nzl & 1) == 0 && (g.z0 & 1) == 0);
 }
 // can the descriptor-addressed forms of the two-kernel iteration (k_cg1b FORM 1 / FORM 2) run on this slab?
 bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi) {
@@ -3028,6 +3034,13 @@ int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in,
     case 5: OI_F2(2, 0); return blocks;  case 6: OI_F2(3, 0); return blocks;  case 7: OI_F2(1, 0); return blocks;  default: OI_F2(0, 0); return blocks;
   }
 #endif
+  if (g.periodic) {  // (the cell problems of the homogenization path: the form's periodic instantiation, oi_effdiff.hip)
+    hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 2, kNtSt2, kNtLd2, 8>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r_in, r_out, q,
+                       (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk, tiles_x, tiles_y, nzc,
+                       0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg, (g.pitch + kLV - 1) / kLV, 1, bcoarse, c,
+                       omega, 0.0);
+    return blocks;
+  }
   if (g.tune.cg1_nt) OI_F2(kNtLd2, kNtSt2); else OI_F2(0, 0);
 #undef OI_F2
   return blocks;
@@ -3066,6 +3079,19 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
 #endif
   // (does this launch touch x?  The kernel's own rule, evaluated here: an instantiation without the x path otherwise)
   const bool touches_x = x != nullptr && (p_prev2 ? (k >= 2 && (k & 1) == 0) : k > 0);
+  if (g.periodic) {  // (periodic instantiations: fp64 p, the shipped cache policy)
+    if (!touches_x)
+      hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 3, kNtSt3, kNtLd3, 8, true>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, b, z,
+                         (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr, const_cast<double*>(hist), k, 0, zchunk,
+                         tiles_x, tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,
+                         (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, c, omega, scale);
+    else
+      hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 3, kNtSt3, kNtLd3, 8>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, x, b, z, (const double*)nullptr,
+                         (double*)nullptr, (const double*)p_prev, (double*)const_cast<void*>(p_prev2), const_cast<double*>(hist), k, (x && p_prev2) ? 1 : 0, zchunk,
+                         tiles_x, tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,
+                         (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, c, omega, scale);
+    return blocks;
+  }
   if (!touches_x) { if (g.tune.cg1_nt) OI_F3N(kNtLd3, kNtSt3); else OI_F3N(0, 0); }
   else if (g.tune.cg1_nt) { if (p_f32) OI_F3(float, kNtLd3, kNtSt3); else OI_F3(double, kNtLd3, kNtSt3); }
   else { if (p_f32) OI_F3(float, 0, 0); else OI_F3(double, 0, 0); }
@@ -3077,7 +3103,10 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
                    int p_f32, double* q, int jacobi, const double* hist, int k, double* partials, const Ctrl* ctrl,
                    const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s, int x_elsewhere) {
   const int R = g.tune.fused_rows;
-  if (R == 2 && (!g.periodic || fused_descr_ok(g, lineoff, plane_first, seg, jacobi))) {
+  // (a periodic problem takes the descriptor-addressed form -- its periodic instantiation -- with fp64 p and the x update in the
+  // post-smoother, what oi_effdiff.hip runs; anything else periodic stays on k_fused_a)
+  const bool per_descr = g.periodic && !p_f32 && x_elsewhere && fused_descr_ok(g, lineoff, plane_first, seg, jacobi);
+  if (R == 2 && (!g.periodic || per_descr)) {
     const int by = kNW * R;
     const int tiles_x = (g.pitch + kBX - 1) / kBX, tiles_y = (g.ny + by - 1) / by;
     const long long cols = (long long)tiles_x * tiles_y;
@@ -3104,6 +3133,13 @@ int launch_fused_a(const Geom& g, const uint8_t* code, double* x, const double* 
         case 7: OI_FB(double, 4, 4); return blocks;  default: OI_FB(double, 0, 0); return blocks;
       }
 #endif
+      if (g.periodic) {  // (periodic instantiation: fp64 p, x updated by the post-smoother -- what oi_effdiff.hip runs)
+        hipLaunchKernelGGL((k_cg1b<2, kNW, double, false, true, 1, kNtSt1, kNtLd1, 8, true>), dim3(blocks), dim3(64 * kNW), 0, s, g, code, (double*)nullptr, r,
+                           (double*)nullptr, (const double*)nullptr, q, (const double*)p_in, (double*)p_out, const_cast<double*>(hist), k, -1, zchunk, tiles_x,
+                           tiles_y, nzc, 0, 0, partials, const_cast<Ctrl*>(ctrl), lineoff, plane_first, (const uint2*)seg,
+                           (g.pitch + kLV - 1) / kLV, 1, (float*)nullptr, MgCoarse{}, 0.0, 0.0);
+        return blocks;
+      }
       if (x_elsewhere) {  // (the post-smoother of this iteration has taken the x update: the instantiation without the x path)
         if (g.tune.cg1_nt) { if (p_f32) OI_FBN(float, kNtLd1, kNtSt1); else OI_FBN(double, kNtLd1, kNtSt1); }
         else { if (p_f32) OI_FBN(float, 0, 0); else OI_FBN(double, 0, 0); }
