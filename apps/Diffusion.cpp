@@ -207,23 +207,35 @@ int main(int argc, char* argv[]) {
       oi_tort_opts o = hopts;
       o.verbose = vb;
       oi_effdiff* eh = nullptr;
+      const auto t_obj = std::chrono::steady_clock::now();
       oi_status est = oi_effdiff_create(&eh, ph, nx, ny, nz, phase_id, &o);
       if (est != OI_OK) throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error());
+      if (vb >= 1) {
+        int compacted = 0;
+        int64_t nel = 0;
+        (void)oi_effdiff_layout(eh, &compacted, &nel);
+        std::cout << "  [wall] solver object (upload, codes, hierarchy): " << since(t_obj) << " s; CG vectors of " << nel << " doubles ("
+                  << (compacted ? "lines with an active cell only" : "dense") << ")\n";
+      }
       bool ok = true;
       for (int k = 0; k < 3 && ok; ++k) {
         if (vb >= 1) std::cout << "\n--- Solving for " << what << " chi_" << axis_names[k] << " ---\n";
         int conv = 0, iters = 0;
         double rel = 0.0;
+        const auto t_solve = std::chrono::steady_clock::now();
         est = oi_effdiff_solve(eh, k, &conv, &iters, &rel);
         if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
         if (vb >= 1)
           std::cout << "  Solver iterations: " << iters << "\n  Final Relative Residual Norm: " << std::scientific << rel
-                    << std::defaultfloat << "\n  Solver Converged Status: " << (conv ? "Yes" : "No") << "\n";
+                    << std::defaultfloat << "\n  Solver Converged Status: " << (conv ? "Yes" : "No") << "\n  [wall] solve: " << since(t_solve)
+                    << " s\n";
         if (!conv) ok = false;
       }
       if (ok) {
+        const auto t_ten = std::chrono::steady_clock::now();
         est = oi_effdiff_tensor(eh, D);
         if (est != OI_OK) { oi_effdiff_destroy(eh); throw std::runtime_error(std::string(oi_status_string(est)) + ": " + oi_last_error()); }
+        if (vb >= 1) std::cout << "  [wall] tensor: " << since(t_ten) << " s\n";
       }
       oi_effdiff_destroy(eh);
       return ok;
