@@ -2374,7 +2374,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   struct HRaw { double2 r, q; PPair p; typename PBuf<PT>::One p1; float c; };
   // FORM 3: the fp32 coarse correction of the aggregate that holds a voxel pair (x pairs share it: i is even); the offset inside
   // the coarse plane does not change along the march, the plane comes with the descriptor
-  auto cplane_of = [&](int gz) { return ((g.z0 + gz - 1) >> 1) - C.z0c + 1; };
+  // (periodic instantiations: the planes beyond the two ends are images whose parents sit in the coarse GHOST planes; an odd nz does
+  // not give that by the arithmetic -- k_mg_fine's rule)
+  auto cplane_of = [&](int gz) {
+    const int kg = g.z0 + gz - 1;
+    if ((VAR & 8) && kg >= g.nz) return C.cnzl + 1;
+    if ((VAR & 8) && kg < 0) return 0;
+    return (kg >> 1) - C.z0c + 1;
+  };
   auto corr_buf = [&](const float* a, int gz) { return buf_of(a + C.csz * cplane_of(gz), 4ll * C.csz); };
   auto corr_ld = [&](int gz, int off) {
     float cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(corr_buf(C.xc, gz), off, 0, 0));
@@ -3001,10 +3008,10 @@ static void fused_chunks(const Geom& g, long long cols, bool even, int* zchunk, 
     gg.tune.zchunk = g.tune.fused_zchunk;
   pick_chunks(gg, cols, even, zchunk, nzc);
 }
-// a periodic problem (g.periodic) on k_cg1b's forms (their VAR & 8 instantiations): even extents -- no pad column, no voxel pair,
-// row pair or plane pair that straddles the seam
+// a periodic problem (g.periodic) on k_cg1b's forms (their VAR & 8 instantiations): an even nx -- no pad column, no voxel pair that
+// straddles the seam -- and an even first plane; an odd ny or nz leaves a single row / plane in the last aggregates as in the open problem
 bool periodic_tiles_ok(const Geom& g) {
-  return !g.periodic || ((g.nx & 1) == 0 && g.pitch == g.nx && (g.ny & 1) == 0 && (g.nzl & 1) == 0 && (g.z0 & 1) == 0);
+  return !g.periodic || ((g.nx & 1) == 0 && g.pitch == g.nx && (g.z0 & 1) == 0);
 }
 // can the descriptor-addressed forms of the two-kernel iteration (k_cg1b FORM 1 / FORM 2) run on this slab?
 bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi) {
