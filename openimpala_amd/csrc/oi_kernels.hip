@@ -2160,6 +2160,16 @@ template <> struct PBuf<float> {
 // policy: they are what the L2 is for).  Chosen per form by in-process A/B on one handle (tools/pol_ab.py, profiles/r04/
 // k_cg1b_cache_policies_*.txt): r, p and x written nontemporally and x, p_{k-2} read nontemporally take 7.6 % off FORM 0, while
 // nontemporal loads of r, q, p (re-read by the neighbouring tiles' halos) cost 10 %.
+// a / c for a neighbour count c = 1 .. 6 without the division instruction sequence: yc = {RN(1 / c), c};
+// q = RN(a y), r = a - c q (exact in one fma: q is a faithful quotient, |1/c - y| <= 2^-54 / c for these six divisors), q' = RN(q + r y)
+// is the CORRECTLY ROUNDED quotient (Markstein) -- the bits of a / c, in three instructions instead of about fourteen.  Checked
+// against the division for 2.5e9 operands per divisor set (random and mantissa edge patterns); the Jacobi-preconditioned
+// single-kernel iteration divides four times per voxel and was instruction-bound on it (config 5's share).
+__device__ __forceinline__ double div_small(double a, double2 yc) {
+  const double q = a * yc.x;
+  const double r = __builtin_fma(-yc.y, q, a);
+  return __builtin_fma(r, yc.x, q);
+}
 constexpr int kNtSt0 = 13, kNtLd0 = 24;
 // (the light forms are instruction-bound and gain less: FORM 1 p_out 1.9 %, FORM 2 r_out 0.7 %, FORM 3 x written and x, p_{k-1} read 1.4 %
 // of the cycle; q_out / z nontemporal is a loss everywhere: the next kernel of the same iteration reads it first)
@@ -2196,9 +2206,14 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
   // FORM 2: y-pair sums of the restriction (odd waves publish, even waves own the aggregates), omega / c for c = 0..6
   __shared__ double ysum[FORM == 2 ? 2 : 1][FORM == 2 ? R * (NW / 2) * 64 : 1];
   __shared__ double wtab[8];
+  __shared__ double2 jtab[JACOBI ? 8 : 1];  // {1 / c, c} for div_small
   if (FORM >= 2) {
     static_assert(FORM != 2 || (NW & 1) == 0, "rows 2m and 2m+1 of a tile belong to waves w and w+1");
     if (threadIdx.x < 8) wtab[threadIdx.x] = threadIdx.x ? omega / (double)threadIdx.x : 0.0;
+    __syncthreads();
+  }
+  if (JACOBI) {
+    if (threadIdx.x < 8) jtab[threadIdx.x] = threadIdx.x ? make_double2(1.0 / (double)threadIdx.x, (double)threadIdx.x) : make_double2(0.0, 0.0);
     __syncthreads();
   }
 
@@ -2487,8 +2502,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       double z0 = r0, z1 = r1;
       if (JACOBI) {
         const unsigned short cc = cn[rr_];
-        if (cc & 0xff) z0 = r0 / (double)(cc & 0xff);
-        if (cc >> 8) z1 = r1 / (double)(cc >> 8);
+        if (cc & 0xff) z0 = div_small(r0, jtab[cc & 0xff]);
+        if (cc >> 8) z1 = div_small(r1, jtab[cc >> 8]);
       }
       pn[rr_] = make_double2(PIo<PT>::rnd(z0 + beta * pin.x), PIo<PT>::rnd(z1 + beta * pin.y));
       if (mode != 0) {
@@ -2585,8 +2600,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
           if (hcode >> 8) h.y = z1 * wtab[hcode >> 8] + cr;
         }
         if (JACOBI) {
-          if (hcode & 0xff) z0 = z0 / (double)(hcode & 0xff);
-          if (hcode >> 8) z1 = z1 / (double)(hcode >> 8);
+          if (hcode & 0xff) z0 = div_small(z0, jtab[hcode & 0xff]);
+          if (hcode >> 8) z1 = div_small(z1, jtab[hcode >> 8]);
         }
         if (FORM < 2) {
           const double2 hp = PBuf<PT>::wide(hr.p);
@@ -2598,7 +2613,7 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
       double h = 0.0;
       if (hcode) {
         double z = (FORM == 0 || FORM == 2) ? hr.r.x - alpha_prev * hr.q.x : hr.r.x;
-        if (JACOBI) z = z / (double)hcode;
+        if (JACOBI) z = div_small(z, jtab[hcode & 7]);
         if (FORM == 2) h = z * wtab[hcode];
         else if (FORM == 3) { h = z * wtab[hcode]; h += scale * (double)hr.c; }
         else h = PIo<PT>::rnd(z + beta * PBuf<PT>::wide1(hr.p1));
@@ -2730,8 +2745,8 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
         bst2<(STAUX & 2) ? 2 : 0>(qob, qoff, q0, q1);
         double z0 = rc.x, z1 = rc.y, d0 = q0, d1 = q1;
         if (JACOBI) {
-          if (c0) { z0 = rc.x / (double)c0; d0 = q0 / (double)c0; }
-          if (c1) { z1 = rc.y / (double)c1; d1 = q1 / (double)c1; }
+          if (c0) { const double2 yc = jtab[c0]; z0 = div_small(rc.x, yc); d0 = div_small(q0, yc); }
+          if (c1) { const double2 yc = jtab[c1]; z1 = div_small(rc.y, yc); d1 = div_small(q1, yc); }
         }
         s_pq += pc.x * q0; s_pq += pc.y * q1;
         if (FORM == 0) {
