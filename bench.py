@@ -566,6 +566,7 @@ def main():
             hs.append(time.perf_counter())
         D = eh.tensor()
         h1 = time.perf_counter()
+        lay = eh.layout()
         eh.destroy()
         del ph
         # (GPUTEST_r02 showed 3.7 s here against 1.25 s in every run of the builder: the split says where such a run spends it
@@ -575,6 +576,8 @@ def main():
                  "seconds_split": {"create_incl_pageable_upload": hc - h0, "solve_x": hs[0] - hc, "solve_y": hs[1] - hs[0],
                                    "solve_z": hs[2] - hs[1], "tensor": h1 - hs[2]},
                  "device_free_GB_before": free_before / 1e9,
+                 # (round 4: even nx on one GPU -> the flow-through path's compacted vectors and rotated multigrid iteration)
+                 "vectors": {"compacted_lines": bool(lay[0]), "GB_per_vector": lay[1] * 8 / 1e9},
                  "iterations": [r[1] for r in res], "converged": [bool(r[0]) for r in res],
                  "D_diag": [float(D[i, i]) for i in range(3)]}
 
