@@ -198,7 +198,7 @@ struct MgCoarse {
 };
 // the two-kernel iteration on compacted vectors, descriptor-addressed forms (k_cg1b FORM 1 / 2): may they run on this slab?
 bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi);
-// a periodic problem (Geom::periodic) may take those forms (their periodic instantiations) when nx is even
+// a periodic problem (Geom::periodic) may take those forms (their periodic instantiations) on a slab with an even first plane
 bool periodic_tiles_ok(const Geom& g);
 // residual update + fine pre-smoother + restriction in one pass (k_cg1b FORM 2); see oi_kernels.hip
 int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in, double* r_out, const double* q, const double* hist, int k,

@@ -217,7 +217,7 @@ struct oi_effdiff {
   double* z = nullptr;              // preconditioned residual (OI_PRECOND_MG)
   double* p2 = nullptr;             // second search-direction buffer of the fused two-kernel iteration
   bool fused = false;               // multigrid PCG on the tiled kernels of the flow-through path (even extents)
-  // round 4: volumes with an even nx on one GPU take the flow-through path's COMPACTED vectors (r, q, p, z: only the 8-voxel lines
+  // round 4: on one GPU the multigrid-preconditioned solves take the flow-through path's COMPACTED vectors (r, q, p, z: only the 8-voxel lines
   // that hold an active cell) and its rotated multigrid iteration on k_cg1b's forms (oi_tort.cpp: cg_one_iteration, h->rot)
   bool rot = false;
   int* lineoff = nullptr;
@@ -352,7 +352,7 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   const bool want_mg = (o.precond == OI_PRECOND_MG || o.precond == OI_PRECOND_DEFAULT) && h->n_active > 0 && nx >= 4 && ny >= 4 && nz >= 4;
   h->nvec_cg = g.nvec;
   // Compacted vectors + the rotated iteration of the flow-through path (k_cg1b FORM 2 -> coarse levels, FORM 3 -> FORM 1, their
-  // periodic instantiations): one GPU, even nx (no voxel pair straddles the seam)
+  // periodic instantiations): one GPU, any extents
   if (want_mg && !h->comm && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g)) {
     const int LW = (g.pitch + kLV - 1) / kLV;
     const long long nlines = (long long)(nzl + 2) * ny * LW;
@@ -434,12 +434,12 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
     return OI_OK;
   }
   HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * (h->maxiter + 2), s));
-  // (rotated iteration: r is written whole by k_ed_rhs_lines + its images, r2 and p by launch 0 before anything reads them; what
-  // launch 0 READS beside r -- q_{-1} and p_{-1}, multiplied by alpha = beta = 0 -- must be finite, so those two are cleared)
-  if (!h->rot) {
-    HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * h->nvec_cg, s));
-    HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * h->nvec_cg, s));
-  }
+  // (rotated iteration: r2 and p are written whole by launch 0 before anything reads them -- checked with both filled with NaNs
+  // before 450 solves of 150 shapes, tools/homog_oddnx_probe.py; r is cleared because k_ed_rhs_lines leaves the pad voxel of an odd
+  // nx alone -- garbage there enters ||r||^2 --, and what launch 0 READS beside r -- q_{-1} and p_{-1}, multiplied by alpha = beta = 0
+  // -- must be finite)
+  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * h->nvec_cg, s));
+  if (!h->rot) HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * h->nvec_cg, s));
   if (h->p2) HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
   HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * h->nvec_cg, s));
   HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));
@@ -614,7 +614,7 @@ extern "C" oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int
 }
 
 // which vectors the solves run on: *compacted = 1 when r, q, p, z hold only the 8-voxel lines with an active cell and the solves
-// take the rotated multigrid iteration (even nx, one GPU, multigrid preconditioner); *vector_elements = doubles per such vector
+// take the rotated multigrid iteration (one GPU, multigrid preconditioner); *vector_elements = doubles per such vector
 extern "C" oi_status oi_effdiff_layout(const oi_effdiff* h, int* compacted, int64_t* vector_elements) {
   if (!h) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (compacted) *compacted = h->rot ? 1 : 0;

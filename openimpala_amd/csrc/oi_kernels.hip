@@ -2578,7 +2578,10 @@ __global__ void __launch_bounds__(64 * NW, (R <= 2 ? 4 : 2)) k_cg1b(Geom g, cons
 #pragma unroll
     for (int rr_ = 0; rr_ < R; ++rr_) {
       if (per && (i == g.nx || row_of(rr_) == g.ny)) continue;  // (that slot holds the wrapped column / row)
-      *reinterpret_cast<double2*>(&T[(wu + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
+      // odd nx, periodic: the pair (nx - 1, pad) straddles the seam -- its second slot holds the wrapped column 0 (wave 2), which the
+      // stencil then reads as this pair's second value: the +x neighbour of voxel nx - 1 (the pad voxel itself has code 0)
+      if (per && i + 1 == g.nx) T[(wu + rr_ * NW + 1) * kLP + 2 + 2 * lane] = pn[rr_].x;
+      else *reinterpret_cast<double2*>(&T[(wu + rr_ * NW + 1) * kLP + 2 + 2 * lane]) = pn[rr_];
     }
   };
   auto stage_halo = [&](double* T, const HRaw& hr) {
@@ -3023,10 +3026,10 @@ static void fused_chunks(const Geom& g, long long cols, bool even, int* zchunk, 
     gg.tune.zchunk = g.tune.fused_zchunk;
   pick_chunks(gg, cols, even, zchunk, nzc);
 }
-// a periodic problem (g.periodic) on k_cg1b's forms (their VAR & 8 instantiations): an even nx -- no pad column, no voxel pair that
-// straddles the seam -- and an even first plane; an odd ny or nz leaves a single row / plane in the last aggregates as in the open problem
+// a periodic problem (g.periodic) on k_cg1b's forms (their VAR & 8 instantiations): an even first plane; an odd nx, ny or nz leaves a
+// single column / row / plane in the last aggregates as in the open problem
 bool periodic_tiles_ok(const Geom& g) {
-  return !g.periodic || ((g.nx & 1) == 0 && g.pitch == g.nx && (g.z0 & 1) == 0);
+  return !g.periodic || (g.z0 & 1) == 0;
 }
 // can the descriptor-addressed forms of the two-kernel iteration (k_cg1b FORM 1 / FORM 2) run on this slab?
 bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi) {

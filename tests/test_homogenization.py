@@ -136,10 +136,10 @@ def test_gpu_homogenization_multigrid(sample_phase, shape, pid):
     sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 2))[:nz, :ny, :nx])
     want, its = o.effective_diffusivity(sub, pid, eps=1e-10)
     h = oia.EffectiveDiffusivityMI355(sub, pid, eps=1e-10, precond=oia.PRECOND_MG)
-    # (round 4: an even nx runs on compacted vectors with the rotated iteration -- the wrapped row / column staged inside a tile for
-    # 36, 40, 18, 31 and 19 rows, 44, 300, 130, 36 and 132 columns; odd ny / nz: (25, 31, 36), (17, 40, 132), (40, 19, 44) -- an odd nx on
-    # dense vectors)
-    assert h.layout()[0] == (nx % 2 == 0)
+    # (round 4: all of them run on compacted vectors with the rotated iteration -- the wrapped row / column staged inside a tile for
+    # 36, 40, 18, 31 and 19 rows, 44, 300, 130, 36, 132 and 33 columns; odd ny / nz: (25, 31, 36), (17, 40, 132), (40, 19, 44); odd nx,
+    # the pair (nx - 1, pad) with the wrapped column 0 in its second LDS slot: (25, 31, 33))
+    assert h.layout()[0]
     for k in range(3):
         conv, it, rel = h.solve(k)
         assert conv and rel <= 1e-10 and it < max(12, its[k] // 2), (k, it, its[k])
@@ -243,14 +243,15 @@ def test_gpu_homogenization_tiled_and_plain_kernels_agree(sample_phase, oi_optio
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,pid", [((12, 32, 128), 1), ((20, 16, 256), 0), ((6, 48, 128), 1), ((34, 64, 384), 1), ((10, 30, 136), 1),
-                                       ((8, 34, 120), 0), ((4, 4, 8), 1), ((22, 50, 260), 1), ((9, 33, 128), 1), ((33, 17, 24), 0)])
+                                       ((8, 34, 120), 0), ((4, 4, 8), 1), ((22, 50, 260), 1), ((9, 33, 128), 1), ((33, 17, 24), 0), ((12, 20, 129), 1), ((10, 16, 127), 0), ((7, 9, 11), 1)])
 def test_gpu_homogenization_on_compacted_vectors_matches_oracle(sample_phase, shape, pid):
-    """Round 4: volumes with an even nx on one GPU take the flow-through path's compacted vectors and rotated multigrid iteration
+    """Round 4: on one GPU the multigrid-preconditioned cell problems take the flow-through path's compacted vectors and rotated multigrid iteration
     (k_cg1b FORM 2 -> coarse levels -> FORM 3 -> FORM 1, their periodic instantiations) with the halo of the first row / column
     wrapped to the last one inside the kernel and z wrapped through image copies of the line lists.  Same chi and tensor as the
     oracle: planes of whole 128 x 16 tiles (one tile column / one tile row / several of each), the domain ending inside a tile (one
     line / two rows past a tile boundary: 136, 34; short of it: 120, 30; 260 x 50), a volume smaller than a tile, odd ny and nz (a single
-    row / plane in the last aggregates, the image planes' parents in the coarse ghost planes)."""
+    row / plane in the last aggregates, the image planes' parents in the coarse ghost planes), odd nx one voxel past / before a tile
+    boundary (the voxel pair that straddles the seam)."""
     import openimpala_amd as oia
     nz, ny, nx = shape
     sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 4))[:nz, :ny, :nx])
