@@ -457,6 +457,153 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
   *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- round 4 (late): the correction + post-smoothing step of a big byte / 16-bit level through an LDS TILE ----
+// k_mg_post4 forms the corrected iterate x2 = w b / D + s e (e = the parent's correction) of its four cells AND of their eighteen
+// face neighbours from global memory (b, D and e of every neighbour: ~27 load instructions per four cells, cache hits, and the
+// kernel is bound by them: 0.65 ms on the 512^3 level of a 1024^3 solve against 0.3 ms for its bytes).  Here a block of 512 threads
+// owns a tile of 64 x 8 x 8 cells: x2 of the tile and of its six faces goes to LDS once (1.53 evaluations per cell instead of
+// 5.5), the stencil reads its neighbours there.  Same arithmetic in the same order: bit-identical to k_mg_post4 (option
+// mg_coarse_tiled = 0 keeps that kernel as the cross-check).  Out-of-domain positions hold zeros -- the value k_mg_post4 uses
+// there; a periodic level finds the wrapped row / quad / column there, the image planes in the ghost planes as ever.
+constexpr int kTX = 64, kTY = 8, kTZ = 8;       // cells of a tile
+constexpr int kTRP = kTX + 8;                    // LDS row pitch in floats: [3 pad | left halo | 64 cells | right halo | 3 pad]
+constexpr int kTPP = (kTY + 2) * kTRP;           // LDS plane pitch
+template <class W, class D>
+__global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* __restrict__ b, const float* __restrict__ xc,
+                                                    const float* __restrict__ xc2, Dims C, float scale, const float* __restrict__ xpre,
+                                                    float* __restrict__ out, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float T[(kTZ + 2) * kTPP];
+  int t_ = blockIdx.x;
+  if ((gridDim.x & 7) == 0) t_ = (t_ & 7) * (gridDim.x >> 3) + (t_ >> 3);  // (every XCD a contiguous z range of tiles)
+  const int bx = t_ % tiles_x, by = (t_ / tiles_x) % tiles_y, bz = t_ / (tiles_x * tiles_y);
+  const int i0 = bx * kTX, j0 = by * kTY, k0 = 1 + bz * kTZ;  // first cell of the tile (k: local plane, ghosts 0 and nzl + 1)
+  const long long sy = L.nx, sz = L.sz;
+  const bool per = L.periodic != 0;
+  auto x21 = [&](float bb, float dd, float cc) -> float { return dd > 0.f ? L.omega * bb * rcp(dd) + scale * cc : 0.f; };
+  auto x21p = [&](float xp, float dd, float cc) -> float { return dd > 0.f ? xp + scale * cc : 0.f; };
+  // where a position of the tile or of its faces lives: the wrapped index of a periodic level one step beyond an end, -1 = nowhere
+  auto row_of = [&](int jj) { return (jj >= 0 && jj < L.ny) ? jj : (per && jj == -1 ? L.ny - 1 : (per && jj == L.ny ? 0 : -1)); };
+  auto col_of = [&](int ii) { return (ii >= 0 && ii < L.nx) ? ii : (per && ii == -1 ? L.nx - 1 : (per && ii == L.nx ? 0 : -1)); };
+  // x2 of the four cells ii .. ii + 3 of row jj in plane kk (all inside the arrays)
+  auto x24 = [&](int ii, int jj, int kk, float (&o)[4]) {
+    const long long mm = (long long)ii + sy * jj + sz * kk;
+    float bb[4], dd[4];
+    ld4(L.diag + mm, dd);
+    if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    ld4((xpre ? xpre : b) + mm, bb);
+    const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
+    float2 p = *reinterpret_cast<const float2*>(xc + cm);
+    if (xc2) { const float2 q = *reinterpret_cast<const float2*>(xc2 + cm); p.x += q.x; p.y += q.y; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = xpre ? x21p(bb[c], dd[c], c < 2 ? p.x : p.y) : x21(bb[c], dd[c], c < 2 ? p.x : p.y);
+  };
+  auto x2one = [&](int ii, int jj, int kk) -> float {
+    const long long mm = (long long)ii + sy * jj + sz * kk;
+    const float dd = (float)L.diag[mm];
+    if (!(dd > 0.f)) return 0.f;
+    const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
+    float c = xc[cm];
+    if (xc2) c += xc2[cm];
+    return xpre ? x21p(xpre[mm], dd, c) : x21(b[mm], dd, c);
+  };
+  const int tid = threadIdx.x;
+  const int tq = tid & 15, ty = (tid >> 4) & 7, tz = tid >> 7;  // own quads: (tq, ty, tz) and (tq, ty, tz + 4)
+  auto lds_at = [&](int lq, int ly, int lz) { return (lz + 1) * kTPP + (ly + 1) * kTRP + 4 + 4 * lq; };  // quad lq of tile row ly, plane lz
+  // ---- own quads: x2 to registers and LDS (a position outside the level: zeros, or what a periodic level wraps there) ----
+  float dc[2][4], bc[2][4], cc[2][4];
+  bool mine[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int lz = tz + 4 * u;
+    const int ii = i0 + 4 * tq, jj = j0 + ty, kk = k0 + lz;
+    mine[u] = ii < L.nx && jj < L.ny && kk <= L.nzl;
+    const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);  // (a quad starts inside the level or exactly at its end)
+    cc[u][0] = cc[u][1] = cc[u][2] = cc[u][3] = 0.f;
+    dc[u][0] = dc[u][1] = dc[u][2] = dc[u][3] = 0.f;
+    if (iw >= 0 && jw >= 0 && kk <= L.nzl + 1) {
+      if (mine[u]) {
+        const long long m = (long long)ii + sy * jj + sz * kk;
+        ld4(L.diag + m, dc[u]);
+        if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
+          ld4(b + m, bc[u]);
+          float xs[4];
+          if (xpre) ld4(xpre + m, xs);
+          const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
+          float2 p = *reinterpret_cast<const float2*>(xc + cm);
+          if (xc2) { const float2 q = *reinterpret_cast<const float2*>(xc2 + cm); p.x += q.x; p.y += q.y; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            cc[u][c] = xpre ? x21p(xs[c], dc[u][c], c < 2 ? p.x : p.y) : x21(bc[u][c], dc[u][c], c < 2 ? p.x : p.y);
+        }
+      } else {
+        x24(iw, jw, kk, cc[u]);
+      }
+    }
+    *reinterpret_cast<float4*>(&T[lds_at(tq, ty, lz)]) = make_float4(cc[u][0], cc[u][1], cc[u][2], cc[u][3]);
+  }
+  // ---- the six faces ----
+  {
+    float h[4];
+    // y faces: 8 planes x 2 sides x 16 quads (threads 0 .. 255); z faces: 8 rows x 2 sides x 16 quads (threads 256 .. 511)
+    const int hq = tid & 15, side = (tid >> 4) & 1, a = (tid >> 5) & 7;
+    const bool zface = tid >= 256;
+    const int ly = zface ? a : (side ? kTY : -1), lz = zface ? (side ? kTZ : -1) : a;
+    const int ii = i0 + 4 * hq, jj = j0 + ly, kk = k0 + lz;
+    const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);
+    h[0] = h[1] = h[2] = h[3] = 0.f;
+    if (iw >= 0 && jw >= 0 && kk >= 0 && kk <= L.nzl + 1) x24(iw, jw, kk, h);
+    *reinterpret_cast<float4*>(&T[lds_at(hq, ly, lz)]) = make_float4(h[0], h[1], h[2], h[3]);
+    // x faces: 8 planes x 8 rows x 2 sides, one cell each (threads 0 .. 127)
+    if (tid < 128) {
+      const int xs_ = tid & 1, xy = (tid >> 1) & 7, xz = tid >> 4;
+      const int xi = xs_ ? i0 + kTX : i0 - 1, xj = j0 + xy, xk = k0 + xz;
+      const int xiw = col_of(xi);
+      float v = 0.f;
+      if (xiw >= 0 && xj < L.ny && xk <= L.nzl + 1) v = x2one(xiw, xj, xk);
+      T[(xz + 1) * kTPP + (xy + 1) * kTRP + (xs_ ? 4 + kTX : 3)] = v;
+    }
+  }
+  __syncthreads();
+  // ---- the stencil of the own quads ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!mine[u]) continue;
+    const int lz = tz + 4 * u;
+    const int i = i0 + 4 * tq, j = j0 + ty, k = k0 + lz;
+    const long long m = (long long)i + sy * j + sz * k;
+    if (!(dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f)) {
+      *reinterpret_cast<float4*>(out + m) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const int pos = lds_at(tq, ty, lz);
+    const float xl = T[pos - 1], xr = T[pos + 4];
+    const float4 ym4 = *reinterpret_cast<const float4*>(&T[pos - kTRP]), yp4 = *reinterpret_cast<const float4*>(&T[pos + kTRP]);
+    const float4 zm4 = *reinterpret_cast<const float4*>(&T[pos - kTPP]), zp4 = *reinterpret_cast<const float4*>(&T[pos + kTPP]);
+    const float xym[4] = {ym4.x, ym4.y, ym4.z, ym4.w}, xyp[4] = {yp4.x, yp4.y, yp4.z, yp4.w};
+    const float xzm[4] = {zm4.x, zm4.y, zm4.z, zm4.w}, xzp[4] = {zp4.x, zp4.y, zp4.z, zp4.w};
+    const long long mxm = (per && i == 0) ? m + (L.nx - 1) : m - 1;
+    const long long mym = (per && j == 0) ? m + sy * (L.ny - 1) : m - sy;
+    float wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
+    ld4(L.wx + m, wxc); ld4(L.wy + m, wyc); ld4(L.wy + mym, wym); ld4(L.wz + m, wzc); ld4(L.wz + (m - sz), wzm);
+    const float wxl = (float)L.wx[mxm];
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o[c] = 0.f;
+      if (dc[u][c] > 0.f) {
+        float s = (c == 0 ? wxl : wxc[c > 0 ? c - 1 : 0]) * (c == 0 ? xl : cc[u][c > 0 ? c - 1 : 0]);
+        s += wxc[c] * (c == 3 ? xr : cc[u][c < 3 ? c + 1 : 3]);
+        s += wym[c] * xym[c];
+        s += wyc[c] * xyp[c];
+        s += wzm[c] * xzm[c];
+        s += wzc[c] * xzp[c];
+        o[c] = cc[u][c] + L.omega * (bc[u][c] - (dc[u][c] * cc[u][c] - s)) * rcp(dc[u][c]);
+      }
+    }
+    *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // ---- round 4: pre-smoothing residual + restriction on BLOCKS of 4 x 2 x 2 cells per thread (open problems on one rank, even extents) ----
 // A thread that owns rows 2J, 2J+1 of planes 2K, 2K+1 holds all eight children of its two coarse cells: the pre-smoothing residual is
 // restricted in registers -- no residual array, no restriction launch (0.22 ms of a 13.5 ms iteration at 1024^3; the stencil part itself
@@ -756,6 +903,7 @@ struct MgHierarchy {
   bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
   bool blocked = true;  // round 4: pre-smoothing residual + restriction as k_mg_lin4r (4 x 2 x 2 cells per thread) where a level allows it; false: cross-check
   bool coarsest_plain = false;  // cross-check: one launch per sweep on the coarsest level instead of k_mg_coarsest
+  int coarse_tiled = 1;         // levels of >= 2^21 cells: correction + post-smoothing through an LDS tile (k_mg_post4t); 0: k_mg_post4 (cross-check); 2: every four-cell level (tests)
   int nu_coarse = 1;    // damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (1 or 2)
   bool failed = false;
 };
@@ -869,6 +1017,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   mg->blocked = g.tune.mg_blocked != 0;
   mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
   mg->coarsest_plain = g.tune.mg_coarsest_plain != 0;
+  mg->coarse_tiled = g.tune.mg_coarse_tiled;
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
     L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
@@ -1040,7 +1189,13 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   // correction + post-smoothing: one sweep fused with the prolongation; with two sweeps a plain one follows
   const float* xpre = two ? L.t : nullptr;
   float* dst = two ? L.t2 : out;
-  if (vec4 && blocks4 > 0)
+  // (big levels: through an LDS tile of 64 x 8 x 8 cells, k_mg_post4t -- bit-identical)
+  const bool tiled = vec4 && blocks4 > 0 && mg->coarse_tiled && ((long long)L.d.sz * L.d.nzl >= (1ll << 21) || mg->coarse_tiled > 1) && kfirst == 1;
+  if (tiled) {
+    const int tx_ = (L.d.nx + kTX - 1) / kTX, ty_ = (L.d.ny + kTY - 1) / kTY, tz_ = (L.d.nzl + kTZ - 1) / kTZ;
+    hipLaunchKernelGGL((k_mg_post4t<uint8_t, uint16_t>), dim3(tx_ * ty_ * tz_), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.x2, second, C.d,
+                       mg->scale, xpre, dst, tx_, ty_);
+  } else if (vec4 && blocks4 > 0)
     hipLaunchKernelGGL((k_mg_post4<uint8_t, uint16_t>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), kfirst, L.d.nzl, rhs,
                        C.x2, second, C.d, mg->scale, xpre, dst);
   else

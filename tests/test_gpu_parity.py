@@ -782,3 +782,32 @@ def test_readers_hand_out_page_locked_buffers_on_request():
     t = oia.TortuosityMI355(out[1], 1, 0)   # (the reference's default tolerance: the 1e-6 flux gate needs it)
     assert t.value() > 1.0 and t.status == oia.OI_OK
     t.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 72, 256), (48, 96, 384), (30, 50, 520), (17, 24, 136)])
+def test_multigrid_tiled_coarse_post_smoother_is_bit_identical(oi_option, shape):
+    """Round 4: on big byte / 16-bit levels the correction + post-smoothing step runs through an LDS tile of 64 x 8 x 8 cells
+    (k_mg_post4t: the corrected iterate of the tile and its six faces is formed once instead of once per neighbour).  Same arithmetic in
+    the same order as k_mg_post4: with `mg_coarse_tiled` = 2 (every four-cell level; the default tiles levels of 2^21 cells and more)
+    and = 0 the flow-through solve and the three periodic cell problems give the same bits -- tiles that end inside the level in x, y
+    and z (260 = 4 x 64 + 4 cells, 36 and 25 rows, 20 and 15 planes), the wrapped quad of a periodic level at the level's end."""
+    import openimpala_amd as oia
+    rng = np.random.default_rng(5)
+    ph = (rng.random(shape) < 0.75).astype(np.uint8)
+
+    def run(v):
+        oi_option("mg_coarse_tiled", v, 1)
+        t = oia.TortuosityMI355(ph, 1, 0, eps=1e-10, precond=oia.PRECOND_MG)
+        tau, its, x = t.value(), t.stats().iterations, t.solution()
+        t.destroy()
+        h = oia.EffectiveDiffusivityMI355(ph, 1, eps=1e-10, precond=oia.PRECOND_MG)
+        hs = [h.solve(k) for k in range(3)]
+        chi, D = h.getChiSolution(1), h.tensor()
+        h.destroy()
+        return tau, its, x, hs, chi, D
+
+    a, b = run(2), run(0)
+    assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3] and all(r[0] for r in a[3])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
