@@ -604,6 +604,145 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
   }
 }
 
+// The pre-smoothing residual through the same tile: u = w b / D of the tile and its faces in LDS, res = b - A u of the own cells;
+// RESTRICT: the residuals stay in LDS and 256 threads sum the eight children of the tile's 32 x 4 x 4 coarse cells in
+// k_mg_restrict's order (plane, row, x) -- no residual array, no restriction launch, what k_mg_lin4r does with 4 x 2 x 2 cells per
+// thread, on open AND periodic levels (even extents, the whole level and its child on this rank).  Bit-identical to k_mg_lin4<0, 0>
+// (+ k_mg_restrict) and to k_mg_lin4r.
+template <class W, class D, bool RESTRICT>
+__global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* __restrict__ b, float* __restrict__ r, Dims C,
+                                                   float* __restrict__ bcoarse, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float T[(kTZ + 2) * kTPP];
+  __shared__ __attribute__((aligned(16))) float R[RESTRICT ? kTZ * kTY * kTX : 4];
+  int t_ = blockIdx.x;
+  if ((gridDim.x & 7) == 0) t_ = (t_ & 7) * (gridDim.x >> 3) + (t_ >> 3);
+  const int bx = t_ % tiles_x, by = (t_ / tiles_x) % tiles_y, bz = t_ / (tiles_x * tiles_y);
+  const int i0 = bx * kTX, j0 = by * kTY, k0 = 1 + bz * kTZ;
+  const long long sy = L.nx, sz = L.sz;
+  const bool per = L.periodic != 0;
+  auto xs1 = [&](float bb, float dd) -> float { return dd > 0.f ? L.omega * bb * rcp(dd) : 0.f; };
+  auto row_of = [&](int jj) { return (jj >= 0 && jj < L.ny) ? jj : (per && jj == -1 ? L.ny - 1 : (per && jj == L.ny ? 0 : -1)); };
+  auto col_of = [&](int ii) { return (ii >= 0 && ii < L.nx) ? ii : (per && ii == -1 ? L.nx - 1 : (per && ii == L.nx ? 0 : -1)); };
+  auto u4 = [&](int ii, int jj, int kk, float (&o)[4]) {
+    const long long mm = (long long)ii + sy * jj + sz * kk;
+    float bb[4], dd[4];
+    ld4(L.diag + mm, dd);
+    if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    ld4(b + mm, bb);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = xs1(bb[c], dd[c]);
+  };
+  const int tid = threadIdx.x;
+  const int tq = tid & 15, ty = (tid >> 4) & 7, tz = tid >> 7;
+  auto lds_at = [&](int lq, int ly, int lz) { return (lz + 1) * kTPP + (ly + 1) * kTRP + 4 + 4 * lq; };
+  float dc[2][4], bc[2][4], uc[2][4];
+  bool mine[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int lz = tz + 4 * u;
+    const int ii = i0 + 4 * tq, jj = j0 + ty, kk = k0 + lz;
+    mine[u] = ii < L.nx && jj < L.ny && kk <= L.nzl;
+    const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);
+    uc[u][0] = uc[u][1] = uc[u][2] = uc[u][3] = 0.f;
+    dc[u][0] = dc[u][1] = dc[u][2] = dc[u][3] = 0.f;
+    bc[u][0] = bc[u][1] = bc[u][2] = bc[u][3] = 0.f;
+    if (iw >= 0 && jw >= 0 && kk <= L.nzl + 1) {
+      if (mine[u]) {
+        const long long m = (long long)ii + sy * jj + sz * kk;
+        ld4(L.diag + m, dc[u]);
+        if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
+          ld4(b + m, bc[u]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) uc[u][c] = xs1(bc[u][c], dc[u][c]);
+        }
+      } else {
+        u4(iw, jw, kk, uc[u]);
+      }
+    }
+    *reinterpret_cast<float4*>(&T[lds_at(tq, ty, lz)]) = make_float4(uc[u][0], uc[u][1], uc[u][2], uc[u][3]);
+  }
+  {
+    float h[4];
+    const int hq = tid & 15, side = (tid >> 4) & 1, a = (tid >> 5) & 7;
+    const bool zface = tid >= 256;
+    const int ly = zface ? a : (side ? kTY : -1), lz = zface ? (side ? kTZ : -1) : a;
+    const int ii = i0 + 4 * hq, jj = j0 + ly, kk = k0 + lz;
+    const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);
+    h[0] = h[1] = h[2] = h[3] = 0.f;
+    if (iw >= 0 && jw >= 0 && kk >= 0 && kk <= L.nzl + 1) u4(iw, jw, kk, h);
+    *reinterpret_cast<float4*>(&T[lds_at(hq, ly, lz)]) = make_float4(h[0], h[1], h[2], h[3]);
+    if (tid < 128) {
+      const int xs_ = tid & 1, xy = (tid >> 1) & 7, xz = tid >> 4;
+      const int xi = xs_ ? i0 + kTX : i0 - 1, xj = j0 + xy, xk = k0 + xz;
+      const int xiw = col_of(xi);
+      float v = 0.f;
+      if (xiw >= 0 && xj < L.ny && xk <= L.nzl + 1) {
+        const long long mm = (long long)xiw + sy * xj + sz * xk;
+        v = xs1(b[mm], (float)L.diag[mm]);
+      }
+      T[(xz + 1) * kTPP + (xy + 1) * kTRP + (xs_ ? 4 + kTX : 3)] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int lz = tz + 4 * u;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    const int i = i0 + 4 * tq, j = j0 + ty, k = k0 + lz;
+    const long long m = (long long)i + sy * j + sz * k;
+    const bool live = mine[u] && (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f);
+    if (live) {
+      const int pos = lds_at(tq, ty, lz);
+      const float xl = T[pos - 1], xr = T[pos + 4];
+      const float4 ym4 = *reinterpret_cast<const float4*>(&T[pos - kTRP]), yp4 = *reinterpret_cast<const float4*>(&T[pos + kTRP]);
+      const float4 zm4 = *reinterpret_cast<const float4*>(&T[pos - kTPP]), zp4 = *reinterpret_cast<const float4*>(&T[pos + kTPP]);
+      const float xym[4] = {ym4.x, ym4.y, ym4.z, ym4.w}, xyp[4] = {yp4.x, yp4.y, yp4.z, yp4.w};
+      const float xzm[4] = {zm4.x, zm4.y, zm4.z, zm4.w}, xzp[4] = {zp4.x, zp4.y, zp4.z, zp4.w};
+      const long long mxm = (per && i == 0) ? m + (L.nx - 1) : m - 1;
+      const long long mym = (per && j == 0) ? m + sy * (L.ny - 1) : m - sy;
+      float wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
+      ld4(L.wx + m, wxc); ld4(L.wy + m, wyc); ld4(L.wy + mym, wym); ld4(L.wz + m, wzc); ld4(L.wz + (m - sz), wzm);
+      const float wxl = (float)L.wx[mxm];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (dc[u][c] > 0.f) {
+          float s = (c == 0 ? wxl : wxc[c > 0 ? c - 1 : 0]) * (c == 0 ? xl : uc[u][c > 0 ? c - 1 : 0]);
+          s += wxc[c] * (c == 3 ? xr : uc[u][c < 3 ? c + 1 : 3]);
+          s += wym[c] * xym[c];
+          s += wyc[c] * xyp[c];
+          s += wzm[c] * xzm[c];
+          s += wzc[c] * xzp[c];
+          res[c] = bc[u][c] - (dc[u][c] * uc[u][c] - s);
+        }
+      }
+    }
+    if (RESTRICT) *reinterpret_cast<float4*>(&R[((lz * kTY) + ty) * kTX + 4 * tq]) = make_float4(res[0], res[1], res[2], res[3]);
+    else if (mine[u]) *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
+  }
+  if (RESTRICT) {
+    __syncthreads();
+    if (tid < 256) {
+      const int cq = tid & 15, cy = (tid >> 4) & 3, cz = tid >> 6;  // coarse cells 2 cq, 2 cq + 1 of coarse row cy, coarse plane cz of the tile
+      const int I = (i0 >> 1) + 2 * cq, J = (j0 >> 1) + cy, kf = k0 + 2 * cz;  // kf: the first of the two fine planes (local)
+      if (I < C.nx && J < C.ny && kf <= L.nzl) {
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float t = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {  // k_mg_restrict's order: plane, row, x
+            const float* q = &R[(((2 * cz + (s >> 1)) * kTY) + 2 * cy + (s & 1)) * kTX + 4 * cq + 2 * e];
+            t += q[0]; t += q[1];
+          }
+          o[e] = t;
+        }
+        const long long cm = (long long)I + (long long)C.nx * J + C.sz * (((L.z0 + kf - 1) >> 1) - C.z0 + 1);
+        *reinterpret_cast<float2*>(bcoarse + cm) = make_float2(o[0], o[1]);
+      }
+    }
+  }
+}
+
 // ---- round 4: pre-smoothing residual + restriction on BLOCKS of 4 x 2 x 2 cells per thread (open problems on one rank, even extents) ----
 // A thread that owns rows 2J, 2J+1 of planes 2K, 2K+1 holds all eight children of its two coarse cells: the pre-smoothing residual is
 // restricted in registers -- no residual array, no restriction launch (0.22 ms of a 13.5 ms iteration at 1024^3; the stencil part itself
@@ -1158,10 +1297,18 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
 #define OI_MG_LIN4(SRC, OUT, B, X, DST)                                                                                      \
   hipLaunchKernelGGL((k_mg_lin4<uint8_t, uint16_t, SRC, OUT>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), \
                      kfirst, L.d.nzl, B, X, DST)
-  if (blk) {  // pre-smoothing residual and its restriction in one launch; no residual array
+  // big levels: through the LDS tile (k_mg_lin4t), with the restriction inside where the level's extents allow it -- periodic levels too
+  const bool tiled_pre = vec4 && blocks4 > 0 && !two && mg->coarse_tiled && ((long long)L.d.sz * L.d.nzl >= (1ll << 21) || mg->coarse_tiled > 1) && kfirst == 1;
+  const bool blkt = tiled_pre && mg->blocked && !mg->comm && (L.d.ny & 1) == 0 && (L.d.nzl & 1) == 0 && (L.d.z0 & 1) == 0 && !C.replicated &&
+                    C.d.nx * 2 == L.d.nx && C.d.ny * 2 == L.d.ny && C.d.nzl * 2 == L.d.nzl && C.d.z0 * 2 == L.d.z0;
+  const int ttx = (L.d.nx + kTX - 1) / kTX, tty = (L.d.ny + kTY - 1) / kTY, ttz = (L.d.nzl + kTZ - 1) / kTZ;
+  if (blkt) {
+    hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, true>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, (float*)nullptr, C.d, C.b, ttx, tty);
+  } else if (blk) {  // pre-smoothing residual and its restriction in one launch; no residual array
     hipLaunchKernelGGL((k_mg_lin4r<uint8_t, uint16_t>), dim3(blocks8), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.d, C.b);
   } else if (!two) {
-    if (vec4 && blocks4 > 0) OI_MG_LIN4(0, 0, rhs, (const float*)nullptr, L.r);
+    if (tiled_pre) hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, L.r, C.d, (float*)nullptr, ttx, tty);
+    else if (vec4 && blocks4 > 0) OI_MG_LIN4(0, 0, rhs, (const float*)nullptr, L.r);
     else OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
   } else {
     // x2 = two damped-Jacobi sweeps from zero (kept in L.t for the post-smoother), r = rhs - A x2
@@ -1176,7 +1323,7 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
     if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 0, rhs, (const float*)L.t, L.r);
     else OI_MG_LAUNCH(k_mg_resid, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t, L.r);
   }
-  if (blk) { if (!finish_child_array(mg, C, false, C.b, s)) return false; }
+  if (blk || blkt) { if (!finish_child_array(mg, C, false, C.b, s)) return false; }
   else if (!restrict_to(mg, nullptr, nullptr, nullptr, &L, C, C.b, s)) return false;
   if (!coarse_cycle(mg, l + 1, C.b, C.x2, s)) return false;
   const float* second = nullptr;
