@@ -383,6 +383,17 @@ int main(int argc, char* argv[]) {
     if (opts.kernel == OI_KERNEL_LEAN && opts.precond == OI_PRECOND_MG) opts.precond = OI_PRECOND_JACOBI;  // capacity mode: CG
     if (opts.precond == OI_PRECOND_MG && opts.kernel == OI_KERNEL_FUSED1) opts.kernel = OI_KERNEL_AUTO;  // the cycle sits between the two kernels
     in.query("gpu.device", opts.device);
+    // gpu.p_storage = f64 (default, every vector fp64 as in the reference) | f32: the search direction p kept as fp32 in HBM -- x, r, q
+    // and every operation stay fp64, r stays the exact recurrence residual of x; same iteration counts at 1024^3, the solve 7-9 %
+    // shorter (profiles/r04/mg_pcg_p_stored_fp32.txt)
+    {
+      std::string ps = "f64";
+      in.query("gpu.p_storage", ps);
+      const std::string psl = lower(ps);
+      if (psl == "f32" || psl == "fp32" || psl == "float") opts.p_storage = OI_STORE_F32;
+      else if (psl == "f64" || psl == "fp64" || psl == "double") opts.p_storage = OI_STORE_F64;
+      else throw std::runtime_error("gpu.p_storage must be f64 or f32 (got '" + ps + "')");
+    }
     // gpu.ngpus > 1: one host thread per GPU, z-slabs, RCCL over xGMI (the reference's mpirun -np N);
     // gpu.transport = local keeps all slabs on ONE GPU (in-process transport: a rehearsal of the slab path)
     int ngpus = 1;

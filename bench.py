@@ -509,6 +509,28 @@ def main():
         tm.destroy()
         t = None
         extras["solve_mg"] = solve_mg
+        # the same solve with the search direction STORED as fp32 (opts.p_storage; x, r, q, z and every operation fp64): a variant,
+        # not the default -- the reference keeps every vector in fp64
+        if not args.no_variants:
+            bufm, _ = make_structure(oia, args, shape, z0, nzl)
+            kwm["p_storage"] = oia.STORE_F32
+            if comm is not None:
+                tm = oia.TortuosityMI355(bufm, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=nz, **kwm)
+            else:
+                tm = oia.TortuosityMI355(bufm, 1, direction, 0.0, 1.0, shape=shape, **kwm)
+            bufm.free()
+            barrier()
+            m0 = time.perf_counter()
+            tm.cg_begin()
+            fdone, fits, frel = False, 0, float("nan")
+            while not fdone and fits < 1000:
+                tm.cg_iterate(4)
+                fits, frel, fdone = tm.cg_state()
+            tm.cg_finish()
+            barrier()
+            solve_mg["p_stored_fp32"] = {"converged": bool(fdone), "iterations": fits, "relres": frel, "seconds": time.perf_counter() - m0,
+                                         "device_GB": tm.stats().bytes_device / 1e9}
+            tm.destroy()
 
     # ---- variant: search direction p STORED as fp32 (x, r, q and all arithmetic fp64) ----
     variants = None
