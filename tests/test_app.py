@@ -50,9 +50,10 @@ verbose = 0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precond", ["", "gpu.precond = jacobi", "gpu.precond = none\ngpu.kernel = fused"])
+@pytest.mark.parametrize("precond", ["", "gpu.precond = jacobi", "gpu.precond = none\ngpu.kernel = fused", "gpu.p_storage = f32"])
 def test_diffusion_results_file(app, tmp_path, goldens, precond):
-    """Default solver = multigrid-preconditioned CG; the plain CG variants give the same file."""
+    """Default solver = multigrid-preconditioned CG; the plain CG variants -- and the default with the search direction stored as
+    fp32 (gpu.p_storage) -- give the same file."""
     g = goldens["phases"]["1"]
     text = f"""
 {precond}
