@@ -156,6 +156,62 @@ def test_slabs_multigrid_distributed_levels(oi_option, nranks, direction, shape)
     np.testing.assert_allclose(x, ref["x"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("nranks,shape", [(2, (64, 48, 256)), (3, (96, 36, 264))])
+def test_slabs_multigrid_tiled_coarse_kernels(oi_option, nranks, shape):
+    """Round 4: the LDS-tiled coarse-level kernels (k_mg_post4t, k_mg_lin4t; forced onto every four-cell level with
+    `mg_coarse_tiled` = 2) on SLAB-partitioned levels -- the tile's z faces are the ghost planes the neighbours sent -- for the
+    flow-through problem, and on a ring of slabs for the periodic cell problems: same iteration counts as one GPU, same answers;
+    with `mg_coarse_tiled` = 0 (k_mg_post4 / k_mg_lin4) the slab solves are the same bit for bit."""
+    rng = np.random.default_rng(11)
+    phase = (rng.random(shape) < 0.72).astype(np.uint8)
+    oi_option("mg_replicate_cells", 600)
+    res = {}
+    for v in (2, 0):
+        oi_option("mg_coarse_tiled", v, 1)
+        single = oia.TortuosityMI355(phase, 1, 0, -1.0, 1.0, eps=1e-10, precond=oia.PRECOND_MG)
+        tau1, it1 = single.value(), single.getSolverIterations()
+        single.destroy()
+        outs = run_slabs(phase, 1, 0, nranks, -1.0, 1.0, eps=1e-10, precond=oia.PRECOND_MG)
+        assert all(r["status"] == oia.OI_OK for r in outs)
+        assert outs[0]["tau"] == pytest.approx(tau1, rel=1e-8)
+        assert abs(outs[0]["st"]["iterations"] - it1) <= 2, (outs[0]["st"]["iterations"], it1)
+        res[v] = (outs[0]["tau"], outs[0]["st"]["iterations"], np.concatenate([r["x"] for r in outs]))
+    assert res[2][0] == res[0][0] and res[2][1] == res[0][1] and np.array_equal(res[2][2], res[0][2])
+    # the periodic cell problems on a ring of the same slabs
+    nz = shape[0]
+    tens = {}
+    for v in (2, 0):
+        oi_option("mg_coarse_tiled", v, 1)
+        comms = oia.Comm.create_local(nranks)
+        out, err = [None] * nranks, []
+
+        def work(r):
+            try:
+                z0, z1 = oia.slab_range(nz, nranks, r)
+                h = oia.EffectiveDiffusivityMI355(np.ascontiguousarray(phase[z0:z1]), 1, eps=1e-10, precond=oia.PRECOND_MG, comm=comms[r], z0=z0,
+                                                  nz_global=nz)
+                rs = [h.solve(k) for k in range(3)]
+                out[r] = (rs, h.tensor().copy())
+                h.destroy()
+            except Exception as e:
+                err.append((r, repr(e)))
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        [t.start() for t in th]
+        [t.join(timeout=300) for t in th]
+        assert not any(t.is_alive() for t in th) and not err, err
+        for c in comms:
+            c.destroy()
+        assert all(x[0] for x in out[0][0])
+        tens[v] = (out[0][0], out[0][1])
+    assert tens[2][0] == tens[0][0] and np.array_equal(tens[2][1], tens[0][1])
+    h1 = oia.EffectiveDiffusivityMI355(phase, 1, eps=1e-10, precond=oia.PRECOND_MG)
+    r1 = [h1.solve(k) for k in range(3)]
+    np.testing.assert_allclose(tens[2][1], h1.tensor(), rtol=0, atol=1e-9)
+    assert all(abs(a[1] - b[1]) <= 1 for a, b in zip(tens[2][0], r1))
+    h1.destroy()
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_slabs_multigrid_compacted_lines(sample_phase, goldens, nranks):
     """The multigrid-preconditioned iteration on compacted lines across slabs: ghost planes of r and z travel as
