@@ -609,9 +609,12 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
 // k_mg_restrict's order (plane, row, x) -- no residual array, no restriction launch, what k_mg_lin4r does with 4 x 2 x 2 cells per
 // thread, on open AND periodic levels (even extents, the whole level and its child on this rank).  Bit-identical to k_mg_lin4<0, 0>
 // (+ k_mg_restrict) and to k_mg_lin4r.
-template <class W, class D, bool RESTRICT>
+// SRC / OUT as in k_mg_lin4: u = w b / D formed on the fly (SRC 0) or a stored vector x (SRC 1); the result is res (OUT 0) or the
+// smoothed u + w res / D (OUT 1) -- the four steps of a level that runs two sweeps before and after the correction.
+template <class W, class D, bool RESTRICT, int SRC = 0, int OUT = 0>
 __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* __restrict__ b, float* __restrict__ r, Dims C,
-                                                   float* __restrict__ bcoarse, int tiles_x, int tiles_y) {
+                                                   float* __restrict__ bcoarse, int tiles_x, int tiles_y, const float* __restrict__ x = nullptr) {
+  static_assert(!RESTRICT || (SRC == 0 && OUT == 0), "the restriction takes the pre-smoothing residual");
   __shared__ __attribute__((aligned(16))) float T[(kTZ + 2) * kTPP];
   __shared__ __attribute__((aligned(16))) float R[RESTRICT ? kTZ * kTY * kTX : 4];
   int t_ = blockIdx.x;
@@ -625,6 +628,7 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
   auto col_of = [&](int ii) { return (ii >= 0 && ii < L.nx) ? ii : (per && ii == -1 ? L.nx - 1 : (per && ii == L.nx ? 0 : -1)); };
   auto u4 = [&](int ii, int jj, int kk, float (&o)[4]) {
     const long long mm = (long long)ii + sy * jj + sz * kk;
+    if (SRC == 1) { ld4(x + mm, o); return; }
     float bb[4], dd[4];
     ld4(L.diag + mm, dd);
     if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
@@ -652,8 +656,14 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
         ld4(L.diag + m, dc[u]);
         if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
           ld4(b + m, bc[u]);
+          if (SRC == 1) {
+            ld4(x + m, uc[u]);
+          } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) uc[u][c] = xs1(bc[u][c], dc[u][c]);
+            for (int c = 0; c < 4; ++c) uc[u][c] = xs1(bc[u][c], dc[u][c]);
+          }
+        } else if (SRC == 1) {
+          ld4(x + m, uc[u]);  // (a stored iterate is what it is, also where no cell has a row: the neighbours read it from the tile)
         }
       } else {
         u4(iw, jw, kk, uc[u]);
@@ -678,7 +688,7 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
       float v = 0.f;
       if (xiw >= 0 && xj < L.ny && xk <= L.nzl + 1) {
         const long long mm = (long long)xiw + sy * xj + sz * xk;
-        v = xs1(b[mm], (float)L.diag[mm]);
+        v = SRC == 1 ? x[mm] : xs1(b[mm], (float)L.diag[mm]);
       }
       T[(xz + 1) * kTPP + (xy + 1) * kTRP + (xs_ ? 4 + kTX : 3)] = v;
     }
@@ -712,7 +722,8 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
           s += wyc[c] * xyp[c];
           s += wzm[c] * xzm[c];
           s += wzc[c] * xzp[c];
-          res[c] = bc[u][c] - (dc[u][c] * uc[u][c] - s);
+          const float rr = bc[u][c] - (dc[u][c] * uc[u][c] - s);
+          res[c] = OUT == 0 ? rr : uc[u][c] + L.omega * rr * rcp(dc[u][c]);
         }
       }
     }
@@ -1302,6 +1313,11 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   const bool blkt = tiled_pre && mg->blocked && !mg->comm && (L.d.ny & 1) == 0 && (L.d.nzl & 1) == 0 && (L.d.z0 & 1) == 0 && !C.replicated &&
                     C.d.nx * 2 == L.d.nx && C.d.ny * 2 == L.d.ny && C.d.nzl * 2 == L.d.nzl && C.d.z0 * 2 == L.d.z0;
   const int ttx = (L.d.nx + kTX - 1) / kTX, tty = (L.d.ny + kTY - 1) / kTY, ttz = (L.d.nzl + kTZ - 1) / kTZ;
+  // (two sweeps before and after the correction: the same tile for the three k_mg_lin4 steps of such a level)
+  const bool tiled2 = vec4 && blocks4 > 0 && two && mg->coarse_tiled && ((long long)L.d.sz * L.d.nzl >= (1ll << 21) || mg->coarse_tiled > 1) && kfirst == 1;
+#define OI_MG_LIN4T(SRC, OUT, B, X, DST)                                                                                              \
+  hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false, SRC, OUT>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), \
+                     B, DST, C.d, (float*)nullptr, ttx, tty, X)
   if (blkt) {
     hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, true>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, (float*)nullptr, C.d, C.b, ttx, tty);
   } else if (blk) {  // pre-smoothing residual and its restriction in one launch; no residual array
@@ -1312,7 +1328,9 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
     else OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
   } else {
     // x2 = two damped-Jacobi sweeps from zero (kept in L.t for the post-smoother), r = rhs - A x2
-    if (vec4 && blocks4 > 0) {
+    if (tiled2) {
+      OI_MG_LIN4T(0, 1, rhs, (const float*)nullptr, L.t);
+    } else if (vec4 && blocks4 > 0) {
       OI_MG_LIN4(0, 1, rhs, (const float*)nullptr, L.t);
     } else {
       OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)nullptr, L.t2, 1);
@@ -1320,7 +1338,8 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
       OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t2, L.t, 0);
     }
     if (!ghost_exchange(mg, L, L.t, sizeof(float), s)) return false;
-    if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 0, rhs, (const float*)L.t, L.r);
+    if (tiled2) OI_MG_LIN4T(1, 0, rhs, (const float*)L.t, L.r);
+    else if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 0, rhs, (const float*)L.t, L.r);
     else OI_MG_LAUNCH(k_mg_resid, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t, L.r);
   }
   if (blk || blkt) { if (!finish_child_array(mg, C, false, C.b, s)) return false; }
@@ -1349,10 +1368,12 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
     OI_MG_LAUNCH(k_mg_post, L, L.d.nzl, s, kfirst, rhs, C.x2, second, C.d, mg->scale, xpre, dst);
   if (two) {
     if (!ghost_exchange(mg, L, L.t2, sizeof(float), s)) return false;
-    if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 1, rhs, (const float*)L.t2, out);
+    if (tiled2) OI_MG_LIN4T(1, 1, rhs, (const float*)L.t2, out);
+    else if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 1, rhs, (const float*)L.t2, out);
     else OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t2, out, 0);
   }
 #undef OI_MG_LIN4
+#undef OI_MG_LIN4T
   return ghost_exchange(mg, L, out, sizeof(float), s);
 }
 
