@@ -282,7 +282,8 @@ int oi_tort_line_voxels(void);
  *                   "mg_coarsest_plain" (1: the coarsest level's sweeps as separate launches), "mg_xpair" (0: the x update inside the
  *                   post-smoother every iteration instead of two terms every second one), "mg_blocked" (0: pre-smoothing residual and
  *                   restriction of the coarse levels as two kernels instead of one), "mg_coarse_tiled" (0: correction + post-smoothing of the
- *                   big coarse levels without the LDS tile; 2: the tile on every four-cell level); of the single-kernel iteration:
+ *                   big coarse levels without the LDS tile; 2: the tile on every four-cell level), "mg_fused_images" (0: periodic levels keep
+ *                   their image-plane copies although the kernels write the images); of the single-kernel iteration:
  *                   "cg1_seg" (0: per-line slot table instead of segment records), "cg1_fin_sliced" (0: final sums by one block)
  *   "dense_nt"      bit mask (default 31): nontemporal stores of p (1), x (2), q (4), r (8) and the smoother's output (16) in the
  *                   kernels of the dense layouts (homogenization, two-kernel and unfused variants); 0 = the default policy (A/B)

@@ -52,6 +52,8 @@ struct Tune {
   int mg_xpair = 1;           // x update inside the post-smoother: 1 = every second iteration, two terms (round 4); 0 = every iteration (cross-check)
   int mg_post_kernel = 0;     // 1: the fine post-smoother as k_mg_fine<2, 2> also where k_cg1b FORM 3 could run (cross-check)
   int mg_coarsest_plain = 0;  // 1: the coarsest level's sweeps as separate launches (cross-check of the one-launch kernel)
+  int mg_fused_images = 1;    // periodic coarse levels that live whole on one rank: the cycle's kernels write the z images of what they store (no
+                              // image-plane copy launch after them); 0: the copies run as well (cross-check)
   int mg_coarse_tiled = 1;    // coarse levels of >= 2^21 cells: correction + post-smoothing through an LDS tile (k_mg_post4t); 0: k_mg_post4 (cross-check); 2: every four-cell level (tests)
   int mg_nu_coarse = 0;  // damped-Jacobi sweeps before / after the coarse correction on the coarse levels (the fine level: 1): 1, 2, or
                          // 0 = by the structure -- 2 where fewer than 35 % of the 8-voxel lines hold a free voxel (low porosity: fewer

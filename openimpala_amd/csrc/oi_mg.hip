@@ -61,6 +61,8 @@ struct Dims {
   int nx, ny, nzl, z0;  // owned planes [z0, z0 + nzl) of the level's global z range
   int nzg;              // planes of the whole level
   int periodic;         // 1: the homogenization cell problem (x, y wrap by index, z through the ghost planes)
+  int zimg;             // 1: periodic AND the whole level lives on this rank: the ghost planes are the images of planes nzl and 1, and
+                        // whoever writes a cell of plane 1 / nzl writes its image too (OI_MG_IMG) -- no image-plane copy afterwards
   long long sz;         // plane stride = nx * ny; arrays hold nzl + 2 planes (ghosts at 0 and nzl + 1)
   float omega;          // Jacobi damping of the cycle (MgHierarchy::omega, the same on every level)
 };
@@ -85,6 +87,15 @@ struct LevelT : Dims {
 // 1/d for the (small-integer) diagonals: one v_rcp_f32 (1 ulp) instead of the IEEE division sequence; the
 // smoother only needs a fixed positive diagonal scaling
 __device__ __forceinline__ float rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+
+// the image of a value just stored at cell m of local plane k (Dims::zimg; one plane only: both images)
+#define OI_MG_IMG(L, arr, m, k, T, v)                                                       \
+  do {                                                                                      \
+    if (L.zimg) {                                                                           \
+      if ((k) == 1) *reinterpret_cast<T*>((arr) + (m) + L.sz * L.nzl) = (v);                \
+      if ((k) == L.nzl) *reinterpret_cast<T*>((arr) + (m) - L.sz * L.nzl) = (v);            \
+    }                                                                                       \
+  } while (0)
 
 // indices of the -x / +x / -y / +y neighbours of cell (i, j) at m.  Non-periodic levels need no edge tests (the
 // weights on the domain faces are zero and every index stays inside the ghosted array); periodic levels wrap.
@@ -227,6 +238,7 @@ __global__ void __launch_bounds__(256) k_mg_resid(LevelT<W, D> L, int kfirst, co
     res = b[m] - (d * x[m] - offdiag(L, m, mxm, mym, x[mxm], x[mxp], x[mym], x[myp], x[m - sz], x[m + sz]));
   }
   r[m] = res;
+  OI_MG_IMG(L, r, m, k, float, res);
 }
 
 // coarse right-hand side = P^T r (sum over the owned children); L is the COARSE level
@@ -248,6 +260,7 @@ __global__ void __launch_bounds__(256) k_mg_restrict(Dims F, const float* __rest
     }
   }
   bc[m] = s;
+  OI_MG_IMG(L, bc, m, k, float, s);
 }
 
 __global__ void __launch_bounds__(256) k_mg_fine_restrict(Geom g, const uint8_t* __restrict__ code,
@@ -300,6 +313,7 @@ __global__ void __launch_bounds__(256) k_mg_post(LevelT<W, D> L, int kfirst, con
     o = c + L.omega * (b[m] - (d * c - s)) * rcp(d);
   }
   out[m] = o;
+  OI_MG_IMG(L, out, m, k, float, o);
 }
 
 // ---- the same two kernels, FOUR cells along x per thread (byte / 16-bit levels whose nx is a multiple of 4) ----
@@ -359,6 +373,7 @@ __global__ void __launch_bounds__(256) k_mg_lin4(LevelT<W, D> L, int kfirst, int
   // 40-45 % of the first coarse level's cells dead, in runs)
   if (!(dc[0] > 0.f || dc[1] > 0.f || dc[2] > 0.f || dc[3] > 0.f)) {
     *reinterpret_cast<float4*>(r + m) = make_float4(0.f, 0.f, 0.f, 0.f);
+    OI_MG_IMG(L, r, m, k, float4, make_float4(0.f, 0.f, 0.f, 0.f));
     return;
   }
   ld4(b + m, bc);
@@ -388,6 +403,7 @@ __global__ void __launch_bounds__(256) k_mg_lin4(LevelT<W, D> L, int kfirst, int
     }
   }
   *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
+  OI_MG_IMG(L, r, m, k, float4, make_float4(res[0], res[1], res[2], res[3]));
 }
 
 template <class W, class D>
@@ -425,6 +441,7 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
   ld4(L.diag + m, dc);
   if (!(dc[0] > 0.f || dc[1] > 0.f || dc[2] > 0.f || dc[3] > 0.f)) {  // (see k_mg_lin4)
     *reinterpret_cast<float4*>(out + m) = make_float4(0.f, 0.f, 0.f, 0.f);
+    OI_MG_IMG(L, out, m, k, float4, make_float4(0.f, 0.f, 0.f, 0.f));
     return;
   }
   ld4(b + m, bc);
@@ -455,6 +472,7 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
     }
   }
   *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
+  OI_MG_IMG(L, out, m, k, float4, make_float4(o[0], o[1], o[2], o[3]));
 }
 
 // ---- round 4 (late): the correction + post-smoothing step of a big byte / 16-bit level through an LDS TILE ----
@@ -573,6 +591,7 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     const long long m = (long long)i + sy * j + sz * k;
     if (!(dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f)) {
       *reinterpret_cast<float4*>(out + m) = make_float4(0.f, 0.f, 0.f, 0.f);
+      OI_MG_IMG(L, out, m, k, float4, make_float4(0.f, 0.f, 0.f, 0.f));
       continue;
     }
     const int pos = lds_at(tq, ty, lz);
@@ -601,6 +620,7 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
       }
     }
     *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
+    OI_MG_IMG(L, out, m, k, float4, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -728,7 +748,10 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
       }
     }
     if (RESTRICT) *reinterpret_cast<float4*>(&R[((lz * kTY) + ty) * kTX + 4 * tq]) = make_float4(res[0], res[1], res[2], res[3]);
-    else if (mine[u]) *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
+    else if (mine[u]) {
+      *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
+      OI_MG_IMG(L, r, m, k, float4, make_float4(res[0], res[1], res[2], res[3]));
+    }
   }
   if (RESTRICT) {
     __syncthreads();
@@ -747,8 +770,10 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
           }
           o[e] = t;
         }
-        const long long cm = (long long)I + (long long)C.nx * J + C.sz * (((L.z0 + kf - 1) >> 1) - C.z0 + 1);
+        const int cp = ((L.z0 + kf - 1) >> 1) - C.z0 + 1;
+        const long long cm = (long long)I + (long long)C.nx * J + C.sz * cp;
         *reinterpret_cast<float2*>(bcoarse + cm) = make_float2(o[0], o[1]);
+        OI_MG_IMG(C, bcoarse, cm, cp, float2, make_float2(o[0], o[1]));
       }
     }
   }
@@ -867,6 +892,7 @@ __global__ void __launch_bounds__(256) k_mg_jacobi(LevelT<W, D> L, int kfirst, c
     }
   }
   xout[m] = o;
+  OI_MG_IMG(L, xout, m, k, float, o);
 }
 
 // coarsest level, all sweeps in ONE launch: <= 512 cells, one thread per cell, weights and right-hand side in registers, the
@@ -923,7 +949,11 @@ __global__ void __launch_bounds__(512) k_mg_coarsest(LevelT<W, D> L, const float
     c = o;
     __syncthreads();
   }
-  if (act) out[m] = c;
+  if (act) {
+    out[m] = c;
+    const int kk1 = t / sz + 1;  // local plane of this cell
+    OI_MG_IMG(L, out, m, kk1, float, c);
+  }
 }
 
 // ------------------------------ plain fine-level kernels (cross-check of the tiled ones) ------------------------------
@@ -1053,6 +1083,7 @@ struct MgHierarchy {
   bool novec4 = false;  // cross-check: one-cell coarse kernels instead of the four-cells-per-thread ones
   bool blocked = true;  // round 4: pre-smoothing residual + restriction as k_mg_lin4r (4 x 2 x 2 cells per thread) where a level allows it; false: cross-check
   bool coarsest_plain = false;  // cross-check: one launch per sweep on the coarsest level instead of k_mg_coarsest
+  bool fused_images = true;     // periodic levels on one rank: no image-plane copy after a kernel that wrote the images itself; false: cross-check
   int coarse_tiled = 1;         // levels of >= 2^21 cells: correction + post-smoothing through an LDS tile (k_mg_post4t); 0: k_mg_post4 (cross-check); 2: every four-cell level (tests)
   int nu_coarse = 1;    // damped-Jacobi sweeps before and after the coarse correction on the COARSE levels (1 or 2)
   bool failed = false;
@@ -1094,11 +1125,13 @@ __global__ void __launch_bounds__(256) k_wrap_planes(uint32_t* __restrict__ p, l
 }
 
 // ghost planes of a per-level array from the z-neighbours (no-op without neighbours / on replicated levels)
-static bool ghost_exchange(MgHierarchy* mg, const MgLevelHost& L, void* base, size_t elem, hipStream_t s) {
+// imaged: the kernel that produced the array wrote the images itself (OI_MG_IMG on a level with Dims::zimg)
+static bool ghost_exchange(MgHierarchy* mg, const MgLevelHost& L, void* base, size_t elem, hipStream_t s, bool imaged = false) {
   char* p = (char*)base;
   const size_t pb = (size_t)L.d.sz * elem;
   if (!mg->comm || L.replicated) {
     if (!mg->periodic) return true;
+    if (imaged && L.d.zimg && mg->fused_images) return true;
     // the whole level lives here: its first / last plane are each other's periodic images
     if ((pb & 3) == 0 && L.d.nzl >= 2) {  // (one plane only: source and destination of the two copies are the same pair, keep the ordered copies)
       const long long words = (long long)(pb >> 2);
@@ -1131,14 +1164,15 @@ static void child_span(const MgLevelHost& C, int pz0, int pnzl, int* kfirst, int
 
 // after the owned contributions of a right-hand side / operator array are in place: sum across ranks
 // (first replicated level) or fetch the ghost planes (slab level)
-static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool parent_replicated, float* a, hipStream_t s) {
+static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool parent_replicated, float* a, hipStream_t s, bool imaged = false) {
   if (mg->comm && !parent_replicated && C.replicated) {
     if (mg->comm->allreduce_sum_f32(a + C.d.sz, (size_t)C.d.sz * C.d.nzl, s) != OI_OK) {
       mg->failed = true;
       return false;
     }
+    imaged = false;  // (the sum over the ranks came after the producer's images)
   }
-  return ghost_exchange(mg, C, a, sizeof(float), s);  // neighbours' planes, or the periodic images, or nothing to do
+  return ghost_exchange(mg, C, a, sizeof(float), s, imaged);  // neighbours' planes, or the periodic images, or nothing to do
 }
 
 #define MGC(call)                                                            \
@@ -1168,6 +1202,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   mg->nu_coarse = g.tune.mg_nu_coarse >= 2 ? 2 : 1;
   mg->coarsest_plain = g.tune.mg_coarsest_plain != 0;
   mg->coarse_tiled = g.tune.mg_coarse_tiled;
+  mg->fused_images = g.tune.mg_fused_images != 0;
   for (int l = 0; l < 24; ++l) {
     MgLevelHost L;
     L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
@@ -1191,6 +1226,7 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
       L.d.z0 = 0;
       L.d.nzl = L.nz;
     }
+    L.d.zimg = (periodic && (!mg->comm || L.replicated)) ? 1 : 0;  // the cycle's kernels write the z images of what they store
     L.n = L.d.sz * (L.d.nzl + 2);
     const size_t wb = L.compact ? 1 : 4, db = L.compact ? 2 : 4;
     MGC(oi::dev_malloc(&L.wx, wb * L.n)); MGC(oi::dev_malloc(&L.wy, wb * L.n)); MGC(oi::dev_malloc(&L.wz, wb * L.n));
@@ -1270,7 +1306,7 @@ static bool restrict_to(MgHierarchy* mg, const Geom* g, const uint8_t* code, con
     if (P) hipLaunchKernelGGL(k_mg_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, P->d, P->r, C.d, kfirst, bc);
     else hipLaunchKernelGGL(k_mg_fine_restrict, dim3(C.blocks(nplanes)), dim3(C.bx()), 0, s, *g, code, r1, C.d, kfirst, bc);
   }
-  return finish_child_array(mg, C, prep, bc, s);
+  return finish_child_array(mg, C, prep, bc, s, P != nullptr);  // (k_mg_restrict writes the images of its level; the fine-level kernels do not)
 }
 
 // Approximate solve of level l: right-hand side `rhs` (ghost planes valid), result in `out` (ghost
@@ -1284,14 +1320,14 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
     // (periodic levels: on one rank only -- a ring of slabs exchanges the planes of a replicated level through the transport)
     if ((mg->periodic ? !mg->comm : (!mg->comm || L.replicated)) && !L.compact && !mg->coarsest_plain && L.d.sz * L.d.nzl <= 512 && L.d.sz <= 512) {
       hipLaunchKernelGGL((k_mg_coarsest<float, float>), dim3(1), dim3(512), 0, s, L.dev<float, float>(), rhs, out, kCoarsestSweeps);
-      return mg->periodic ? ghost_exchange(mg, L, out, sizeof(float), s) : true;  // (the parent reads the image planes of the correction)
+      return mg->periodic ? ghost_exchange(mg, L, out, sizeof(float), s, true) : true;  // (the parent reads the image planes of the correction)
     }
     for (int it = 1; it <= kCoarsestSweeps; ++it) {
       const bool to_out = ((kCoarsestSweeps - it) & 1) == 0;
       float* dst = to_out ? out : L.r;
       const float* src = to_out ? L.r : out;
       OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, src, dst, it == 1 ? 1 : 0);
-      if (!ghost_exchange(mg, L, dst, sizeof(float), s)) return false;
+      if (!ghost_exchange(mg, L, dst, sizeof(float), s, true)) return false;
     }
     return true;
   }
@@ -1334,21 +1370,21 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
       OI_MG_LIN4(0, 1, rhs, (const float*)nullptr, L.t);
     } else {
       OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)nullptr, L.t2, 1);
-      if (!ghost_exchange(mg, L, L.t2, sizeof(float), s)) return false;
+      if (!ghost_exchange(mg, L, L.t2, sizeof(float), s, true)) return false;
       OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t2, L.t, 0);
     }
-    if (!ghost_exchange(mg, L, L.t, sizeof(float), s)) return false;
+    if (!ghost_exchange(mg, L, L.t, sizeof(float), s, true)) return false;
     if (tiled2) OI_MG_LIN4T(1, 0, rhs, (const float*)L.t, L.r);
     else if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 0, rhs, (const float*)L.t, L.r);
     else OI_MG_LAUNCH(k_mg_resid, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t, L.r);
   }
-  if (blk || blkt) { if (!finish_child_array(mg, C, false, C.b, s)) return false; }
+  if (blk || blkt) { if (!finish_child_array(mg, C, false, C.b, s, blkt)) return false; }
   else if (!restrict_to(mg, nullptr, nullptr, nullptr, &L, C, C.b, s)) return false;
   if (!coarse_cycle(mg, l + 1, C.b, C.x2, s)) return false;
   const float* second = nullptr;
   if ((mg->wmask >> (l + 1)) & 1u) {
     OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, kfirst, C.b, C.x2, C.b2);
-    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s)) return false;
+    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s, true)) return false;
     if (!coarse_cycle(mg, l + 1, C.b2, C.xs, s)) return false;
     second = C.xs;
   }
@@ -1367,14 +1403,14 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   else
     OI_MG_LAUNCH(k_mg_post, L, L.d.nzl, s, kfirst, rhs, C.x2, second, C.d, mg->scale, xpre, dst);
   if (two) {
-    if (!ghost_exchange(mg, L, L.t2, sizeof(float), s)) return false;
+    if (!ghost_exchange(mg, L, L.t2, sizeof(float), s, true)) return false;
     if (tiled2) OI_MG_LIN4T(1, 1, rhs, (const float*)L.t2, out);
     else if (vec4 && blocks4 > 0) OI_MG_LIN4(1, 1, rhs, (const float*)L.t2, out);
     else OI_MG_LAUNCH(k_mg_jacobi, L, L.d.nzl, s, kfirst, rhs, (const float*)L.t2, out, 0);
   }
 #undef OI_MG_LIN4
 #undef OI_MG_LIN4T
-  return ghost_exchange(mg, L, out, sizeof(float), s);
+  return ghost_exchange(mg, L, out, sizeof(float), s, true);
 }
 
 // z = M^-1 r on the fine level; `scratch` is a fine vector the caller does not need meanwhile.
@@ -1417,7 +1453,7 @@ static int mg_vcycle_launch(MgHierarchy* mg, const Geom& g, const uint8_t* code,
   if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
   if (mg->wmask & 1u) {
     OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, 1, C.b, C.x2, C.b2);
-    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s)) return -1;
+    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s, true)) return -1;
     if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
     cref.xc2 = C.xs;
   }
@@ -1451,7 +1487,7 @@ int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* c
   if (!coarse_cycle(mg, 0, C.b, C.x2, s)) return -1;
   if (mg->wmask & 1u) {
     OI_MG_LAUNCH(k_mg_resid, C, C.d.nzl, s, 1, C.b, C.x2, C.b2);
-    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s)) return -1;
+    if (!ghost_exchange(mg, C, C.b2, sizeof(float), s, true)) return -1;
     if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
     cref.xc2 = C.xs;
   }

@@ -2172,6 +2172,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_xpair") t.mg_xpair = iv != 0;
   else if (k == "mg_blocked") t.mg_blocked = iv != 0;
   else if (k == "mg_coarse_tiled") t.mg_coarse_tiled = iv < 0 ? 0 : iv;
+  else if (k == "mg_fused_images") t.mg_fused_images = iv != 0;
   else if (k == "mg_post_kernel") t.mg_post_kernel = iv != 0;
   else if (k == "mg_xfirst") t.mg_xfirst = iv != 0;
   else if (k == "cg1_fin_sliced") t.cg1_fin_sliced = iv != 0;
@@ -2194,7 +2195,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_compact = old.cg1_compact;
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
-  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_omega_coarse = old.mg_omega_coarse; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst; t.mg_xpair = old.mg_xpair; t.mg_blocked = old.mg_blocked; t.mg_coarse_tiled = old.mg_coarse_tiled; t.cg1_fin_sliced = old.cg1_fin_sliced;
+  t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_omega_coarse = old.mg_omega_coarse; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst; t.mg_xpair = old.mg_xpair; t.mg_blocked = old.mg_blocked; t.mg_coarse_tiled = old.mg_coarse_tiled; t.mg_fused_images = old.mg_fused_images; t.cg1_fin_sliced = old.cg1_fin_sliced;
   t.force_comm = old.force_comm;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;

@@ -297,3 +297,29 @@ def test_gpu_homogenization_compacted_and_dense_vectors_agree(sample_phase, oi_o
         np.testing.assert_allclose(lines[1][k], dense[1][k], rtol=0, atol=1e-9)
     np.testing.assert_allclose(lines[2], dense[2], rtol=0, atol=1e-10)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,tiled", [((64, 64, 64), 1), ((40, 36, 44), 1), ((25, 31, 33), 1), ((48, 96, 384), 2), ((30, 50, 520), 2), ((2, 6, 8), 1)])
+def test_gpu_homogenization_kernels_write_their_own_z_images(sample_phase, oi_option, shape, tiled):
+    """Round 4: on a periodic level that lives whole on one rank every kernel of the cycle writes, with a cell of the first / last
+    plane, its image in the ghost plane beyond the other end -- the image-plane copy launches after them (78 per cycle at 1024^3)
+    are gone.  The copies moved, nothing else: with `mg_fused_images` = 0 (the copies run as well) the solves are the same bit for
+    bit; one-cell, four-cell and LDS-tiled kernels (`mg_coarse_tiled` = 2), one and two sweeps per visit, a level of one plane."""
+    import openimpala_amd as oia
+    nz, ny, nx = shape
+    sub = np.ascontiguousarray(np.tile(sample_phase, (1, 1, 6))[:nz, :ny, :nx])
+    oi_option("mg_coarse_tiled", tiled, 1)
+    out = {}
+    for nu in (1, 2):
+        oi_option("mg_nu_coarse", nu)
+        for v in (1, 0):
+            oi_option("mg_fused_images", v, 1)
+            h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-10, precond=oia.PRECOND_MG)
+            res = [h.solve(k) for k in range(3)]
+            out[v] = res, [h.getChiSolution(k).copy() for k in range(3)], h.tensor().copy()
+            h.destroy()
+        assert out[1][0] == out[0][0] and all(r[0] for r in out[1][0])
+        for k in range(3):
+            assert np.array_equal(out[1][1][k], out[0][1][k])
+        assert np.array_equal(out[1][2], out[0][2])
+
