@@ -242,8 +242,9 @@ int launch_update_r(const Geom& g, const uint8_t* code, double* r, const double*
                     const double* hist, int k, double* partials, const Ctrl* ctrl, long long first_slot, long long nslots,
                     hipStream_t s);
 // x += alpha_k p  (deferred update flush of the fused variant)
+// p_next != null: x = (x + alpha_k p) + alpha_{k+1} p_next in one pass over x (the same two dependent additions as two calls)
 void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k, const int* lineoff,
-                      hipStream_t s);
+                      hipStream_t s, const void* p_next = nullptr);
 // dst[slot..slot+ncomp) = sum of partials (deterministic order); optional convergence test on
 // dst[check_rr_index]: sets ctrl->done = iter_done when <= tol2
 void launch_finalize(const double* partials, int nblocks, int ncomp, double* dst, Ctrl* ctrl, int check,

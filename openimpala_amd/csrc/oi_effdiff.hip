@@ -547,7 +547,8 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
       double* pbuf[2] = {h->p, h->p2};
       const int m = seen.done ? K - 1 : K;
       const int e = m < 0 ? 0 : (m & ~1);
-      for (int j = e; j < K; ++j) launch_axpy_hist(g, chi, pbuf[j & 1], 0, h->hist, j, h->lineoff, s);
+      if (K - e == 2) launch_axpy_hist(g, chi, pbuf[e & 1], 0, h->hist, e, h->lineoff, s, pbuf[(e + 1) & 1]);  // (two terms: one pass over chi)
+      else for (int j = e; j < K; ++j) launch_axpy_hist(g, chi, pbuf[j & 1], 0, h->hist, j, h->lineoff, s);
     } else if (h->fused && K > 0) {  // the fused iteration applies chi += alpha_k p_k inside iteration k + 1: flush the last one
       double* pbuf[2] = {h->p, h->p2};
       launch_axpy_hist(g, chi, pbuf[(K - 1) & 1], 0, h->hist, K - 1, nullptr, s);

@@ -473,6 +473,11 @@ __global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __rest
                                                     const int* __restrict__ lineoff, int LW) {
   double rr = 0.0, rz = 0.0;
   OI_PAIR_LOOP_BEGIN
+  if (!cc) {  // a pair without a free voxel: zeros (not stored in the compacted layout), none of the seven loads, nothing for the sums
+    if (!lineoff) st2(r + e, 0.0, 0.0);
+    if (p) st2(p + e, 0.0, 0.0);
+    continue;
+  }
   const Pair q = apply_pair(g, x, e, i, j, c0, c1);
   const double r0 = c0 ? -q.a : 0.0, r1 = c1 ? -q.b : 0.0;
   const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;
@@ -835,11 +840,13 @@ template <> struct PIo<float> {
   static __device__ __forceinline__ double rnd(double v) { return (double)(float)v; }
 };
 
+// p2 != null: a second term, x = (x + alpha_k p) + alpha_{k+1} p2 -- the two dependent additions two launches would make, x moved once
 template <typename PT>
 __global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ x, const PT* __restrict__ p,
                                                     const double* __restrict__ hist, int k, const int* __restrict__ lineoff,
-                                                    int LW) {
+                                                    int LW, const PT* __restrict__ p2) {
   const double alpha = safe_div(hist[H_STRIDE * k + H_RZ], hist[H_STRIDE * k + H_PQ]);
+  const double alpha2 = p2 ? safe_div(hist[H_STRIDE * (k + 1) + H_RZ], hist[H_STRIDE * (k + 1) + H_PQ]) : 0.0;
   const long long npairs = (long long)g.nzl * g.plane / 2;
   const int hp = g.pitch >> 1;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npairs;
@@ -853,7 +860,12 @@ __global__ void __launch_bounds__(256) k_axpy_hist(Geom g, double* __restrict__ 
       ev = (long long)kLV * lo + (i & (kLV - 1));
     }
     const double2 xv = ld2(x + e), pv = PIo<PT>::ld_pair(p + ev);
-    st2(x + e, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+    double x0 = xv.x + alpha * pv.x, x1 = xv.y + alpha * pv.y;
+    if (p2) {
+      const double2 qv = PIo<PT>::ld_pair(p2 + ev);
+      x0 = x0 + alpha2 * qv.x; x1 = x1 + alpha2 * qv.y;
+    }
+    st2(x + e, x0, x1);
   }
 }
 
@@ -890,11 +902,11 @@ void launch_axpy_ptr(const Geom& g, double* x, const void* p, int p_f32, const d
 }
 
 void launch_axpy_hist(const Geom& g, double* x, const void* p, int p_f32, const double* hist, int k, const int* lineoff,
-                      hipStream_t s) {
+                      hipStream_t s, const void* p_next) {
   const int blocks = cap_blocks((long long)g.nzl * g.plane / 2, 256, 2048);
   const int LW = (g.pitch + kLV - 1) / kLV;
-  if (p_f32) hipLaunchKernelGGL(k_axpy_hist<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, hist, k, lineoff, LW);
-  else hipLaunchKernelGGL(k_axpy_hist<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, hist, k, lineoff, LW);
+  if (p_f32) hipLaunchKernelGGL(k_axpy_hist<float>, dim3(blocks), dim3(256), 0, s, g, x, (const float*)p, hist, k, lineoff, LW, (const float*)p_next);
+  else hipLaunchKernelGGL(k_axpy_hist<double>, dim3(blocks), dim3(256), 0, s, g, x, (const double*)p, hist, k, lineoff, LW, (const double*)p_next);
 }
 
 // --------------------------------------------------------------------------------------

@@ -1358,9 +1358,15 @@ extern "C" oi_status oi_tort_cg_finish(oi_tort* h) {
     // (the same two dependent additions the kernel makes); p_j lives in p[j & 1] and neither buffer has been overwritten since
     const int m = done ? K - 1 : K;
     const int e = m < 0 ? 0 : (m & ~1);
-    for (int j = e; j < K; ++j) {
+    // (two terms pending: one pass over x)
+    if (K - e == 2) {
       PROF(K_AXPY);
-      launch_axpy_hist(h->g, h->x, h->p[j & 1], h->p_f32 ? 1 : 0, h->hist, j, h->lineoff, h->stream);
+      launch_axpy_hist(h->g, h->x, h->p[e & 1], h->p_f32 ? 1 : 0, h->hist, e, h->lineoff, h->stream, h->p[(e + 1) & 1]);
+    } else {
+      for (int j = e; j < K; ++j) {
+        PROF(K_AXPY);
+        launch_axpy_hist(h->g, h->x, h->p[j & 1], h->p_f32 ? 1 : 0, h->hist, j, h->lineoff, h->stream);
+      }
     }
   } else if (h->fused && !h->cg1 && K > 0 && !(h->rot && !done)) {
     // the fused variant applies x += alpha_{k} p_{k} inside iteration k+1: flush the last one
