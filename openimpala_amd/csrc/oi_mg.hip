@@ -1318,8 +1318,10 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   const int kfirst = 1;
   if (l == (int)Ls.size() - 1) {  // coarsest: a fixed number of damped-Jacobi sweeps, the last one lands in `out`
     // (periodic levels: on one rank only -- a ring of slabs exchanges the planes of a replicated level through the transport)
-    if ((mg->periodic ? !mg->comm : (!mg->comm || L.replicated)) && !L.compact && !mg->coarsest_plain && L.d.sz * L.d.nzl <= 512 && L.d.sz <= 512) {
-      hipLaunchKernelGGL((k_mg_coarsest<float, float>), dim3(1), dim3(512), 0, s, L.dev<float, float>(), rhs, out, kCoarsestSweeps);
+    // (a hierarchy of three levels or fewer -- volumes up to 64^3, REV samples -- ends on a byte / 16-bit level: the same kernel on its types)
+    if ((mg->periodic ? !mg->comm : (!mg->comm || L.replicated)) && !mg->coarsest_plain && L.d.sz * L.d.nzl <= 512 && L.d.sz <= 512) {
+      if (L.compact) hipLaunchKernelGGL((k_mg_coarsest<uint8_t, uint16_t>), dim3(1), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, out, kCoarsestSweeps);
+      else hipLaunchKernelGGL((k_mg_coarsest<float, float>), dim3(1), dim3(512), 0, s, L.dev<float, float>(), rhs, out, kCoarsestSweeps);
       return mg->periodic ? ghost_exchange(mg, L, out, sizeof(float), s, true) : true;  // (the parent reads the image planes of the correction)
     }
     for (int it = 1; it <= kCoarsestSweeps; ++it) {
