@@ -480,12 +480,55 @@ __global__ void __launch_bounds__(256) k_mg_post4(LevelT<W, D> L, int kfirst, in
 // face neighbours from global memory (b, D and e of every neighbour: ~27 load instructions per four cells, cache hits, and the
 // kernel is bound by them: 0.65 ms on the 512^3 level of a 1024^3 solve against 0.3 ms for its bytes).  Here a block of 512 threads
 // owns a tile of 64 x 8 x 8 cells: x2 of the tile and of its six faces goes to LDS once (1.53 evaluations per cell instead of
-// 5.5), the stencil reads its neighbours there.  Same arithmetic in the same order: bit-identical to k_mg_post4 (option
-// mg_coarse_tiled = 0 keeps that kernel as the cross-check).  Out-of-domain positions hold zeros -- the value k_mg_post4 uses
+// 5.5), the stencil reads its neighbours there.  Same arithmetic in the same order: bit-identical to k_mg_post4 / k_mg_post (option
+// mg_coarse_tiled = 0 keeps those kernels as the cross-check).  Out-of-domain positions hold zeros -- the value k_mg_post4 uses
 // there; a periodic level finds the wrapped row / quad / column there, the image planes in the ghost planes as ever.
+// ANY nx (>= 64): the rows of a level whose nx is not a multiple of four start anywhere, so the quads are read and written through
+// under-aligned vector types (one instruction on this target), and the last quad of a row that ends past it moves the cells that
+// exist one by one -- k_mg_post4 needs nx % 4 == 0, and such levels (a 500^3 or 900^3 volume's first coarse level) fell back to
+// the one-cell kernels: 2.8 instead of 2.1 ms per iteration at 500^3 against 512^3.
 constexpr int kTX = 64, kTY = 8, kTZ = 8;       // cells of a tile
 constexpr int kTRP = kTX + 8;                    // LDS row pitch in floats: [3 pad | left halo | 64 cells | right halo | 3 pad]
 constexpr int kTPP = (kTY + 2) * kTRP;           // LDS plane pitch
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u_t __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned short us4u_t __attribute__((ext_vector_type(4), aligned(2)));
+typedef unsigned char uc4u_t __attribute__((ext_vector_type(4), aligned(1)));
+// the first nv (1 .. 4) of four consecutive values, the others 0
+__device__ __forceinline__ void ldq(const float* p, int nv, float (&v)[4]) {
+  if (nv == 4) { const f4u_t t = *reinterpret_cast<const f4u_t*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; return; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = c < nv ? p[c] : 0.f;
+}
+__device__ __forceinline__ void ldq(const uint16_t* p, int nv, float (&v)[4]) {
+  if (nv == 4) { const us4u_t t = *reinterpret_cast<const us4u_t*>(p); v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w; return; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = c < nv ? (float)p[c] : 0.f;
+}
+__device__ __forceinline__ void ldq(const uint8_t* p, int nv, float (&v)[4]) {
+  if (nv == 4) { const uc4u_t t = *reinterpret_cast<const uc4u_t*>(p); v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w; return; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = c < nv ? (float)p[c] : 0.f;
+}
+__device__ __forceinline__ void stq(float* p, int nv, float a, float b, float c, float d) {
+  if (nv == 4) { f4u_t t; t.x = a; t.y = b; t.z = c; t.w = d; *reinterpret_cast<f4u_t*>(p) = t; return; }
+  p[0] = a;
+  if (nv > 1) p[1] = b;
+  if (nv > 2) p[2] = c;
+}
+// the corrections of the two parents of a quad (the second one only where the quad reaches it)
+__device__ __forceinline__ float2 ldpar(const float* xc, const float* xc2, long long cm, int nv) {
+  float2 p;
+  if (nv > 2) {
+    const f2u_t t = *reinterpret_cast<const f2u_t*>(xc + cm);
+    p = make_float2(t.x, t.y);
+    if (xc2) { const f2u_t q = *reinterpret_cast<const f2u_t*>(xc2 + cm); p.x += q.x; p.y += q.y; }
+  } else {
+    p = make_float2(xc[cm], 0.f);
+    if (xc2) p.x += xc2[cm];
+  }
+  return p;
+}
 template <class W, class D>
 __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* __restrict__ b, const float* __restrict__ xc,
                                                     const float* __restrict__ xc2, Dims C, float scale, const float* __restrict__ xpre,
@@ -502,16 +545,16 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
   // where a position of the tile or of its faces lives: the wrapped index of a periodic level one step beyond an end, -1 = nowhere
   auto row_of = [&](int jj) { return (jj >= 0 && jj < L.ny) ? jj : (per && jj == -1 ? L.ny - 1 : (per && jj == L.ny ? 0 : -1)); };
   auto col_of = [&](int ii) { return (ii >= 0 && ii < L.nx) ? ii : (per && ii == -1 ? L.nx - 1 : (per && ii == L.nx ? 0 : -1)); };
-  // x2 of the four cells ii .. ii + 3 of row jj in plane kk (all inside the arrays)
-  auto x24 = [&](int ii, int jj, int kk, float (&o)[4]) {
+  auto nv_of = [&](int ii) { return L.nx - ii < 4 ? L.nx - ii : 4; };  // cells of the quad that starts at column ii (< nx)
+  // x2 of the cells ii .. ii + nv - 1 of row jj in plane kk (all inside the arrays), zeros behind them
+  auto x24 = [&](int ii, int jj, int kk, int nv, float (&o)[4]) {
     const long long mm = (long long)ii + sy * jj + sz * kk;
     float bb[4], dd[4];
-    ld4(L.diag + mm, dd);
+    ldq(L.diag + mm, nv, dd);
     if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
-    ld4((xpre ? xpre : b) + mm, bb);
+    ldq((xpre ? xpre : b) + mm, nv, bb);
     const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
-    float2 p = *reinterpret_cast<const float2*>(xc + cm);
-    if (xc2) { const float2 q = *reinterpret_cast<const float2*>(xc2 + cm); p.x += q.x; p.y += q.y; }
+    const float2 p = ldpar(xc, xc2, cm, nv);
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = xpre ? x21p(bb[c], dd[c], c < 2 ? p.x : p.y) : x21(bb[c], dd[c], c < 2 ? p.x : p.y);
   };
@@ -530,10 +573,12 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
   // ---- own quads: x2 to registers and LDS (a position outside the level: zeros, or what a periodic level wraps there) ----
   float dc[2][4], bc[2][4], cc[2][4];
   bool mine[2];
+  const int ii = i0 + 4 * tq;
+  const int nvq = ii < L.nx ? nv_of(ii) : 4;  // (a quad that starts exactly at the end of a periodic level is the wrapped quad 0: whole)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int lz = tz + 4 * u;
-    const int ii = i0 + 4 * tq, jj = j0 + ty, kk = k0 + lz;
+    const int jj = j0 + ty, kk = k0 + lz;
     mine[u] = ii < L.nx && jj < L.ny && kk <= L.nzl;
     const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);  // (a quad starts inside the level or exactly at its end)
     cc[u][0] = cc[u][1] = cc[u][2] = cc[u][3] = 0.f;
@@ -541,20 +586,25 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     if (iw >= 0 && jw >= 0 && kk <= L.nzl + 1) {
       if (mine[u]) {
         const long long m = (long long)ii + sy * jj + sz * kk;
-        ld4(L.diag + m, dc[u]);
+        ldq(L.diag + m, nvq, dc[u]);
         if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
-          ld4(b + m, bc[u]);
-          float xs[4];
-          if (xpre) ld4(xpre + m, xs);
+          ldq(b + m, nvq, bc[u]);
+          float xs[4] = {0.f, 0.f, 0.f, 0.f};
+          if (xpre) ldq(xpre + m, nvq, xs);
           const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
-          float2 p = *reinterpret_cast<const float2*>(xc + cm);
-          if (xc2) { const float2 q = *reinterpret_cast<const float2*>(xc2 + cm); p.x += q.x; p.y += q.y; }
+          const float2 p = ldpar(xc, xc2, cm, nvq);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             cc[u][c] = xpre ? x21p(xs[c], dc[u][c], c < 2 ? p.x : p.y) : x21(bc[u][c], dc[u][c], c < 2 ? p.x : p.y);
         }
+        // a row that ends inside this quad: the slot behind its last cell is that cell's +x neighbour -- column 0 of a periodic level
+        // (the open level keeps the zero k_mg_post4 uses there)
+        if (per && nvq < 4) {
+          const float wv = x2one(0, jj, kk);
+          if (nvq == 1) cc[u][1] = wv; else if (nvq == 2) cc[u][2] = wv; else cc[u][3] = wv;
+        }
       } else {
-        x24(iw, jw, kk, cc[u]);
+        x24(iw, jw, kk, iw == ii ? nvq : 4, cc[u]);
       }
     }
     *reinterpret_cast<float4*>(&T[lds_at(tq, ty, lz)]) = make_float4(cc[u][0], cc[u][1], cc[u][2], cc[u][3]);
@@ -566,10 +616,10 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     const int hq = tid & 15, side = (tid >> 4) & 1, a = (tid >> 5) & 7;
     const bool zface = tid >= 256;
     const int ly = zface ? a : (side ? kTY : -1), lz = zface ? (side ? kTZ : -1) : a;
-    const int ii = i0 + 4 * hq, jj = j0 + ly, kk = k0 + lz;
-    const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);
+    const int hi = i0 + 4 * hq, jj = j0 + ly, kk = k0 + lz;
+    const int iw = hi < L.nx ? hi : col_of(hi), jw = row_of(jj);
     h[0] = h[1] = h[2] = h[3] = 0.f;
-    if (iw >= 0 && jw >= 0 && kk >= 0 && kk <= L.nzl + 1) x24(iw, jw, kk, h);
+    if (iw >= 0 && jw >= 0 && kk >= 0 && kk <= L.nzl + 1) x24(iw, jw, kk, nv_of(iw), h);
     *reinterpret_cast<float4*>(&T[lds_at(hq, ly, lz)]) = make_float4(h[0], h[1], h[2], h[3]);
     // x faces: 8 planes x 8 rows x 2 sides, one cell each (threads 0 .. 127)
     if (tid < 128) {
@@ -587,11 +637,14 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
   for (int u = 0; u < 2; ++u) {
     if (!mine[u]) continue;
     const int lz = tz + 4 * u;
-    const int i = i0 + 4 * tq, j = j0 + ty, k = k0 + lz;
+    const int i = ii, j = j0 + ty, k = k0 + lz;
     const long long m = (long long)i + sy * j + sz * k;
     if (!(dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f)) {
-      *reinterpret_cast<float4*>(out + m) = make_float4(0.f, 0.f, 0.f, 0.f);
-      OI_MG_IMG(L, out, m, k, float4, make_float4(0.f, 0.f, 0.f, 0.f));
+      stq(out + m, nvq, 0.f, 0.f, 0.f, 0.f);
+      if (L.zimg) {
+        if (k == 1) stq(out + m + L.sz * L.nzl, nvq, 0.f, 0.f, 0.f, 0.f);
+        if (k == L.nzl) stq(out + m - L.sz * L.nzl, nvq, 0.f, 0.f, 0.f, 0.f);
+      }
       continue;
     }
     const int pos = lds_at(tq, ty, lz);
@@ -603,7 +656,7 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     const long long mxm = (per && i == 0) ? m + (L.nx - 1) : m - 1;
     const long long mym = (per && j == 0) ? m + sy * (L.ny - 1) : m - sy;
     float wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
-    ld4(L.wx + m, wxc); ld4(L.wy + m, wyc); ld4(L.wy + mym, wym); ld4(L.wz + m, wzc); ld4(L.wz + (m - sz), wzm);
+    ldq(L.wx + m, nvq, wxc); ldq(L.wy + m, nvq, wyc); ldq(L.wy + mym, nvq, wym); ldq(L.wz + m, nvq, wzc); ldq(L.wz + (m - sz), nvq, wzm);
     const float wxl = (float)L.wx[mxm];
     float o[4];
 #pragma unroll
@@ -619,8 +672,11 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
         o[c] = cc[u][c] + L.omega * (bc[u][c] - (dc[u][c] * cc[u][c] - s)) * rcp(dc[u][c]);
       }
     }
-    *reinterpret_cast<float4*>(out + m) = make_float4(o[0], o[1], o[2], o[3]);
-    OI_MG_IMG(L, out, m, k, float4, make_float4(o[0], o[1], o[2], o[3]));
+    stq(out + m, nvq, o[0], o[1], o[2], o[3]);
+    if (L.zimg) {
+      if (k == 1) stq(out + m + L.sz * L.nzl, nvq, o[0], o[1], o[2], o[3]);
+      if (k == L.nzl) stq(out + m - L.sz * L.nzl, nvq, o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -646,25 +702,32 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
   auto xs1 = [&](float bb, float dd) -> float { return dd > 0.f ? L.omega * bb * rcp(dd) : 0.f; };
   auto row_of = [&](int jj) { return (jj >= 0 && jj < L.ny) ? jj : (per && jj == -1 ? L.ny - 1 : (per && jj == L.ny ? 0 : -1)); };
   auto col_of = [&](int ii) { return (ii >= 0 && ii < L.nx) ? ii : (per && ii == -1 ? L.nx - 1 : (per && ii == L.nx ? 0 : -1)); };
-  auto u4 = [&](int ii, int jj, int kk, float (&o)[4]) {
+  auto nv_of = [&](int ii) { return L.nx - ii < 4 ? L.nx - ii : 4; };
+  auto u4 = [&](int ii, int jj, int kk, int nv, float (&o)[4]) {
     const long long mm = (long long)ii + sy * jj + sz * kk;
-    if (SRC == 1) { ld4(x + mm, o); return; }
+    if (SRC == 1) { ldq(x + mm, nv, o); return; }
     float bb[4], dd[4];
-    ld4(L.diag + mm, dd);
+    ldq(L.diag + mm, nv, dd);
     if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
-    ld4(b + mm, bb);
+    ldq(b + mm, nv, bb);
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = xs1(bb[c], dd[c]);
+  };
+  auto u1 = [&](int ii, int jj, int kk) -> float {
+    const long long mm = (long long)ii + sy * jj + sz * kk;
+    return SRC == 1 ? x[mm] : xs1(b[mm], (float)L.diag[mm]);
   };
   const int tid = threadIdx.x;
   const int tq = tid & 15, ty = (tid >> 4) & 7, tz = tid >> 7;
   auto lds_at = [&](int lq, int ly, int lz) { return (lz + 1) * kTPP + (ly + 1) * kTRP + 4 + 4 * lq; };
   float dc[2][4], bc[2][4], uc[2][4];
   bool mine[2];
+  const int ii = i0 + 4 * tq;
+  const int nvq = ii < L.nx ? nv_of(ii) : 4;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int lz = tz + 4 * u;
-    const int ii = i0 + 4 * tq, jj = j0 + ty, kk = k0 + lz;
+    const int jj = j0 + ty, kk = k0 + lz;
     mine[u] = ii < L.nx && jj < L.ny && kk <= L.nzl;
     const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);
     uc[u][0] = uc[u][1] = uc[u][2] = uc[u][3] = 0.f;
@@ -673,20 +736,24 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
     if (iw >= 0 && jw >= 0 && kk <= L.nzl + 1) {
       if (mine[u]) {
         const long long m = (long long)ii + sy * jj + sz * kk;
-        ld4(L.diag + m, dc[u]);
+        ldq(L.diag + m, nvq, dc[u]);
         if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
-          ld4(b + m, bc[u]);
+          ldq(b + m, nvq, bc[u]);
           if (SRC == 1) {
-            ld4(x + m, uc[u]);
+            ldq(x + m, nvq, uc[u]);
           } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) uc[u][c] = xs1(bc[u][c], dc[u][c]);
           }
         } else if (SRC == 1) {
-          ld4(x + m, uc[u]);  // (a stored iterate is what it is, also where no cell has a row: the neighbours read it from the tile)
+          ldq(x + m, nvq, uc[u]);  // (a stored iterate is what it is, also where no cell has a row: the neighbours read it from the tile)
+        }
+        if (per && nvq < 4) {  // (the slot behind the row's last cell: column 0 of a periodic level, see k_mg_post4t)
+          const float wv = u1(0, jj, kk);
+          if (nvq == 1) uc[u][1] = wv; else if (nvq == 2) uc[u][2] = wv; else uc[u][3] = wv;
         }
       } else {
-        u4(iw, jw, kk, uc[u]);
+        u4(iw, jw, kk, iw == ii ? nvq : 4, uc[u]);
       }
     }
     *reinterpret_cast<float4*>(&T[lds_at(tq, ty, lz)]) = make_float4(uc[u][0], uc[u][1], uc[u][2], uc[u][3]);
@@ -696,20 +763,17 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
     const int hq = tid & 15, side = (tid >> 4) & 1, a = (tid >> 5) & 7;
     const bool zface = tid >= 256;
     const int ly = zface ? a : (side ? kTY : -1), lz = zface ? (side ? kTZ : -1) : a;
-    const int ii = i0 + 4 * hq, jj = j0 + ly, kk = k0 + lz;
-    const int iw = ii < L.nx ? ii : col_of(ii), jw = row_of(jj);
+    const int hi = i0 + 4 * hq, jj = j0 + ly, kk = k0 + lz;
+    const int iw = hi < L.nx ? hi : col_of(hi), jw = row_of(jj);
     h[0] = h[1] = h[2] = h[3] = 0.f;
-    if (iw >= 0 && jw >= 0 && kk >= 0 && kk <= L.nzl + 1) u4(iw, jw, kk, h);
+    if (iw >= 0 && jw >= 0 && kk >= 0 && kk <= L.nzl + 1) u4(iw, jw, kk, nv_of(iw), h);
     *reinterpret_cast<float4*>(&T[lds_at(hq, ly, lz)]) = make_float4(h[0], h[1], h[2], h[3]);
     if (tid < 128) {
       const int xs_ = tid & 1, xy = (tid >> 1) & 7, xz = tid >> 4;
       const int xi = xs_ ? i0 + kTX : i0 - 1, xj = j0 + xy, xk = k0 + xz;
       const int xiw = col_of(xi);
       float v = 0.f;
-      if (xiw >= 0 && xj < L.ny && xk <= L.nzl + 1) {
-        const long long mm = (long long)xiw + sy * xj + sz * xk;
-        v = SRC == 1 ? x[mm] : xs1(b[mm], (float)L.diag[mm]);
-      }
+      if (xiw >= 0 && xj < L.ny && xk <= L.nzl + 1) v = u1(xiw, xj, xk);
       T[(xz + 1) * kTPP + (xy + 1) * kTRP + (xs_ ? 4 + kTX : 3)] = v;
     }
   }
@@ -718,7 +782,7 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
   for (int u = 0; u < 2; ++u) {
     const int lz = tz + 4 * u;
     float res[4] = {0.f, 0.f, 0.f, 0.f};
-    const int i = i0 + 4 * tq, j = j0 + ty, k = k0 + lz;
+    const int i = ii, j = j0 + ty, k = k0 + lz;
     const long long m = (long long)i + sy * j + sz * k;
     const bool live = mine[u] && (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f);
     if (live) {
@@ -731,7 +795,7 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
       const long long mxm = (per && i == 0) ? m + (L.nx - 1) : m - 1;
       const long long mym = (per && j == 0) ? m + sy * (L.ny - 1) : m - sy;
       float wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
-      ld4(L.wx + m, wxc); ld4(L.wy + m, wyc); ld4(L.wy + mym, wym); ld4(L.wz + m, wzc); ld4(L.wz + (m - sz), wzm);
+      ldq(L.wx + m, nvq, wxc); ldq(L.wy + m, nvq, wyc); ldq(L.wy + mym, nvq, wym); ldq(L.wz + m, nvq, wzc); ldq(L.wz + (m - sz), nvq, wzm);
       const float wxl = (float)L.wx[mxm];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -749,8 +813,11 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
     }
     if (RESTRICT) *reinterpret_cast<float4*>(&R[((lz * kTY) + ty) * kTX + 4 * tq]) = make_float4(res[0], res[1], res[2], res[3]);
     else if (mine[u]) {
-      *reinterpret_cast<float4*>(r + m) = make_float4(res[0], res[1], res[2], res[3]);
-      OI_MG_IMG(L, r, m, k, float4, make_float4(res[0], res[1], res[2], res[3]));
+      stq(r + m, nvq, res[0], res[1], res[2], res[3]);
+      if (L.zimg) {
+        if (k == 1) stq(r + m + L.sz * L.nzl, nvq, res[0], res[1], res[2], res[3]);
+        if (k == L.nzl) stq(r + m - L.sz * L.nzl, nvq, res[0], res[1], res[2], res[3]);
+      }
     }
   }
   if (RESTRICT) {
@@ -772,8 +839,13 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
         }
         const int cp = ((L.z0 + kf - 1) >> 1) - C.z0 + 1;
         const long long cm = (long long)I + (long long)C.nx * J + C.sz * cp;
-        *reinterpret_cast<float2*>(bcoarse + cm) = make_float2(o[0], o[1]);
-        OI_MG_IMG(C, bcoarse, cm, cp, float2, make_float2(o[0], o[1]));
+        const bool two_cells = I + 1 < C.nx;  // (nx % 4 == 2: the row's last quad holds one coarse cell)
+        bcoarse[cm] = o[0];
+        if (two_cells) bcoarse[cm + 1] = o[1];
+        if (C.zimg) {
+          if (cp == 1) { bcoarse[cm + C.sz * C.nzl] = o[0]; if (two_cells) bcoarse[cm + 1 + C.sz * C.nzl] = o[1]; }
+          if (cp == C.nzl) { bcoarse[cm - C.sz * C.nzl] = o[0]; if (two_cells) bcoarse[cm + 1 - C.sz * C.nzl] = o[1]; }
+        }
       }
     }
   }
@@ -1336,6 +1408,11 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   MgLevelHost& C = Ls[l + 1];
   // byte / 16-bit levels whose rows split into groups of four cells take the four-cells-per-thread kernels
   const bool vec4 = L.compact && (L.d.nx & 3) == 0 && L.d.nx >= 64 && !mg->novec4;
+  // (the LDS-tiled kernels take any nx: under-aligned quads, the last one of a row cell by cell)
+  const bool quads = L.compact && L.d.nx >= 64 && !mg->novec4 && L.d.nzl >= 1;
+  // from how many cells on: where the four-cell kernels run (nx % 4 == 0) they hold up to 2^21 cells; against the one-cell kernels
+  // the tile pays from 2^17 cells on (a 500^3 volume's second coarse level, 125^3: profiles/r04/size_scan.txt)
+  const long long tile_from = mg->coarse_tiled > 1 ? 0 : (vec4 ? (1ll << 21) : (1ll << 17));
   const int blocks4 = (int)((((long long)(L.d.nx >> 2) * L.d.ny * L.d.nzl) + 255) / 256);
   const bool two = mg->nu_coarse > 1;  // two sweeps before and two after the correction
   // blocks of 4 x 2 x 2 cells per thread, the restriction in registers: open problem, the whole level and its child on this rank,
@@ -1347,12 +1424,12 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   hipLaunchKernelGGL((k_mg_lin4<uint8_t, uint16_t, SRC, OUT>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), \
                      kfirst, L.d.nzl, B, X, DST)
   // big levels: through the LDS tile (k_mg_lin4t), with the restriction inside where the level's extents allow it -- periodic levels too
-  const bool tiled_pre = vec4 && blocks4 > 0 && !two && mg->coarse_tiled && ((long long)L.d.sz * L.d.nzl >= (1ll << 21) || mg->coarse_tiled > 1) && kfirst == 1;
+  const bool tiled_pre = quads && !two && mg->coarse_tiled && (long long)L.d.sz * L.d.nzl >= tile_from && kfirst == 1;
   const bool blkt = tiled_pre && mg->blocked && !mg->comm && (L.d.ny & 1) == 0 && (L.d.nzl & 1) == 0 && (L.d.z0 & 1) == 0 && !C.replicated &&
                     C.d.nx * 2 == L.d.nx && C.d.ny * 2 == L.d.ny && C.d.nzl * 2 == L.d.nzl && C.d.z0 * 2 == L.d.z0;
   const int ttx = (L.d.nx + kTX - 1) / kTX, tty = (L.d.ny + kTY - 1) / kTY, ttz = (L.d.nzl + kTZ - 1) / kTZ;
   // (two sweeps before and after the correction: the same tile for the three k_mg_lin4 steps of such a level)
-  const bool tiled2 = vec4 && blocks4 > 0 && two && mg->coarse_tiled && ((long long)L.d.sz * L.d.nzl >= (1ll << 21) || mg->coarse_tiled > 1) && kfirst == 1;
+  const bool tiled2 = quads && two && mg->coarse_tiled && (long long)L.d.sz * L.d.nzl >= tile_from && kfirst == 1;
 #define OI_MG_LIN4T(SRC, OUT, B, X, DST)                                                                                              \
   hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false, SRC, OUT>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), \
                      B, DST, C.d, (float*)nullptr, ttx, tty, X)
@@ -1394,7 +1471,7 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   const float* xpre = two ? L.t : nullptr;
   float* dst = two ? L.t2 : out;
   // (big levels: through an LDS tile of 64 x 8 x 8 cells, k_mg_post4t -- bit-identical)
-  const bool tiled = vec4 && blocks4 > 0 && mg->coarse_tiled && ((long long)L.d.sz * L.d.nzl >= (1ll << 21) || mg->coarse_tiled > 1) && kfirst == 1;
+  const bool tiled = quads && mg->coarse_tiled && (long long)L.d.sz * L.d.nzl >= tile_from && kfirst == 1;
   if (tiled) {
     const int tx_ = (L.d.nx + kTX - 1) / kTX, ty_ = (L.d.ny + kTY - 1) / kTY, tz_ = (L.d.nzl + kTZ - 1) / kTZ;
     hipLaunchKernelGGL((k_mg_post4t<uint8_t, uint16_t>), dim3(tx_ * ty_ * tz_), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.x2, second, C.d,

@@ -786,7 +786,8 @@ def test_readers_hand_out_page_locked_buffers_on_request():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nu", [1, 2])
-@pytest.mark.parametrize("shape", [(40, 72, 256), (48, 96, 384), (30, 50, 520), (17, 24, 136)])
+@pytest.mark.parametrize("shape", [(40, 72, 256), (48, 96, 384), (30, 50, 520), (17, 24, 136), (20, 24, 132), (12, 20, 134), (10, 18, 130),
+                                   (16, 24, 268), (9, 33, 139)])
 def test_multigrid_tiled_coarse_post_smoother_is_bit_identical(oi_option, shape, nu):
     """Round 4: on big byte / 16-bit levels the correction + post-smoothing step runs through an LDS tile of 64 x 8 x 8 cells
     (k_mg_post4t: the corrected iterate of the tile and its six faces is formed once instead of once per neighbour).  Same arithmetic in
@@ -794,7 +795,10 @@ def test_multigrid_tiled_coarse_post_smoother_is_bit_identical(oi_option, shape,
     and = 0 the flow-through solve and the three periodic cell problems give the same bits -- tiles that end inside the level in x, y
     and z (260 = 4 x 64 + 4 cells, 36 and 25 rows, 20 and 15 planes), the wrapped quad of a periodic level at the level's end.  The
     pre-smoothing residual (+ restriction) goes through the same tile (k_mg_lin4t), and with two sweeps per visit (`mg_nu_coarse` = 2)
-    its three other forms -- second Jacobi iterate, residual of a stored iterate, sweep on a stored iterate."""
+    its three other forms -- second Jacobi iterate, residual of a stored iterate, sweep on a stored iterate.  The tile takes ANY nx
+    (under-aligned quads, the last quad of a row cell by cell; k_mg_post4 / k_mg_lin4 need nx % 4 == 0 and such levels ran the one-cell
+    kernels): first coarse levels of 66, 67, 65, 134 and 70 cells per row against the one-cell kernels, open and periodic (the wrapped
+    column 0 in the slot behind a row's last cell)."""
     oi_option("mg_nu_coarse", nu)
     import openimpala_amd as oia
     rng = np.random.default_rng(5)

@@ -6,7 +6,7 @@ import numpy as np
 import openimpala_amd as oia
 rng = np.random.default_rng(5)
 ok = True
-for shape in [(40, 72, 256), (33, 70, 132), (64, 64, 64), (20, 130, 260), (9, 17, 68), (48, 96, 384)]:
+for shape in [(40, 72, 256), (33, 70, 132), (64, 64, 64), (20, 130, 260), (9, 17, 68), (48, 96, 384), (12, 20, 134), (10, 18, 130), (16, 24, 268), (24, 40, 300)]:
     ph = (rng.random(shape) < 0.75).astype(np.uint8)
     res = {}
     for v in (2, 0):
