@@ -1409,7 +1409,8 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   // byte / 16-bit levels whose rows split into groups of four cells take the four-cells-per-thread kernels
   const bool vec4 = L.compact && (L.d.nx & 3) == 0 && L.d.nx >= 64 && !mg->novec4;
   // (the LDS-tiled kernels take any nx: under-aligned quads, the last one of a row cell by cell)
-  const bool quads = L.compact && L.d.nx >= 64 && !mg->novec4 && L.d.nzl >= 1;
+  const bool quads = L.compact && L.d.nx >= 8 && !mg->novec4 && L.d.nzl >= 1;  // (a narrow level fills part of the tile's 16 quads per row: still far
+                                                                                 // fewer loads than the one-cell kernels, whose blocks are row segments of 256)
   // from how many cells on: where the four-cell kernels run (nx % 4 == 0) they hold up to 2^21 cells; against the one-cell kernels
   // the tile pays from 2^17 cells on (a 500^3 volume's second coarse level, 125^3: profiles/r04/size_scan.txt)
   const long long tile_from = mg->coarse_tiled > 1 ? 0 : (vec4 ? (1ll << 21) : (1ll << 17));

@@ -787,7 +787,7 @@ def test_readers_hand_out_page_locked_buffers_on_request():
 @pytest.mark.gpu
 @pytest.mark.parametrize("nu", [1, 2])
 @pytest.mark.parametrize("shape", [(40, 72, 256), (48, 96, 384), (30, 50, 520), (17, 24, 136), (20, 24, 132), (12, 20, 134), (10, 18, 130),
-                                   (16, 24, 268), (9, 33, 139)])
+                                   (16, 24, 268), (9, 33, 139), (24, 40, 40), (30, 64, 22), (16, 200, 18)])
 def test_multigrid_tiled_coarse_post_smoother_is_bit_identical(oi_option, shape, nu):
     """Round 4: on big byte / 16-bit levels the correction + post-smoothing step runs through an LDS tile of 64 x 8 x 8 cells
     (k_mg_post4t: the corrected iterate of the tile and its six faces is formed once instead of once per neighbour).  Same arithmetic in
