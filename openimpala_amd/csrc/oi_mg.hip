@@ -529,7 +529,25 @@ __device__ __forceinline__ float2 ldpar(const float* xc, const float* xc2, long 
   }
   return p;
 }
-template <class W, class D>
+// AL (a template parameter of the tiled kernels): nx % 4 == 0 -- every quad is whole and 16-byte aligned, the loads and stores are the
+// aligned vector ones (the under-aligned types above compile to one instruction per ELEMENT: fine for the levels that would otherwise
+// run the one-cell kernels, 10 % of the cycle lost on the levels that need none of it)
+template <bool AL, class P>
+__device__ __forceinline__ void ldqa(const P* p, int nv, float (&v)[4]) {
+  if (AL) ld4(p, v); else ldq(p, nv, v);
+}
+template <bool AL>
+__device__ __forceinline__ void stqa(float* p, int nv, float a, float b, float c, float d) {
+  if (AL) *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); else stq(p, nv, a, b, c, d);
+}
+template <bool AL>
+__device__ __forceinline__ float2 ldpara(const float* xc, const float* xc2, long long cm, int nv) {
+  if (!AL) return ldpar(xc, xc2, cm, nv);
+  float2 p = *reinterpret_cast<const float2*>(xc + cm);
+  if (xc2) { const float2 q = *reinterpret_cast<const float2*>(xc2 + cm); p.x += q.x; p.y += q.y; }
+  return p;
+}
+template <class W, class D, bool AL>
 __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* __restrict__ b, const float* __restrict__ xc,
                                                     const float* __restrict__ xc2, Dims C, float scale, const float* __restrict__ xpre,
                                                     float* __restrict__ out, int tiles_x, int tiles_y) {
@@ -550,11 +568,11 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
   auto x24 = [&](int ii, int jj, int kk, int nv, float (&o)[4]) {
     const long long mm = (long long)ii + sy * jj + sz * kk;
     float bb[4], dd[4];
-    ldq(L.diag + mm, nv, dd);
+    ldqa<AL>(L.diag + mm, nv, dd);
     if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
-    ldq((xpre ? xpre : b) + mm, nv, bb);
+    ldqa<AL>((xpre ? xpre : b) + mm, nv, bb);
     const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
-    const float2 p = ldpar(xc, xc2, cm, nv);
+    const float2 p = ldpara<AL>(xc, xc2, cm, nv);
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = xpre ? x21p(bb[c], dd[c], c < 2 ? p.x : p.y) : x21(bb[c], dd[c], c < 2 ? p.x : p.y);
   };
@@ -586,13 +604,13 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     if (iw >= 0 && jw >= 0 && kk <= L.nzl + 1) {
       if (mine[u]) {
         const long long m = (long long)ii + sy * jj + sz * kk;
-        ldq(L.diag + m, nvq, dc[u]);
+        ldqa<AL>(L.diag + m, nvq, dc[u]);
         if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
-          ldq(b + m, nvq, bc[u]);
+          ldqa<AL>(b + m, nvq, bc[u]);
           float xs[4] = {0.f, 0.f, 0.f, 0.f};
-          if (xpre) ldq(xpre + m, nvq, xs);
+          if (xpre) ldqa<AL>(xpre + m, nvq, xs);
           const long long cm = (long long)(ii >> 1) + (long long)C.nx * (jj >> 1) + C.sz * parent_plane(L, C, kk);
-          const float2 p = ldpar(xc, xc2, cm, nvq);
+          const float2 p = ldpara<AL>(xc, xc2, cm, nvq);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             cc[u][c] = xpre ? x21p(xs[c], dc[u][c], c < 2 ? p.x : p.y) : x21(bc[u][c], dc[u][c], c < 2 ? p.x : p.y);
@@ -640,10 +658,10 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     const int i = ii, j = j0 + ty, k = k0 + lz;
     const long long m = (long long)i + sy * j + sz * k;
     if (!(dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f)) {
-      stq(out + m, nvq, 0.f, 0.f, 0.f, 0.f);
+      stqa<AL>(out + m, nvq, 0.f, 0.f, 0.f, 0.f);
       if (L.zimg) {
-        if (k == 1) stq(out + m + L.sz * L.nzl, nvq, 0.f, 0.f, 0.f, 0.f);
-        if (k == L.nzl) stq(out + m - L.sz * L.nzl, nvq, 0.f, 0.f, 0.f, 0.f);
+        if (k == 1) stqa<AL>(out + m + L.sz * L.nzl, nvq, 0.f, 0.f, 0.f, 0.f);
+        if (k == L.nzl) stqa<AL>(out + m - L.sz * L.nzl, nvq, 0.f, 0.f, 0.f, 0.f);
       }
       continue;
     }
@@ -656,7 +674,7 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
     const long long mxm = (per && i == 0) ? m + (L.nx - 1) : m - 1;
     const long long mym = (per && j == 0) ? m + sy * (L.ny - 1) : m - sy;
     float wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
-    ldq(L.wx + m, nvq, wxc); ldq(L.wy + m, nvq, wyc); ldq(L.wy + mym, nvq, wym); ldq(L.wz + m, nvq, wzc); ldq(L.wz + (m - sz), nvq, wzm);
+    ldqa<AL>(L.wx + m, nvq, wxc); ldqa<AL>(L.wy + m, nvq, wyc); ldqa<AL>(L.wy + mym, nvq, wym); ldqa<AL>(L.wz + m, nvq, wzc); ldqa<AL>(L.wz + (m - sz), nvq, wzm);
     const float wxl = (float)L.wx[mxm];
     float o[4];
 #pragma unroll
@@ -672,10 +690,10 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
         o[c] = cc[u][c] + L.omega * (bc[u][c] - (dc[u][c] * cc[u][c] - s)) * rcp(dc[u][c]);
       }
     }
-    stq(out + m, nvq, o[0], o[1], o[2], o[3]);
+    stqa<AL>(out + m, nvq, o[0], o[1], o[2], o[3]);
     if (L.zimg) {
-      if (k == 1) stq(out + m + L.sz * L.nzl, nvq, o[0], o[1], o[2], o[3]);
-      if (k == L.nzl) stq(out + m - L.sz * L.nzl, nvq, o[0], o[1], o[2], o[3]);
+      if (k == 1) stqa<AL>(out + m + L.sz * L.nzl, nvq, o[0], o[1], o[2], o[3]);
+      if (k == L.nzl) stqa<AL>(out + m - L.sz * L.nzl, nvq, o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -687,7 +705,7 @@ __global__ void __launch_bounds__(512) k_mg_post4t(LevelT<W, D> L, const float* 
 // (+ k_mg_restrict) and to k_mg_lin4r.
 // SRC / OUT as in k_mg_lin4: u = w b / D formed on the fly (SRC 0) or a stored vector x (SRC 1); the result is res (OUT 0) or the
 // smoothed u + w res / D (OUT 1) -- the four steps of a level that runs two sweeps before and after the correction.
-template <class W, class D, bool RESTRICT, int SRC = 0, int OUT = 0>
+template <class W, class D, bool AL, bool RESTRICT, int SRC = 0, int OUT = 0>
 __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* __restrict__ b, float* __restrict__ r, Dims C,
                                                    float* __restrict__ bcoarse, int tiles_x, int tiles_y, const float* __restrict__ x = nullptr) {
   static_assert(!RESTRICT || (SRC == 0 && OUT == 0), "the restriction takes the pre-smoothing residual");
@@ -705,11 +723,11 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
   auto nv_of = [&](int ii) { return L.nx - ii < 4 ? L.nx - ii : 4; };
   auto u4 = [&](int ii, int jj, int kk, int nv, float (&o)[4]) {
     const long long mm = (long long)ii + sy * jj + sz * kk;
-    if (SRC == 1) { ldq(x + mm, nv, o); return; }
+    if (SRC == 1) { ldqa<AL>(x + mm, nv, o); return; }
     float bb[4], dd[4];
-    ldq(L.diag + mm, nv, dd);
+    ldqa<AL>(L.diag + mm, nv, dd);
     if (!(dd[0] > 0.f || dd[1] > 0.f || dd[2] > 0.f || dd[3] > 0.f)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
-    ldq(b + mm, nv, bb);
+    ldqa<AL>(b + mm, nv, bb);
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = xs1(bb[c], dd[c]);
   };
@@ -736,17 +754,17 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
     if (iw >= 0 && jw >= 0 && kk <= L.nzl + 1) {
       if (mine[u]) {
         const long long m = (long long)ii + sy * jj + sz * kk;
-        ldq(L.diag + m, nvq, dc[u]);
+        ldqa<AL>(L.diag + m, nvq, dc[u]);
         if (dc[u][0] > 0.f || dc[u][1] > 0.f || dc[u][2] > 0.f || dc[u][3] > 0.f) {
-          ldq(b + m, nvq, bc[u]);
+          ldqa<AL>(b + m, nvq, bc[u]);
           if (SRC == 1) {
-            ldq(x + m, nvq, uc[u]);
+            ldqa<AL>(x + m, nvq, uc[u]);
           } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) uc[u][c] = xs1(bc[u][c], dc[u][c]);
           }
         } else if (SRC == 1) {
-          ldq(x + m, nvq, uc[u]);  // (a stored iterate is what it is, also where no cell has a row: the neighbours read it from the tile)
+          ldqa<AL>(x + m, nvq, uc[u]);  // (a stored iterate is what it is, also where no cell has a row: the neighbours read it from the tile)
         }
         if (per && nvq < 4) {  // (the slot behind the row's last cell: column 0 of a periodic level, see k_mg_post4t)
           const float wv = u1(0, jj, kk);
@@ -795,7 +813,7 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
       const long long mxm = (per && i == 0) ? m + (L.nx - 1) : m - 1;
       const long long mym = (per && j == 0) ? m + sy * (L.ny - 1) : m - sy;
       float wxc[4], wyc[4], wym[4], wzc[4], wzm[4];
-      ldq(L.wx + m, nvq, wxc); ldq(L.wy + m, nvq, wyc); ldq(L.wy + mym, nvq, wym); ldq(L.wz + m, nvq, wzc); ldq(L.wz + (m - sz), nvq, wzm);
+      ldqa<AL>(L.wx + m, nvq, wxc); ldqa<AL>(L.wy + m, nvq, wyc); ldqa<AL>(L.wy + mym, nvq, wym); ldqa<AL>(L.wz + m, nvq, wzc); ldqa<AL>(L.wz + (m - sz), nvq, wzm);
       const float wxl = (float)L.wx[mxm];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -813,10 +831,10 @@ __global__ void __launch_bounds__(512) k_mg_lin4t(LevelT<W, D> L, const float* _
     }
     if (RESTRICT) *reinterpret_cast<float4*>(&R[((lz * kTY) + ty) * kTX + 4 * tq]) = make_float4(res[0], res[1], res[2], res[3]);
     else if (mine[u]) {
-      stq(r + m, nvq, res[0], res[1], res[2], res[3]);
+      stqa<AL>(r + m, nvq, res[0], res[1], res[2], res[3]);
       if (L.zimg) {
-        if (k == 1) stq(r + m + L.sz * L.nzl, nvq, res[0], res[1], res[2], res[3]);
-        if (k == L.nzl) stq(r + m - L.sz * L.nzl, nvq, res[0], res[1], res[2], res[3]);
+        if (k == 1) stqa<AL>(r + m + L.sz * L.nzl, nvq, res[0], res[1], res[2], res[3]);
+        if (k == L.nzl) stqa<AL>(r + m - L.sz * L.nzl, nvq, res[0], res[1], res[2], res[3]);
       }
     }
   }
@@ -1413,6 +1431,7 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
                                                                                  // fewer loads than the one-cell kernels, whose blocks are row segments of 256)
   // from how many cells on: where the four-cell kernels run (nx % 4 == 0) they hold up to 2^21 cells; against the one-cell kernels
   // the tile pays from 2^17 cells on (a 500^3 volume's second coarse level, 125^3: profiles/r04/size_scan.txt)
+  const bool al4 = (L.d.nx & 3) == 0;  // whole, aligned quads: the tiled kernels' aligned instantiations
   const long long tile_from = mg->coarse_tiled > 1 ? 0 : (vec4 ? (1ll << 21) : (1ll << 17));
   const int blocks4 = (int)((((long long)(L.d.nx >> 2) * L.d.ny * L.d.nzl) + 255) / 256);
   const bool two = mg->nu_coarse > 1;  // two sweeps before and two after the correction
@@ -1432,14 +1451,20 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   // (two sweeps before and after the correction: the same tile for the three k_mg_lin4 steps of such a level)
   const bool tiled2 = quads && two && mg->coarse_tiled && (long long)L.d.sz * L.d.nzl >= tile_from && kfirst == 1;
 #define OI_MG_LIN4T(SRC, OUT, B, X, DST)                                                                                              \
-  hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false, SRC, OUT>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), \
-                     B, DST, C.d, (float*)nullptr, ttx, tty, X)
+  do {                                                                                                                                \
+    if (al4) hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, true, false, SRC, OUT>), dim3(ttx * tty * ttz), dim3(512), 0, s,        \
+                                L.dev<uint8_t, uint16_t>(), B, DST, C.d, (float*)nullptr, ttx, tty, X);                                \
+    else hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false, false, SRC, OUT>), dim3(ttx * tty * ttz), dim3(512), 0, s,          \
+                            L.dev<uint8_t, uint16_t>(), B, DST, C.d, (float*)nullptr, ttx, tty, X);                                    \
+  } while (0)
   if (blkt) {
-    hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, true>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, (float*)nullptr, C.d, C.b, ttx, tty);
+    if (al4) hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, true, true>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, (float*)nullptr, C.d, C.b, ttx, tty);
+    else hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false, true>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, (float*)nullptr, C.d, C.b, ttx, tty);
   } else if (blk) {  // pre-smoothing residual and its restriction in one launch; no residual array
     hipLaunchKernelGGL((k_mg_lin4r<uint8_t, uint16_t>), dim3(blocks8), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.d, C.b);
   } else if (!two) {
-    if (tiled_pre) hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, L.r, C.d, (float*)nullptr, ttx, tty);
+    if (tiled_pre && al4) hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, true, false>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, L.r, C.d, (float*)nullptr, ttx, tty);
+    else if (tiled_pre) hipLaunchKernelGGL((k_mg_lin4t<uint8_t, uint16_t, false, false>), dim3(ttx * tty * ttz), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, L.r, C.d, (float*)nullptr, ttx, tty);
     else if (vec4 && blocks4 > 0) OI_MG_LIN4(0, 0, rhs, (const float*)nullptr, L.r);
     else OI_MG_LAUNCH(k_mg_pre, L, L.d.nzl, s, kfirst, rhs, L.r);
   } else {
@@ -1475,7 +1500,9 @@ static bool coarse_cycle(MgHierarchy* mg, int l, const float* rhs, float* out, h
   const bool tiled = quads && mg->coarse_tiled && (long long)L.d.sz * L.d.nzl >= tile_from && kfirst == 1;
   if (tiled) {
     const int tx_ = (L.d.nx + kTX - 1) / kTX, ty_ = (L.d.ny + kTY - 1) / kTY, tz_ = (L.d.nzl + kTZ - 1) / kTZ;
-    hipLaunchKernelGGL((k_mg_post4t<uint8_t, uint16_t>), dim3(tx_ * ty_ * tz_), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.x2, second, C.d,
+    if (al4) hipLaunchKernelGGL((k_mg_post4t<uint8_t, uint16_t, true>), dim3(tx_ * ty_ * tz_), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.x2, second, C.d,
+                       mg->scale, xpre, dst, tx_, ty_);
+    else hipLaunchKernelGGL((k_mg_post4t<uint8_t, uint16_t, false>), dim3(tx_ * ty_ * tz_), dim3(512), 0, s, L.dev<uint8_t, uint16_t>(), rhs, C.x2, second, C.d,
                        mg->scale, xpre, dst, tx_, ty_);
   } else if (vec4 && blocks4 > 0)
     hipLaunchKernelGGL((k_mg_post4<uint8_t, uint16_t>), dim3(blocks4), dim3(256), 0, s, L.dev<uint8_t, uint16_t>(), kfirst, L.d.nzl, rhs,
