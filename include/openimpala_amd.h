@@ -184,7 +184,7 @@ oi_status oi_effdiff_get_chi(oi_effdiff* h, int dir_k, double* chi);
 oi_status oi_effdiff_tensor(oi_effdiff* h, double* deff9 /* row-major 3x3, D_eff / D_material */);
 oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int* iterations3, double* relres3);
 /* *compacted = 1: the CG vectors hold only the 8-voxel lines with an active cell and the solves run the flow-through path's
- * rotated multigrid iteration (one GPU, multigrid preconditioner); *vector_elements = doubles per vector */
+ * rotated multigrid iteration (multigrid preconditioner; one GPU, or a ring whose slabs all start on an even plane); *vector_elements = doubles per vector */
 oi_status oi_effdiff_layout(const oi_effdiff* h, int* compacted, int64_t* vector_elements);
 void oi_effdiff_destroy(oi_effdiff* h);
 

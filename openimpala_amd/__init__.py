@@ -671,7 +671,7 @@ class EffectiveDiffusivityMI355:
 
     def layout(self):
         """(compacted, doubles per CG vector): compacted = True when the solves run on line-compacted vectors with the rotated
-        multigrid iteration (one GPU, multigrid preconditioner), False on dense vectors (rings of slabs, precond = none)."""
+        multigrid iteration (multigrid preconditioner; one GPU or a ring of slabs that start on even planes), False on dense vectors."""
         c, n = C.c_int(), C.c_int64()
         _check(lib().oi_effdiff_layout(self._h, C.byref(c), C.byref(n)))
         return bool(c.value), n.value

@@ -106,6 +106,24 @@ struct RcclComm : oi_comm {
     NCCLC(ncclGroupEnd());
     return OI_OK;
   }
+  oi_status exchange_ring_v(const void* send_lo, size_t n_send_lo, void* recv_lo, size_t n_recv_lo, const void* send_hi,
+                            size_t n_send_hi, void* recv_hi, size_t n_recv_hi, hipStream_t s) override {
+    if (size == 1) {
+      if (n_send_hi) HIPC(hipMemcpyAsync(recv_lo, send_hi, n_send_hi, hipMemcpyDeviceToDevice, s));
+      if (n_send_lo) HIPC(hipMemcpyAsync(recv_hi, send_lo, n_send_lo, hipMemcpyDeviceToDevice, s));
+      return OI_OK;
+    }
+    const int prev = (rank + size - 1) % size, next = (rank + 1) % size;
+    // (two ranks: both neighbours are the same peer, messages between a pair match in posting order -- sends (lo, hi),
+    // receives (hi, lo), as in exchange_ring; the lengths were agreed at set-up, so a skipped send meets a skipped receive)
+    NCCLC(ncclGroupStart());
+    if (n_send_lo) NCCLC(ncclSend(send_lo, n_send_lo, ncclInt8, prev, nccl_p2p, s));
+    if (n_send_hi) NCCLC(ncclSend(send_hi, n_send_hi, ncclInt8, next, nccl_p2p, s));
+    if (n_recv_hi) NCCLC(ncclRecv(recv_hi, n_recv_hi, ncclInt8, next, nccl_p2p, s));
+    if (n_recv_lo) NCCLC(ncclRecv(recv_lo, n_recv_lo, ncclInt8, prev, nccl_p2p, s));
+    NCCLC(ncclGroupEnd());
+    return OI_OK;
+  }
   // a one-rank communicator still goes through RCCL (identity): lets a single-GPU box
   // exercise the library's RCCL calls next to torch.distributed's own communicator
   oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) override {
@@ -242,6 +260,30 @@ struct LocalComm : oi_comm {
     HIPC(hipMemcpyAsync(recv_lo, sh->send_hi[prev], bytes, hipMemcpyDeviceToDevice, s));
     HIPC(hipStreamWaitEvent(s, sh->ev_ready[next], 0));
     HIPC(hipMemcpyAsync(recv_hi, sh->send_lo[next], bytes, hipMemcpyDeviceToDevice, s));
+    HIPC(hipEventRecord(sh->ev_done[rank], s));
+    sh->barrier();
+    HIPC(hipStreamWaitEvent(s, sh->ev_done[prev], 0));
+    HIPC(hipStreamWaitEvent(s, sh->ev_done[next], 0));
+    sh->barrier();
+    return OI_OK;
+  }
+  oi_status exchange_ring_v(const void* send_lo, size_t n_send_lo, void* recv_lo, size_t n_recv_lo, const void* send_hi,
+                            size_t n_send_hi, void* recv_hi, size_t n_recv_hi, hipStream_t s) override {
+    if (size == 1) {
+      if (n_send_hi) HIPC(hipMemcpyAsync(recv_lo, send_hi, n_send_hi, hipMemcpyDeviceToDevice, s));
+      if (n_send_lo) HIPC(hipMemcpyAsync(recv_hi, send_lo, n_send_lo, hipMemcpyDeviceToDevice, s));
+      return OI_OK;
+    }
+    (void)n_send_lo; (void)n_send_hi;  // the receiver copies: its sizes are the sender's
+    const int prev = (rank + size - 1) % size, next = (rank + 1) % size;
+    sh->send_lo[rank] = send_lo;
+    sh->send_hi[rank] = send_hi;
+    HIPC(hipEventRecord(sh->ev_ready[rank], s));
+    sh->barrier();
+    HIPC(hipStreamWaitEvent(s, sh->ev_ready[prev], 0));
+    if (n_recv_lo) HIPC(hipMemcpyAsync(recv_lo, sh->send_hi[prev], n_recv_lo, hipMemcpyDeviceToDevice, s));
+    HIPC(hipStreamWaitEvent(s, sh->ev_ready[next], 0));
+    if (n_recv_hi) HIPC(hipMemcpyAsync(recv_hi, sh->send_lo[next], n_recv_hi, hipMemcpyDeviceToDevice, s));
     HIPC(hipEventRecord(sh->ev_done[rank], s));
     sh->barrier();
     HIPC(hipStreamWaitEvent(s, sh->ev_done[prev], 0));

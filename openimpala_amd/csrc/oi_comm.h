@@ -30,6 +30,11 @@ struct oi_comm {
   // cell problems.  With one rank the planes wrap onto the rank's own ghosts.
   virtual oi_status exchange_ring(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
                                   size_t bytes, hipStream_t s) = 0;
+  // the ring exchange with a size per message (compacted planes of a periodic problem): what I send down is my lower neighbour's
+  // n_recv_hi, what I send up my upper neighbour's n_recv_lo; a zero-length message is skipped on both sides.  One rank: the
+  // planes wrap onto the rank's own ghosts (n_send_hi bytes into recv_lo, n_send_lo bytes into recv_hi)
+  virtual oi_status exchange_ring_v(const void* send_lo, size_t n_send_lo, void* recv_lo, size_t n_recv_lo, const void* send_hi,
+                                    size_t n_send_hi, void* recv_hi, size_t n_recv_hi, hipStream_t s) = 0;
   // in-place sum of n doubles resident on the device, asynchronous on `s`
   virtual oi_status allreduce_sum_f64(double* dev, int n, hipStream_t s) = 0;
   // in-place sum of a (large) float array resident on the device, asynchronous on `s`: gathers the

@@ -221,7 +221,7 @@ struct oi_effdiff {
   double* z = nullptr;              // preconditioned residual (OI_PRECOND_MG)
   double* p2 = nullptr;             // second search-direction buffer of the fused two-kernel iteration
   bool fused = false;               // multigrid PCG on the tiled kernels of the flow-through path (even extents)
-  // round 4: on one GPU the multigrid-preconditioned solves take the flow-through path's COMPACTED vectors (r, q, p, z: only the 8-voxel lines
+  // round 4: the multigrid-preconditioned solves (one GPU, or a ring whose slabs all start on an even plane) take the flow-through path's COMPACTED vectors (r, q, p, z: only the 8-voxel lines
   // that hold an active cell) and its rotated multigrid iteration on k_cg1b's forms (oi_tort.cpp: cg_one_iteration, h->rot)
   bool rot = false;
   int* lineoff = nullptr;
@@ -272,8 +272,34 @@ static oi_status wrap_z(oi_effdiff* h, void* base, size_t plane_bytes) {
 static oi_status wrap_lines(oi_effdiff* h, double* v) {
   const std::vector<long long>& pf = h->plane_first;
   const size_t nzl = (size_t)h->g.nzl, le = (size_t)kLV * sizeof(double);
+  if (h->comm)  // a ring of slabs: my first plane's lines -> the previous rank's upper ghost, my last plane's -> the next rank's lower ghost
+    return h->comm->exchange_ring_v(v + kLV * pf[1], le * (size_t)(pf[2] - pf[1]), v + kLV * pf[0], le * (size_t)(pf[1] - pf[0]),
+                                    v + kLV * pf[nzl], le * (size_t)(pf[nzl + 1] - pf[nzl]), v + kLV * pf[nzl + 1],
+                                    le * (size_t)(pf[nzl + 2] - pf[nzl + 1]), h->stream);
   HIPC(hipMemcpyAsync(v + kLV * pf[0], v + kLV * pf[nzl], le * (size_t)(pf[nzl + 1] - pf[nzl]), hipMemcpyDeviceToDevice, h->stream));
   HIPC(hipMemcpyAsync(v + kLV * pf[nzl + 1], v + kLV * pf[1], le * (size_t)(pf[2] - pf[1]), hipMemcpyDeviceToDevice, h->stream));
+  return OI_OK;
+}
+
+// Ring neighbours prove to each other, once, that they agree on the stored-line counts of the planes they exchange (every rank
+// derives them from its OWN copy of the code bytes; exchange_ring_v skips zero-length messages on each side independently, so a
+// disagreement would dead-lock the send / receive group -- oi_tort.cpp: check_plane_message_lengths).  *ok on every rank alike.
+static oi_status ring_lengths_agree(oi_effdiff* h, unsigned long long* d /* 8 device words */, int* ok) {
+  const std::vector<long long>& pf = h->plane_first;
+  const int nzl = h->g.nzl;
+  hipStream_t s = h->stream;
+  const unsigned long long host[8] = {(unsigned long long)(pf[2] - pf[1]), (unsigned long long)(pf[1] - pf[0]), 0, 0,
+                                      (unsigned long long)(pf[nzl + 1] - pf[nzl]), (unsigned long long)(pf[nzl + 2] - pf[nzl + 1]), 0, 0};
+  HIPC(hipMemcpyAsync(d, host, sizeof host, hipMemcpyHostToDevice, s));
+  // {what I send down, what I expect from below} -> the previous rank's words 6, 7; {what I send up, what I expect from above} ->
+  // the next rank's words 2, 3
+  OIC(h->comm->exchange_ring(d + 0, d + 2, d + 4, d + 6, 2 * sizeof(unsigned long long), s));
+  unsigned long long back[8];
+  HIPC(hipMemcpyAsync(back, d, sizeof back, hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  int bad = (back[2] != host[1] || back[3] != host[0] || back[6] != host[5] || back[7] != host[4]) ? 1 : 0;
+  OIC(h->comm->allreduce_max_i32_host(&bad, 1, s));
+  *ok = bad ? 0 : 1;
   return OI_OK;
 }
 
@@ -357,10 +383,19 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   h->nvec_cg = g.nvec;
   // Compacted vectors + the rotated iteration of the flow-through path (k_cg1b FORM 2 -> coarse levels, FORM 3 -> FORM 1, their
   // periodic instantiations): one GPU, any extents
-  if (want_mg && !h->comm && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g)) {
+  // (a ring of slabs: every rank takes the same decision -- the iteration has collectives inside -- and the neighbours agree on
+  // the line lists they will exchange)
+  int can = (want_mg && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g) &&
+             (long long)(nzl + 2) * ny * ((g.pitch + kLV - 1) / kLV) < (1ll << 31)) ? 1 : 0;
+  if (h->comm) {
+    int cannot = can ? 0 : 1;
+    OIC(h->comm->allreduce_max_i32_host(&cannot, 1, s));
+    can = cannot ? 0 : 1;
+  }
+  if (can) {
     const int LW = (g.pitch + kLV - 1) / kLV;
     const long long nlines = (long long)(nzl + 2) * ny * LW;
-    if (nlines < (1ll << 31)) {
+    {
       HIPC(oi::dev_malloc((void**)&h->lineoff, sizeof(int) * (size_t)nlines));
       HIPC(oi::dev_malloc((void**)&h->plane_first_dev, sizeof(long long) * ((size_t)nzl + 3)));
       HIPC(oi::dev_malloc(&h->seg, sizeof(uint2) * (size_t)(nzl + 2) * ny * ((g.pitch + 127) / 128)));
@@ -369,9 +404,22 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (nzl + 3), hipMemcpyDeviceToHost));
       const std::vector<long long>& pf = h->plane_first;
       // (the ghost planes carry the code bytes of their images: the same line lists, or the layout is not what wrap_lines assumes)
-      const bool images = pf[1] - pf[0] == pf[nzl + 1] - pf[nzl] && pf[nzl + 2] - pf[nzl + 1] == pf[2] - pf[1];
+      bool images = pf[1] - pf[0] == pf[nzl + 1] - pf[nzl] && pf[nzl + 2] - pf[nzl + 1] == pf[2] - pf[1];
       g.live_lines = (float)((double)pf[nzl + 2] / (double)nlines);
-      h->rot = images && fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, 0) && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg);
+      int rot = fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, 0) && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg) ? 1 : 0;
+      if (h->comm) {
+        unsigned long long* d8 = nullptr;
+        HIPC(oi::dev_malloc((void**)&d8, 8 * sizeof(unsigned long long)));
+        int agree = 0;
+        const oi_status st8 = ring_lengths_agree(h.get(), d8, &agree);
+        (void)oi::dev_free(d8);
+        OIC(st8);
+        images = agree != 0;
+        int no = (rot && images) ? 0 : 1;  // (the live-line share drives launch shapes: one value on every rank)
+        OIC(h->comm->allreduce_max_i32_host(&no, 1, s));
+        rot = no ? 0 : 1;
+      }
+      h->rot = images && rot;
       if (h->rot) {
         h->nvec_cg = std::max<long long>(16, (long long)kLV * pf[nzl + 2]);
       } else {
@@ -619,7 +667,7 @@ extern "C" oi_status oi_effdiff_info(const oi_effdiff* h, int64_t* n_active, int
 }
 
 // which vectors the solves run on: *compacted = 1 when r, q, p, z hold only the 8-voxel lines with an active cell and the solves
-// take the rotated multigrid iteration (one GPU, multigrid preconditioner); *vector_elements = doubles per such vector
+// take the rotated multigrid iteration (multigrid preconditioner; one GPU or a ring of slabs with even first planes); *vector_elements = doubles per such vector
 extern "C" oi_status oi_effdiff_layout(const oi_effdiff* h, int* compacted, int64_t* vector_elements) {
   if (!h) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   if (compacted) *compacted = h->rot ? 1 : 0;

@@ -197,7 +197,7 @@ def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, oi_option, nranks,
             h = oia.EffectiveDiffusivityMI355(np.ascontiguousarray(sub[z0:z1]), 1, eps=1e-10, precond=oia.PRECOND_MG,
                                               comm=comms[r], z0=z0, nz_global=nzs)
             res = [h.solve(k) for k in range(3)]
-            out[r] = dict(res=res, D=h.tensor())
+            out[r] = dict(res=res, D=h.tensor(), compacted=h.layout()[0])
             h.destroy()
         except Exception as e:
             err.append((r, repr(e)))
@@ -212,6 +212,10 @@ def test_gpu_homogenization_multigrid_on_a_ring(sample_phase, oi_option, nranks,
     assert all(conv for conv, _, _ in out[0]["res"])
     assert all(abs(it - i1) <= 2 for (_, it, _), i1 in zip(out[0]["res"], its1)), ([r[1] for r in out[0]["res"]], its1)
     np.testing.assert_allclose(out[0]["D"], want, rtol=0, atol=2e-9)
+    # (round 4: a ring whose slabs all start on an even plane runs the compacted vectors and the rotated iteration too -- the line
+    # lists of the first / last plane travel round the ring, exchange_ring_v -- the ring of 13 + 12 + 12 planes keeps dense vectors;
+    # every rank takes the same decision)
+    assert [o_["compacted"] for o_ in out] == [nranks != 3] * nranks
 
 
 @pytest.mark.gpu
