@@ -202,7 +202,89 @@ int main(int argc, char* argv[]) {
       else throw std::runtime_error("gpu.precond must be mg, jacobi or none (got '" + hp + "')");
     }
     const char* axis_names[3] = {"X", "Y", "Z"};
+    // gpu.ngpus > 1 for the FULL-domain cell problems: z-slabs on a RING of ranks (periodic z: the first and the last slab are
+    // neighbours), one host thread per slab, RCCL over xGMI or -- gpu.transport = local -- all slabs on one GPU (rehearsal)
+    int h_ngpus = 1;
+    std::string h_transport = "rccl";
+    in.query("gpu.ngpus", h_ngpus);
+    in.query("gpu.transport", h_transport);
     // three chi_k solves + tensor on one (sub-)volume; false when a solve does not converge (:545-548)
+    auto homogenize_ring = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9]) -> bool {
+      const int N = h_ngpus;
+      if (N > 64 || N > nz) throw std::runtime_error("gpu.ngpus must be between 1 and min(64, nz)");
+      if (h_transport != "rccl" && h_transport != "local") throw std::runtime_error("gpu.transport must be rccl or local");
+      if (h_transport == "rccl" && oi_device_count() < N)
+        throw std::runtime_error("gpu.ngpus = " + std::to_string(N) + " but only " + std::to_string(oi_device_count()) +
+                                 " GPU(s) are visible (gpu.transport = local runs the slabs on one GPU)");
+      std::vector<int> zb(N + 1, 0);
+      {
+        const int unit = (nz / N >= 32) ? 16 : 1, units = nz / unit;
+        for (int r = 0; r <= N; ++r) zb[r] = (int)((long long)units * r / N) * unit;
+        zb[N] = nz;
+      }
+      std::vector<oi_comm*> comms(N, nullptr);
+      unsigned char uid[OI_COMM_ID_BYTES];
+      if (h_transport == "local") {
+        const oi_status cs = oi_comm_create_local(comms.data(), N, hopts.device);
+        if (cs != OI_OK) throw std::runtime_error(std::string(oi_status_string(cs)) + ": " + oi_last_error());
+      } else {
+        const oi_status cs = oi_comm_unique_id(uid);
+        if (cs != OI_OK) throw std::runtime_error(std::string(oi_status_string(cs)) + ": " + oi_last_error());
+      }
+      std::vector<std::string> errors(N);
+      std::vector<int> allconv(N, 1);
+      int conv3[3] = {0, 0, 0}, it3[3] = {0, 0, 0}, layout0 = 0;
+      double rel3[3] = {0, 0, 0};
+      std::vector<double> Ds((size_t)9 * N, 0.0);
+      const size_t plane = (size_t)nx * ny;
+      auto work = [&](int r) {
+        oi_effdiff* eh = nullptr;
+        do {
+          if (h_transport == "rccl") {
+            const oi_status cs = oi_comm_create(&comms[r], uid, N, r, r);
+            if (cs != OI_OK) { errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error(); break; }
+          }
+          oi_tort_opts o = hopts;
+          o.verbose = r == 0 ? vb : 0;
+          oi_status cs = oi_effdiff_create_slab(&eh, comms[r], ph + plane * zb[r], 0, nx, ny, nz, zb[r], zb[r + 1] - zb[r], phase_id, &o);
+          if (cs != OI_OK) { errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error(); break; }
+          if (r == 0) { int64_t nel = 0; (void)oi_effdiff_layout(eh, &layout0, &nel); }
+          for (int k = 0; k < 3 && allconv[r]; ++k) {  // (the convergence flag comes from all-reduced sums: every rank leaves the loop alike)
+            int conv = 0, iters = 0;
+            double rel = 0.0;
+            cs = oi_effdiff_solve(eh, k, &conv, &iters, &rel);
+            if (cs != OI_OK) { errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error(); allconv[r] = 0; break; }
+            if (r == 0) { conv3[k] = conv; it3[k] = iters; rel3[k] = rel; }
+            if (!conv) allconv[r] = 0;
+          }
+          if (errors[r].empty() && allconv[r]) {
+            cs = oi_effdiff_tensor(eh, Ds.data() + (size_t)9 * r);
+            if (cs != OI_OK) errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error();
+          }
+        } while (0);
+        if (eh) oi_effdiff_destroy(eh);
+      };
+      std::vector<std::thread> threads;
+      for (int r = 0; r < N; ++r) threads.emplace_back(work, r);
+      for (auto& t : threads) t.join();
+      for (auto* c : comms)
+        if (c) oi_comm_destroy(c);
+      for (int r = 0; r < N; ++r)
+        if (!errors[r].empty()) throw std::runtime_error("slab " + std::to_string(r) + ": " + errors[r]);
+      if (vb >= 1) {
+        std::cout << "  z-slabs on a ring of " << N << (h_transport == "local" ? " in-process ranks (one GPU)" : " GPUs") << ":";
+        for (int r = 0; r < N; ++r) std::cout << " [" << zb[r] << "," << zb[r + 1] << ")";
+        std::cout << (layout0 ? "; CG vectors: lines with an active cell only\n" : "; CG vectors: dense\n");
+        for (int k = 0; k < 3; ++k) {
+          std::cout << "\n--- Solving for " << what << " chi_" << axis_names[k] << " ---\n  Solver iterations: " << it3[k]
+                    << "\n  Final Relative Residual Norm: " << std::scientific << rel3[k] << std::defaultfloat
+                    << "\n  Solver Converged Status: " << (conv3[k] ? "Yes" : "No") << "\n";
+          if (!conv3[k]) break;
+        }
+      }
+      for (int t = 0; t < 9; ++t) D[t] = Ds[t];
+      return allconv[0] != 0;
+    };
     auto homogenize = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9]) -> bool {
       oi_tort_opts o = hopts;
       o.verbose = vb;
@@ -322,7 +404,9 @@ int main(int argc, char* argv[]) {
       }
       (void)solver_from_string(solver_str);  // invalid names abort in the reference (:45-58)
       double D[9];
-      if (homogenize(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D)) {
+      if (h_ngpus < 1) throw std::runtime_error("gpu.ngpus must be between 1 and min(64, nz)");
+      if (h_ngpus > 1 ? homogenize_ring(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D)
+                      : homogenize(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D)) {
         std::cout << "Full Domain Effective Diffusivity Tensor D_eff / D_material:\n";  // :573-582
         for (int r = 0; r < 3; ++r) {
           std::cout << "  [";

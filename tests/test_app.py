@@ -139,6 +139,34 @@ hypre.eps = 1e-10
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ngpus", [2, 3])
+def test_diffusion_homogenization_on_a_ring_of_slabs(app, tmp_path, ngpus):
+    """gpu.ngpus > 1 with the default calculation_method: the full-domain cell problems on a RING of z-slabs (periodic z across the
+    first and the last slab), here all on one GPU through the in-process transport (gpu.transport = local): the tensor of the
+    single-GPU run, the slabs and the vector layout reported."""
+    import numpy as np
+    from oracle import oracle as o
+    tif = os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")  # 100^3
+    want, _ = o.effective_diffusivity(o.read_tiff_phase(tif), 1, eps=1e-10)
+    text = f"""
+filename = SampleData_2Phase_stack_3d_1bit.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+hypre.eps = 1e-10
+gpu.ngpus = {ngpus}
+gpu.transport = local
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text), "verbose=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"z-slabs on a ring of {ngpus} in-process ranks (one GPU):" in r.stdout
+    assert r.stdout.count("Solver Converged Status: Yes") == 3
+    # (slab boundaries on multiples of 16 planes: every slab starts on an even plane -> the compacted vectors)
+    assert "CG vectors: lines with an active cell only" in r.stdout
+    got = np.loadtxt(tmp_path / "res" / "Deff_tensor.txt")
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+
+
+@pytest.mark.gpu
 def test_diffusion_rev_study(app, tmp_path):
     """rev.do_study (Diffusion.cpp:317-502): random cubic sub-volumes with periodic cell problems, one CSV
     row per (sample, size); a row is checked against the oracle on the same crop, oversized targets are
