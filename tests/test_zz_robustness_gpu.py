@@ -6,6 +6,8 @@ selection): a failure here can never hide a parity row under `pytest -x`.
 import math
 import os
 
+import time
+
 import numpy as np
 import pytest
 
@@ -212,13 +214,18 @@ def test_searching_single_kernel_handles_release_their_arenas(oi_option):
         assert pl["nslots"] > 6 and (pl["tried"] > 1 or (n > 0 and pl["cache_hit"])), pl
         assert pl["peak_device_bytes"] > t.stats().bytes_device + 2 * 400e6, pl
         t.cg_begin(); t.cg_iterate(4); t.cg_finish()
-        held.append((oia.device_memory()[0], t.stats().bytes_device))
+        # (the driver reports the spare slots the search has freed a little later -- once, in 14 full runs of the suite, all six were
+        # still counted as used when the handle had finished its first iterations: the reading is the best of half a second)
+        best = 0
+        for _ in range(10):
+            best = max(best, oia.device_memory()[0])
+            time.sleep(0.05)
+        held.append((best, t.stats().bytes_device))
         t.destroy()
         free.append(oia.device_memory()[0])
     ph.free()
     # (a reading right after a destroy may lag by a whole handle -- the driver reports freed arrays a little later, see
     # test_handles_release_their_device_memory -- so the test is on the highest readings: no handle left memory behind for good)
-    import time
     time.sleep(0.5)
     final = oia.device_memory()[0] - int(np.prod(shape))   # (the phase buffer has just gone back too)
     top = sorted(free[1:])[-2:]
