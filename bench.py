@@ -76,7 +76,118 @@ def parse():
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-stored-p variant")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed + RCCL code path even with one rank (rehearsal)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="N > 1 without a launcher: start the N child ranks, let them rendezvous over gloo on the CPU and report "
+                         "their environment and command line instead of benchmarking (tests/test_bench_launch_cpu.py)")
+    ap.add_argument("--launch-grace-s", type=float, default=30.0,
+                    help="self-launched ranks: once one rank has left with an error the others get this long before they are stopped")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the reference's analogue: `mpirun -np N Diffusion inputs`,
+    GNUmakefile:132-133).  This process has NOT imported torch or the solver library and never touches HIP: it starts N fresh
+    interpreters of this file, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torchrun would
+    set them, relays rank 0's single JSON line, sends everything else the ranks print to stderr, and leaves with the worst exit
+    code.  A rank that dies takes the others with it after --launch-grace-s (they would wait in a collective until their own
+    watchdog); the whole launch is bounded by the ranks' own budgets plus a margin."""
+    import signal
+    import subprocess
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    argv = [a for a in sys.argv[1:]]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port), OI_BENCH_SELF_LAUNCHED="1",
+                   # (what the ranks may report: this process has loaded neither torch nor the solver library, so no HIP call was made)
+                   OI_BENCH_LAUNCHER_CLEAN="1" if not ({"torch", "openimpala_amd"} & set(sys.modules)) else "0")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode(errors="replace").splitlines()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.run_budget_s + args.extras_budget_s + args.solve_budget_s + 120.0
+    first_bad = None
+    note = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        now = time.time()
+        if first_bad is None and any(p.poll() not in (None, 0) for p in procs):
+            first_bad = now
+        if (first_bad is not None and now - first_bad > args.launch_grace_s) or now > deadline:
+            note = "launcher: a rank left with an error and the others were stopped" if first_bad is not None else \
+                   "launcher: the ranks overran every budget and were stopped"
+            for p in procs:
+                if p.poll() is None:
+                    p.send_signal(signal.SIGTERM)
+            t_kill = time.time() + 10.0
+            while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                time.sleep(0.2)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10.0)
+    codes = [p.returncode for p in procs]
+    lines = [l for l in out0 if l.strip()]
+    json_lines = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in json_lines[-1:]:
+            print(l, file=sys.stderr)
+    rc = 0
+    for c in codes:
+        if c != 0:
+            rc = max(rc, c if c > 0 else 128 - c)   # (a rank ended by signal s counts as 128 + s)
+    if json_lines:
+        line = json_lines[-1]
+        try:
+            d = json.loads(line)
+            d["launcher"] = {"kind": "self (bench.py started the ranks)", "ranks": n, "exit_codes": codes, "master_port": port}
+            if note:
+                d["launcher"]["note"] = note
+            line = json.dumps(d)
+        except ValueError:
+            pass
+        print(line, flush=True)
+    else:
+        print(json.dumps({"metric": "Mvoxel-iters/sec", "value": None, "unit": "Mvoxel-iters/s", "n_gpus": n, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"{args.size}^3 two-phase {args.structure}, z-slabs over {n} GPU(s)"},
+                          "roofline": None, "cpu_baseline": None,
+                          "launcher": {"kind": "self (bench.py started the ranks)", "ranks": n, "exit_codes": codes, "master_port": port},
+                          "note": (note or "launcher: rank 0 printed no line") + f"; exit codes {codes}; nothing was measured"}), flush=True)
+        rc = rc or 4
+    sys.exit(rc)
+
+
+def dry_rank(args, world, rank, local_rank):
+    """--dry-launch child: rendezvous over gloo at the address the launcher gave, gather every rank's launch facts, rank 0 prints
+    them as the one JSON line.  Touches neither HIP nor the solver library."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = {"rank": rank, "local_rank": local_rank, "world_size": world, "argv": sys.argv[1:], "pid": os.getpid(), "ppid": os.getppid(),
+            "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+            "self_launched": os.environ.get("OI_BENCH_SELF_LAUNCHED") == "1",
+            "launcher_was_gpu_clean": os.environ.get("OI_BENCH_LAUNCHER_CLEAN") == "1", "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "Mvoxel-iters/sec", "value": None, "unit": "Mvoxel-iters/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_launch": True, "ranks": allr}), flush=True)
+    dist.destroy_process_group()
 
 
 def make_structure(oia, args, shape, z0, nzl):
@@ -172,11 +283,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)   # (does not return; nothing GPU-related has been imported or called in this process)
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree",
                   file=sys.stderr)
         sys.exit(2)
+    if args.dry_launch:
+        dry_rank(args, world, rank, local_rank)
+        return
 
     # Whole-run watchdog: start-up, warm-up and the timed region of an N > 1 run contain collectives that this code has
     # never executed on real multi-GPU hardware.  If one never returns, rank 0 still prints ONE line (value null + note)
@@ -323,7 +439,21 @@ def main():
     run_watchdog.cancel()
     ktimes = t.kernel_times()
     it_done, relres, conv = t.cg_state()
+    transport = None
     if dist is not None:
+        # what every rank measured and what its transport really is: the N-rank line describes itself
+        info = comm.info()
+        mine_t = {"rank": rank, "ms_per_step": dt / max(1, args.steps) * 1e3, "cg1_ms_per_launch": (ktimes["cg1"][0] / max(1, ktimes["cg1"][1])) if "cg1" in ktimes else None,
+                  "rccl_ranks_collective": info["ranks_collective"], "rccl_ranks_p2p": info["ranks_p2p"], "exchange_overlaps": info["exchange_overlaps"],
+                  "transport": info["kind"], "device": local_rank}
+        timed = [None] * world
+        dist.all_gather_object(timed, mine_t)
+        for a, b in zip(per_rank, timed):
+            a.update(b)
+        transport = {"kind": info["kind"], "rccl_ranks": [min(t["rccl_ranks_collective"] for t in timed), min(t["rccl_ranks_p2p"] for t in timed)],
+                     "exchange_overlaps": all(t["exchange_overlaps"] for t in timed),
+                     "exchange_stream": "own stream, highest priority" if all(t["exchange_overlaps"] for t in timed) else "solver stream",
+                     "ms_per_step_per_rank": [t["ms_per_step"] for t in timed]}
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -418,6 +548,7 @@ def main():
             # where the CG vectors were put (slots of one arena) and what the placement search measured, ms per iteration
             "vector_placement": placement,
             "per_rank": per_rank,
+            "transport": transport,
         }
         if extras["note"]:
             out["note"] = extras["note"]

@@ -324,6 +324,11 @@ oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device);
 void oi_comm_destroy(oi_comm* c);
 int oi_comm_rank(const oi_comm* c);
 int oi_comm_size(const oi_comm* c);
+/* What the transport really is (a multi-GPU bench line reports it, so that a run is self-describing): kind 1 = RCCL, 2 = in-process;
+ * ranks_collective / ranks_p2p = ncclCommCount of the all-reduce communicator and of the plane-exchange communicator (RCCL; the rank
+ * count of the group otherwise); exchange_overlaps = 1 when the plane exchange runs on its own (highest-priority) stream beside the
+ * scalar all-reduce (it has a communicator of its own), 0 when one communicator serves both and everything stays on one stream. */
+oi_status oi_comm_info(const oi_comm* c, int* kind, int* ranks_collective, int* ranks_p2p, int* exchange_overlaps);
 
 /* ---- seeded synthetic microstructures, generated in HBM (BASELINE.json configs) ----
  * phase_dev: device pointer to nx*ny*nz_local bytes holding global planes
@@ -354,6 +359,15 @@ oi_status oi_dev_free(void* ptr);
 oi_status oi_dev_pool(int enable, double cap_gb);
 double oi_dev_pool_trim(void);
 oi_status oi_dev_pool_stats(double* held_bytes, long long* held_blocks, long long* hits, long long* misses, int* enabled);
+/* The library's allocation LEDGER: every device allocation it makes (handles, transports, scratch, oi_dev_malloc) is entered when made
+ * and struck when freed.  live_bytes / live_blocks = requested bytes / number of the allocations alive now (blocks the pool holds are
+ * not alive); peak_bytes = high-water mark of live_bytes since the last reset (reset != 0 restarts it at the current value).  After
+ * oi_*_destroy of everything a process built these are back at what they were before: the leak tests assert equality. */
+long long oi_dev_live_bytes(void);
+long long oi_dev_live_blocks(void);
+long long oi_dev_peak_bytes(int reset);
+/* test hook: the n-th device allocation from now (1 = the next) fails once, as if the device were full; 0 disarms */
+void oi_debug_fail_alloc_after(long long n);
 /* measurement aid: ms per launch of the library's reference copy stream (linear, 16-byte nontemporal accesses) between
  * two scratch arrays of `bytes` each -- what a 1 read : 1 write stream reaches on this box; bench.py reports it beside
  * the stencil apply */

@@ -43,8 +43,8 @@ ABI_SYMBOLS = (
     "oi_effdiff_info oi_effdiff_layout oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_placement_cost oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
-    "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_gen_bernoulli_device "
-    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_pool oi_dev_pool_trim oi_dev_pool_stats oi_dev_upload oi_dev_download oi_device_count "
+    "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_comm_info oi_gen_bernoulli_device "
+    "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_pool oi_dev_pool_trim oi_dev_pool_stats oi_dev_live_bytes oi_dev_live_blocks oi_dev_peak_bytes oi_debug_fail_alloc_after oi_dev_upload oi_dev_download oi_device_count "
     "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host oi_read_set_pinned"
 ).split()
 
@@ -163,6 +163,7 @@ def lib():
     L.oi_comm_destroy.restype = None
     L.oi_comm_rank.argtypes = [vp]
     L.oi_comm_size.argtypes = [vp]
+    L.oi_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.oi_gen_bernoulli_device.argtypes = [vp, i, i, i, i, i, u64, u64]
     L.oi_gen_spheres_device.argtypes = [vp, i, i, i, i, i, u64, i, i]
     L.oi_gen_blobs_device.argtypes = [vp, i, i, i, i, i, u64, i, u64]
@@ -175,6 +176,12 @@ def lib():
     L.oi_dev_pool.argtypes = [i, d]
     L.oi_dev_pool_trim.restype = d
     L.oi_dev_pool_stats.argtypes = [C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(i)]
+    L.oi_dev_live_bytes.restype = C.c_longlong
+    L.oi_dev_live_blocks.restype = C.c_longlong
+    L.oi_dev_peak_bytes.argtypes = [i]
+    L.oi_dev_peak_bytes.restype = C.c_longlong
+    L.oi_debug_fail_alloc_after.argtypes = [C.c_longlong]
+    L.oi_debug_fail_alloc_after.restype = None
     L.oi_dev_upload.argtypes = [vp, vp, C.c_size_t]
     L.oi_dev_download.argtypes = [vp, vp, C.c_size_t]
     L.oi_device_count.restype = i
@@ -336,6 +343,14 @@ class Comm:
     def size(self):
         return lib().oi_comm_size(self._h)
 
+    def info(self):
+        """What the transport is: kind ('rccl' | 'local'), ncclCommCount of the all-reduce and of the plane-exchange
+        communicator, and whether the exchange overlaps the all-reduce on a stream of its own."""
+        v = [C.c_int(0) for _ in range(4)]
+        _check(lib().oi_comm_info(self._h, *[C.byref(x) for x in v]))
+        return {"kind": {1: "rccl", 2: "local"}.get(v[0].value, "?"), "ranks_collective": v[1].value, "ranks_p2p": v[2].value,
+                "exchange_overlaps": bool(v[3].value)}
+
     def destroy(self):
         if self._h and self._owned:
             lib().oi_comm_destroy(self._h)
@@ -395,6 +410,21 @@ def dev_pool_stats():
     held, blocks, hits, misses, on = C.c_double(), C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_int()
     _check(lib().oi_dev_pool_stats(C.byref(held), C.byref(blocks), C.byref(hits), C.byref(misses), C.byref(on)))
     return {"held_bytes": int(held.value), "held_blocks": blocks.value, "hits": hits.value, "misses": misses.value, "enabled": bool(on.value)}
+
+
+def dev_live():
+    """(bytes, blocks) of the library's device allocations alive now -- the exact ledger of oi_pool.h, not hipMemGetInfo."""
+    return int(lib().oi_dev_live_bytes()), int(lib().oi_dev_live_blocks())
+
+
+def dev_peak_bytes(reset=False):
+    """High-water mark of the ledger's live bytes since the last reset."""
+    return int(lib().oi_dev_peak_bytes(1 if reset else 0))
+
+
+def debug_fail_alloc_after(n):
+    """Test hook: the n-th device allocation from now fails once (0 disarms)."""
+    lib().oi_debug_fail_alloc_after(int(n))
 
 
 def line_voxels():

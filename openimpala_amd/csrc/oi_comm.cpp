@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "oi_device.h"
+#include "oi_pool.h"
 
 namespace oi {
 static thread_local char g_err[512] = "";
@@ -54,7 +55,7 @@ struct RcclComm : oi_comm {
                                   // all-reduce is in flight, and operations of ONE communicator must not overlap
   void* scratch = nullptr;  // 64 bytes of device memory for the host-value collectives
   ~RcclComm() override {
-    if (scratch) (void)hipFree(scratch);
+    if (scratch) (void)oi::dev_free(scratch);
     if (nccl_p2p && nccl_p2p != nccl) ncclCommDestroy(nccl_p2p);
     if (nccl) ncclCommDestroy(nccl);
   }
@@ -187,10 +188,10 @@ struct LocalShared {
   ~LocalShared() {
     for (auto e : ev_ready) (void)hipEventDestroy(e);
     for (auto e : ev_done) (void)hipEventDestroy(e);
-    for (auto p : stage) (void)hipFree(p);
+    for (auto p : stage) (void)oi::dev_free(p);
     for (auto p : big)
-      if (p) (void)hipFree(p);
-    if (stage_ptrs_dev) (void)hipFree((void*)stage_ptrs_dev);
+      if (p) (void)oi::dev_free(p);
+    if (stage_ptrs_dev) (void)oi::dev_free((void*)stage_ptrs_dev);
   }
 };
 constexpr int kStageDoubles = 16;
@@ -312,9 +313,9 @@ struct LocalComm : oi_comm {
     if (size > oi::kMaxSumRanks) return OI_BAD_ARG;
     if (sh->big_cap[rank] < n) {
       HIPC(hipStreamSynchronize(s));
-      if (sh->big[rank]) HIPC(hipFree(sh->big[rank]));
+      if (sh->big[rank]) HIPC(oi::dev_free(sh->big[rank]));
       sh->big[rank] = nullptr;
-      HIPC(hipMalloc((void**)&sh->big[rank], sizeof(float) * n));
+      HIPC(oi::raw_malloc((void**)&sh->big[rank], sizeof(float) * n));
       sh->big_cap[rank] = n;
     }
     sh->send_lo[rank] = dev;
@@ -398,7 +399,7 @@ oi_status oi_comm_create(oi_comm** out, const void* id, int nranks, int rank, in
     c->nccl_p2p = c->nccl;        // one communicator: the solver then keeps exchange and all-reduce on one stream
     c->exchange_overlaps = false;
   }
-  HIPC(hipMalloc(&c->scratch, 128));
+  HIPC(oi::raw_malloc(&c->scratch, 128));
   *out = c.release();
   return OI_OK;
 }
@@ -426,9 +427,9 @@ oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device) {
   for (int r = 0; r < nranks; ++r) {
     HIPC(hipEventCreateWithFlags(&sh->ev_ready[r], hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&sh->ev_done[r], hipEventDisableTiming));
-    HIPC(hipMalloc((void**)&sh->stage[r], sizeof(double) * kStageDoubles));
+    HIPC(oi::raw_malloc((void**)&sh->stage[r], sizeof(double) * kStageDoubles));
   }
-  HIPC(hipMalloc((void**)&sh->stage_ptrs_dev, sizeof(double*) * nranks));
+  HIPC(oi::raw_malloc((void**)&sh->stage_ptrs_dev, sizeof(double*) * nranks));
   HIPC(hipMemcpy((void*)sh->stage_ptrs_dev, sh->stage.data(), sizeof(double*) * nranks, hipMemcpyHostToDevice));
   for (int r = 0; r < nranks; ++r) {
     auto* c = new LocalComm();
@@ -444,5 +445,20 @@ oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device) {
 void oi_comm_destroy(oi_comm* c) { delete c; }
 int oi_comm_rank(const oi_comm* c) { return c ? c->rank : 0; }
 int oi_comm_size(const oi_comm* c) { return c ? c->size : 1; }
+
+oi_status oi_comm_info(const oi_comm* c, int* kind, int* ranks_collective, int* ranks_p2p, int* exchange_overlaps) {
+  if (!c) { oi::set_error("%s: null communicator", __func__); return OI_BAD_ARG; }
+  int k = 2, nc = c->size, np = c->size;
+  if (const RcclComm* r = dynamic_cast<const RcclComm*>(c)) {
+    k = 1;
+    NCCLC(ncclCommCount(r->nccl, &nc));
+    NCCLC(ncclCommCount(r->nccl_p2p, &np));
+  }
+  if (kind) *kind = k;
+  if (ranks_collective) *ranks_collective = nc;
+  if (ranks_p2p) *ranks_p2p = np;
+  if (exchange_overlaps) *exchange_overlaps = c->exchange_overlaps ? 1 : 0;
+  return OI_OK;
+}
 
 }  // extern "C"

@@ -79,7 +79,8 @@ struct oi_tort {
   int phase_id = 0;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t comm_stream = nullptr;         // ghost-plane exchange of the single-kernel variant
+  hipStream_t comm_stream = nullptr;         // ghost-plane exchange of the single-kernel variant (highest stream priority)
+  int comm_stream_priority = 0;
   hipStream_t aux_stream = nullptr;          // interior chunks of a slab with neighbours, beside the boundary chunks
   hipEvent_t ev_boundary = nullptr, ev_exchanged = nullptr, ev_start = nullptr, ev_interior = nullptr;
 
@@ -212,6 +213,16 @@ static oi_status dmalloc(oi_tort* h, T** p, size_t count) {
   h->bytes_device += count * sizeof(T);
   return OI_OK;
 }
+
+// scratch of one call: released on every way out
+template <typename T>
+struct DevTmp {
+  T* p = nullptr;
+  DevTmp() = default;
+  DevTmp(const DevTmp&) = delete;
+  DevTmp& operator=(const DevTmp&) = delete;
+  ~DevTmp() { if (p) (void)oi::dev_free(p); }
+};
 
 static oi_status ensure_device(int device, int* out_device) {
   int ndev = 0;
@@ -382,9 +393,9 @@ std::map<PlaceKey, PlaceEntry> g_place_cache;
 
 static void vecset_free(VecSet& v) {
   for (int k = 0; k < v.nslots; ++k)
-    if (v.slot[k] && !v.block) (void)hipFree(v.slot[k]);
-  if (v.block) (void)hipFree(v.block);
-  if (v.x) (void)hipFree(v.x);
+    if (v.slot[k] && !v.block) (void)oi::dev_free(v.slot[k]);
+  if (v.block) (void)oi::dev_free(v.block);
+  if (v.x) (void)oi::dev_free(v.x);
   v = VecSet();
 }
 
@@ -405,7 +416,7 @@ static void release_unchosen(oi_tort* h) {
   for (int k = 0; k < v.nslots; ++k) {
     bool used = false;
     for (int c = 0; c < 6; ++c) used = used || h->placement[c] == k;
-    if (!used && v.slot[k]) { (void)hipFree(v.slot[k]); v.slot[k] = nullptr; v.bytes -= h->slot_bytes; }
+    if (!used && v.slot[k]) { (void)oi::dev_free(v.slot[k]); v.slot[k] = nullptr; v.bytes -= h->slot_bytes; }
   }
 }
 
@@ -425,7 +436,7 @@ static oi_status vecset_alloc(oi_tort* h, bool search) {
   const double t0 = now_s();
   if (!search) {
     h->x_bytes = 0;
-    if (hipMalloc((void**)&v.block, 6 * h->slot_bytes) != hipSuccess) {
+    if (oi::raw_malloc((void**)&v.block, 6 * h->slot_bytes) != hipSuccess) {
       (void)hipGetLastError();
       oi::set_error("out of device memory for the CG vectors (%zu bytes)", 6 * h->slot_bytes);
       return OI_HIP_ERROR;
@@ -439,6 +450,9 @@ static oi_status vecset_alloc(oi_tort* h, bool search) {
   h->x_bytes = ((size_t)h->g.nvec * sizeof(double) + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
   size_t free_b = 0, total_b = 0;
   HIPC(hipMemGetInfo(&free_b, &total_b));
+  // (hipMemGetInfo counts the blocks the process's pool holds as used; an allocation that needs them gets them back -- raw_malloc
+  // trims the pool when the driver refuses -- so they count as free when the set is sized)
+  free_b += oi::dev_pool_held(h->device);
   // spare slots only while a quarter of the card stays free for the caller's own arrays
   int want = std::min(kMaxSlots, std::max(6, h->g.tune.place_slots));
   for (; want > 6 && (size_t)want * h->slot_bytes + h->x_bytes + total_b / 4 > free_b; --want) {}
@@ -452,7 +466,7 @@ static oi_status vecset_alloc(oi_tort* h, bool search) {
     const int na = spacer_gb > 0.0 ? std::max(6, (want + 1) / 2) : want;  // (the six needed slots lie in front of the spacer)
     char* spacer = nullptr;
     double t_spare = now_s();
-    bool ok = hipMalloc((void**)&v.x, h->x_bytes) == hipSuccess;
+    bool ok = oi::raw_malloc((void**)&v.x, h->x_bytes) == hipSuccess;
     for (int k = 0; ok && k < want; ++k) {
       // SPARE slots (and the spacer) only while the driver hands memory out quickly: memory another process has used is
       // cleared in one lump when an allocation runs past the clean memory (one hipMalloc of 4.2 GB: 0.2 ms or 5.8 s,
@@ -462,13 +476,13 @@ static oi_status vecset_alloc(oi_tort* h, bool search) {
       // profiles/r03/bench_r03d_after_the_test_suite.json, and save nothing)
       if (k == 6) t_spare = now_s();
       if (k >= 6 && now_s() - t_spare > (double)h->g.tune.place_alloc_budget_s) { want = k; break; }
-      if (k == na && k >= 6) ok = hipMalloc((void**)&spacer, (size_t)(spacer_gb * 1e9)) == hipSuccess;
+      if (k == na && k >= 6) ok = oi::raw_malloc((void**)&spacer, (size_t)(spacer_gb * 1e9)) == hipSuccess;
       const double ta = now_s();
-      ok = ok && hipMalloc((void**)&v.slot[k], h->slot_bytes) == hipSuccess;
+      ok = ok && oi::raw_malloc((void**)&v.slot[k], h->slot_bytes) == hipSuccess;
       if (ok) v.nslots = k + 1;
       if (h->opts.verbose > 2) fprintf(stderr, "[openimpala_amd]   slot %d allocated in %.1f ms (%.2f s since the set was begun)\n", k, 1e3 * (now_s() - ta), now_s() - t0);
     }
-    if (spacer) (void)hipFree(spacer);
+    if (spacer) (void)oi::dev_free(spacer);
     if (ok) {
       const size_t set_bytes = (size_t)v.nslots * h->slot_bytes + h->x_bytes;
       v.nfront = std::min(na, v.nslots); v.bytes = set_bytes;
@@ -705,7 +719,12 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   hipStream_t s = h->stream;
   if (h->comm) {
-    HIPC(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    // the exchange stream gets the HIGHEST priority the device offers: RCCL's send/recv kernel must not queue behind the
+    // resident blocks of the interior march it is meant to overlap (numerically lower = higher priority)
+    int prio_least = 0, prio_greatest = 0;
+    HIPC(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPC(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_greatest));
+    h->comm_stream_priority = prio_greatest;
     HIPC(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     HIPC(hipEventCreateWithFlags(&h->ev_boundary, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_exchanged, hipEventDisableTiming));
@@ -1015,9 +1034,9 @@ static oi_status remspot_private_copy(oi_comm* comm, const uint8_t* phase, bool 
   box_cut_flags(nz, box_size, fz);
   do {
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&old, ntot) != hipSuccess || hipMalloc((void**)&cur, ntot) != hipSuccess ||
-        hipMalloc((void**)&cuts, (size_t)nx + ny + nz) != hipSuccess ||
-        hipMalloc((void**)&changed, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&h_changed, sizeof(int)) != hipSuccess ||
+        oi::raw_malloc((void**)&old, ntot) != hipSuccess || oi::raw_malloc((void**)&cur, ntot) != hipSuccess ||
+        oi::raw_malloc((void**)&cuts, (size_t)nx + ny + nz) != hipSuccess ||
+        oi::raw_malloc((void**)&changed, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&h_changed, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(old, 0, ntot, s) != hipSuccess ||
         hipMemcpyAsync(old + plane, phase, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(cuts, fx.data(), (size_t)nx, hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -1046,12 +1065,12 @@ static oi_status remspot_private_copy(oi_comm* comm, const uint8_t* phase, bool 
     }
   } while (0);
   if (rc == OI_HIP_ERROR && !*oi::last_error()) oi::set_error("remspot: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-  if (cur) (void)hipFree(cur);
-  if (cuts) (void)hipFree(cuts);
-  if (changed) (void)hipFree(changed);
+  if (cur) (void)oi::dev_free(cur);
+  if (cuts) (void)oi::dev_free(cuts);
+  if (changed) (void)oi::dev_free(changed);
   if (h_changed) (void)hipHostFree(h_changed);
   if (s) (void)hipStreamDestroy(s);
-  if (rc != OI_OK) { if (old) (void)hipFree(old); return rc; }
+  if (rc != OI_OK) { if (old) (void)oi::dev_free(old); return rc; }
   *out_dev = old;
   *out_phase = old + plane;
   return OI_OK;
@@ -1064,7 +1083,7 @@ static oi_status create_whole(oi_tort** out, const uint8_t* phase, bool on_devic
     OIC(remspot_private_copy(nullptr, phase, on_device, nx, ny, nz, 0, nz, opts->remspot_passes, opts->remspot_box_size,
                              opts->device, &priv, &priv_phase));
     const oi_status st = create_common(out, nullptr, priv_phase, true, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
-    (void)hipFree(priv);
+    (void)oi::dev_free(priv);
     return st;
   }
   return create_common(out, nullptr, phase, on_device, nx, ny, nz, 0, nz, phase_id, dir, vlo, vhi, opts);
@@ -1090,7 +1109,7 @@ extern "C" oi_status oi_tort_create_slab(oi_tort** out, oi_comm* comm, const uin
     OIC(remspot_private_copy(comm, phase, on_device != 0, nx, ny, nz_global, z0, nz_local, opts->remspot_passes,
                              opts->remspot_box_size, opts->device, &priv, &priv_phase));
     const oi_status st = create_common(out, comm, priv_phase, true, nx, ny, nz_global, z0, nz_local, phase_id, dir, vlo, vhi, opts);
-    (void)hipFree(priv);
+    (void)oi::dev_free(priv);
     return st;
   }
   return create_common(out, comm, phase, on_device != 0, nx, ny, nz_global, z0, nz_local, phase_id, dir, vlo, vhi,
@@ -1550,11 +1569,11 @@ extern "C" oi_status oi_tort_get_solution(oi_tort* h, double* phi) {
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
   double* dense = nullptr;
-  HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
+  HIPC(oi::raw_malloc((void**)&dense, n * sizeof(double)));
   launch_pitch_copy_out(g, h->x, dense, h->stream);
   hipError_t e = hipMemcpyAsync(phi, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(dense);
+  (void)oi::dev_free(dense);
   HIPC(e);
   return OI_OK;
 }
@@ -1565,11 +1584,11 @@ extern "C" oi_status oi_tort_get_mask(oi_tort* h, uint8_t* mask) {
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
   uint8_t* dense = nullptr;
-  HIPC(hipMalloc((void**)&dense, n));
+  HIPC(oi::raw_malloc((void**)&dense, n));
   launch_unpack_mask(g, h->active, dense, h->stream);
   hipError_t e = hipMemcpyAsync(mask, dense, n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(dense);
+  (void)oi::dev_free(dense);
   HIPC(e);
   return OI_OK;
 }
@@ -1581,11 +1600,11 @@ extern "C" oi_status oi_tort_debug_get_codes(oi_tort* h, uint8_t* codes) {
   const Geom& g = h->g;
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
   uint8_t* dense = nullptr;
-  HIPC(hipMalloc((void**)&dense, n));
+  HIPC(oi::raw_malloc((void**)&dense, n));
   launch_codes_out(g, h->code, dense, h->stream);
   hipError_t e = hipMemcpyAsync(codes, dense, n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(dense);
+  (void)oi::dev_free(dense);
   HIPC(e);
   return OI_OK;
 }
@@ -1599,18 +1618,18 @@ extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q,
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   // the compacted single-kernel layout keeps r / q as line lists: the stand-alone apply gets dense scratch
-  struct Scratch { double *a = nullptr, *b = nullptr; ~Scratch() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } scratch;
+  struct Scratch { double *a = nullptr, *b = nullptr; ~Scratch() { if (a) (void)oi::dev_free(a); if (b) (void)oi::dev_free(b); } } scratch;
   double *vr = h->r, *vq = h->q;
   if (h->lineoff) {
-    HIPC(hipMalloc((void**)&scratch.a, sizeof(double) * g.nvec));
-    HIPC(hipMalloc((void**)&scratch.b, sizeof(double) * g.nvec));
+    HIPC(oi::raw_malloc((void**)&scratch.a, sizeof(double) * g.nvec));
+    HIPC(oi::raw_malloc((void**)&scratch.b, sizeof(double) * g.nvec));
     HIPC(hipMemsetAsync(scratch.a, 0, sizeof(double) * g.nvec, h->stream));
     HIPC(hipMemsetAsync(scratch.b, 0, sizeof(double) * g.nvec, h->stream));
     vr = scratch.a; vq = scratch.b;
   }
   const size_t n = (size_t)g.nx * g.ny * g.nzl;
   double* dense = nullptr;
-  HIPC(hipMalloc((void**)&dense, n * sizeof(double)));
+  HIPC(oi::raw_malloc((void**)&dense, n * sizeof(double)));
   oi_status rc = OI_OK;
   do {
     if (hipMemcpyAsync(dense, v, n * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -1624,7 +1643,7 @@ extern "C" oi_status oi_tort_debug_apply(oi_tort* h, const double* v, double* q,
     if (hipMemcpyAsync(q, dense, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) rc = OI_HIP_ERROR;
   } while (0);
-  (void)hipFree(dense);
+  (void)oi::dev_free(dense);
   if (rc == OI_HIP_ERROR) oi::set_error("debug_apply: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   return rc;
 }
@@ -1637,11 +1656,11 @@ extern "C" oi_status oi_tort_bench_apply(oi_tort* h, int reps, int variant, doub
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   // the compacted single-kernel layout keeps r / q as line lists: the stand-alone apply gets dense scratch
-  struct Scratch { double *a = nullptr, *b = nullptr; ~Scratch() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } scratch;
+  struct Scratch { double *a = nullptr, *b = nullptr; ~Scratch() { if (a) (void)oi::dev_free(a); if (b) (void)oi::dev_free(b); } } scratch;
   double *vr = h->r, *vq = h->q;
   if (h->lineoff) {
-    HIPC(hipMalloc((void**)&scratch.a, sizeof(double) * g.nvec));
-    HIPC(hipMalloc((void**)&scratch.b, sizeof(double) * g.nvec));
+    HIPC(oi::raw_malloc((void**)&scratch.a, sizeof(double) * g.nvec));
+    HIPC(oi::raw_malloc((void**)&scratch.b, sizeof(double) * g.nvec));
     HIPC(hipMemsetAsync(scratch.a, 0, sizeof(double) * g.nvec, h->stream));
     HIPC(hipMemsetAsync(scratch.b, 0, sizeof(double) * g.nvec, h->stream));
     vr = scratch.a; vq = scratch.b;
@@ -1757,7 +1776,7 @@ extern "C" oi_status oi_tort_true_residual(oi_tort* h, double* relres) {
   HIPC(hipSetDevice(h->device));
   const Geom& g = h->g;
   double* q = nullptr;
-  if (hipMalloc((void**)&q, sizeof(double) * g.nvec) != hipSuccess) {
+  if (oi::raw_malloc((void**)&q, sizeof(double) * g.nvec) != hipSuccess) {
     (void)hipGetLastError();
     oi::set_error("%s: no room for a scratch vector of %lld doubles", __func__, g.nvec);
     return OI_HIP_ERROR;
@@ -1776,7 +1795,7 @@ extern "C" oi_status oi_tort_true_residual(oi_tort* h, double* relres) {
         hipStreamSynchronize(h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
     *relres = h->bnorm > 0.0 ? std::sqrt(h->h_scal[0]) / h->bnorm : std::sqrt(h->h_scal[0]);
   } while (0);
-  (void)hipFree(q);
+  (void)oi::dev_free(q);
   if (rc == OI_HIP_ERROR) oi::set_error("%s: HIP failure: %s", __func__, hipGetErrorString(hipGetLastError()));
   return rc;
 }
@@ -1803,16 +1822,15 @@ extern "C" oi_status oi_tort_check_matrix_properties(oi_tort* h, int64_t* n_viol
   if (h->comm) {
     // ghost planes of the active bits were exchanged during construction: unpack them
     Geom gg = g;
-    uint8_t* dense = nullptr;
-    HIPC(hipMalloc((void**)&dense, (size_t)g.nx * g.ny));
+    DevTmp<uint8_t> dense;
+    HIPC(oi::raw_malloc((void**)&dense.p, (size_t)g.nx * g.ny));
     gg.nzl = 1;
     // plane 0 (lo ghost): unpack by shifting the base pointer one plane down
-    launch_unpack_mask(gg, h->active - g.wplane, dense, h->stream);
-    HIPC(hipMemcpyAsync(lo.data(), dense, lo.size(), hipMemcpyDeviceToHost, h->stream));
-    launch_unpack_mask(gg, h->active + (long long)g.nzl * g.wplane, dense, h->stream);
-    HIPC(hipMemcpyAsync(hi.data(), dense, hi.size(), hipMemcpyDeviceToHost, h->stream));
+    launch_unpack_mask(gg, h->active - g.wplane, dense.p, h->stream);
+    HIPC(hipMemcpyAsync(lo.data(), dense.p, lo.size(), hipMemcpyDeviceToHost, h->stream));
+    launch_unpack_mask(gg, h->active + (long long)g.nzl * g.wplane, dense.p, h->stream);
+    HIPC(hipMemcpyAsync(hi.data(), dense.p, hi.size(), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    (void)hipFree(dense);
   }
   const int nd[3] = {g.nx, g.ny, g.nz};
   long long bad = 0;
@@ -1889,20 +1907,19 @@ extern "C" oi_status oi_volume_fraction(const uint8_t* phase, size_t n, int phas
   const size_t rows = n / g.nx;
   g.ny = 1; g.nz = (int)rows; g.nzl = (int)rows; g.z0 = 0;
   g.W = (g.nx + 63) / 64; g.wplane = g.W; g.nwords = (long long)(g.nzl + 2) * g.wplane;
-  uint8_t* d = nullptr;
-  uint64_t* bits = nullptr;
-  unsigned long long* cnt = nullptr;
-  HIPC(hipMalloc((void**)&d, n));
-  HIPC(hipMalloc((void**)&bits, sizeof(uint64_t) * g.nwords));
-  HIPC(hipMalloc((void**)&cnt, sizeof(unsigned long long)));
-  HIPC(hipMemset(cnt, 0, sizeof(unsigned long long)));
-  HIPC(hipMemcpy(d, phase, n, hipMemcpyHostToDevice));
-  launch_pack_open(d, g, phase_id, bits, cnt, nullptr);
+  DevTmp<uint8_t> d;
+  DevTmp<uint64_t> bits;
+  DevTmp<unsigned long long> cnt;
+  HIPC(oi::raw_malloc((void**)&d.p, n));
+  HIPC(oi::raw_malloc((void**)&bits.p, sizeof(uint64_t) * g.nwords));
+  HIPC(oi::raw_malloc((void**)&cnt.p, sizeof(unsigned long long)));
+  HIPC(hipMemset(cnt.p, 0, sizeof(unsigned long long)));
+  HIPC(hipMemcpy(d.p, phase, n, hipMemcpyHostToDevice));
+  launch_pack_open(d.p, g, phase_id, bits.p, cnt.p, nullptr);
   unsigned long long c = 0;
-  HIPC(hipMemcpy(&c, cnt, sizeof(c), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(&c, cnt.p, sizeof(c), hipMemcpyDeviceToHost));
   // tail that does not fill a row
   for (size_t v = rows * g.nx; v < n; ++v) c += phase[v] == (uint8_t)phase_id;
-  (void)hipFree(d); (void)hipFree(bits); (void)hipFree(cnt);
   *phase_count = (int64_t)c;
   return OI_OK;
 }
@@ -1916,7 +1933,7 @@ extern "C" oi_status oi_remspot(uint8_t* q, int nx, int ny, int nz, int passes, 
   uint8_t* dev_phase = nullptr;
   OIC(remspot_private_copy(nullptr, q, false, nx, ny, nz, 0, nz, passes, box_size, -1, &dev, &dev_phase));
   const hipError_t e = hipMemcpy(q, dev_phase, (size_t)nx * ny * nz, hipMemcpyDeviceToHost);
-  (void)hipFree(dev);
+  (void)oi::dev_free(dev);
   HIPC(e);
   return OI_OK;
 }
@@ -1959,15 +1976,13 @@ extern "C" oi_status oi_gen_spheres_device(uint8_t* phase_dev, int nx, int ny, i
     const int d = fill[cell_of[s]]++;
     sorted[3 * d] = c[3 * s]; sorted[3 * d + 1] = c[3 * s + 1]; sorted[3 * d + 2] = c[3 * s + 2];
   }
-  int *dc = nullptr, *ds = nullptr;
-  HIPC(hipMalloc((void**)&dc, sizeof(int) * sorted.size()));
-  HIPC(hipMalloc((void**)&ds, sizeof(int) * start.size()));
-  HIPC(hipMemcpy(dc, sorted.data(), sizeof(int) * sorted.size(), hipMemcpyHostToDevice));
-  HIPC(hipMemcpy(ds, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
-  launch_gen_spheres(phase_dev, nx, ny, nz_global, z0, nz_local, dc, ds, ncx, ncy, ncz, cell, r2h, nullptr);
-  hipError_t e = hipDeviceSynchronize();
-  (void)hipFree(dc); (void)hipFree(ds);
-  HIPC(e);
+  DevTmp<int> dc, ds;
+  HIPC(oi::raw_malloc((void**)&dc.p, sizeof(int) * sorted.size()));
+  HIPC(oi::raw_malloc((void**)&ds.p, sizeof(int) * start.size()));
+  HIPC(hipMemcpy(dc.p, sorted.data(), sizeof(int) * sorted.size(), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ds.p, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+  launch_gen_spheres(phase_dev, nx, ny, nz_global, z0, nz_local, dc.p, ds.p, ncx, ncy, ncz, cell, r2h, nullptr);
+  HIPC(hipDeviceSynchronize());
   return OI_OK;
 }
 
@@ -2002,10 +2017,10 @@ extern "C" oi_status oi_dev_malloc(void** ptr, size_t bytes) {
   if (!ptr) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;
   OIC(ensure_device(-1, &device));
-  HIPC(hipMalloc(ptr, bytes));
+  HIPC(oi::raw_malloc(ptr, bytes));
   return OI_OK;
 }
-extern "C" oi_status oi_dev_free(void* ptr) { HIPC(hipFree(ptr)); return OI_OK; }
+extern "C" oi_status oi_dev_free(void* ptr) { HIPC(oi::dev_free(ptr)); return OI_OK; }
 
 // The process's pool of released handle arrays (oi_pool.h): OFF by default.
 extern "C" oi_status oi_dev_pool(int enable, double cap_gb) {
@@ -2022,6 +2037,17 @@ extern "C" oi_status oi_dev_pool_stats(double* held_bytes, long long* held_block
   if (enabled) *enabled = st.on;
   return OI_OK;
 }
+// the ledger of oi_pool.h: requested bytes / blocks of every device allocation of this library that is live now (blocks the pool
+// holds are not live), and the high-water mark since the last reset.  Exact: the leak tests compare these, not hipMemGetInfo.
+extern "C" long long oi_dev_live_bytes(void) { return (long long)oi::dev_ledger().live_bytes; }
+extern "C" long long oi_dev_live_blocks(void) { return (long long)oi::dev_ledger().live_blocks; }
+extern "C" long long oi_dev_peak_bytes(int reset) {
+  const long long p = (long long)oi::dev_ledger().peak_bytes;
+  if (reset) oi::dev_ledger_reset_peak();
+  return p;
+}
+// test hook: the n-th device allocation from now fails once with an out-of-memory error (0 disarms)
+extern "C" void oi_debug_fail_alloc_after(long long n) { oi::dev_fail_after(n); }
 extern "C" oi_status oi_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
   if (!free_bytes || !total_bytes) { oi::set_error("%s: null handle or argument out of range", __func__); return OI_BAD_ARG; }
   int device = 0;
@@ -2079,7 +2105,7 @@ extern "C" oi_status oi_dev_stream_copy_bench(size_t bytes, int reps, double* ms
   hipEvent_t e0 = nullptr, e1 = nullptr;
   oi_status st = OI_OK;
   float ms = 0.f;
-  if (hipMalloc((void**)&a, nd * 8) != hipSuccess || hipMalloc((void**)&b, nd * 8) != hipSuccess) {
+  if (oi::raw_malloc((void**)&a, nd * 8) != hipSuccess || oi::raw_malloc((void**)&b, nd * 8) != hipSuccess) {
     oi::set_error("%s: not enough device memory for 2 x %zu bytes", __func__, bytes);
     (void)hipGetLastError();
     st = OI_HIP_ERROR;
@@ -2095,8 +2121,8 @@ extern "C" oi_status oi_dev_stream_copy_bench(size_t bytes, int reps, double* ms
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
-  if (a) (void)hipFree(a);
-  if (b) (void)hipFree(b);
+  if (a) (void)oi::dev_free(a);
+  if (b) (void)oi::dev_free(b);
   if (st == OI_OK) *ms_per_copy = (double)ms / reps;
   return st;
 }

@@ -6,8 +6,6 @@ selection): a failure here can never hide a parity row under `pytest -x`.
 import math
 import os
 
-import time
-
 import numpy as np
 import pytest
 
@@ -86,20 +84,50 @@ def test_independent_handles_in_concurrent_host_threads(sample, goldens):
 
 def test_out_of_memory_is_an_error_not_a_crash():
     """A volume that cannot fit (34e9 voxels: x alone would take 275 GB next to 70 GB of phase and code bytes) fails
-    with OI_HIP_ERROR, gives back what it had allocated, and the library keeps working."""
-    free0, _ = oia.device_memory()
+    with OI_HIP_ERROR, gives back what it had allocated (the ledger is where it was), and the library keeps working."""
+    live0 = oia.dev_live()
     shape = (2048, 4096, 4096)
     buf = oia.gen_bernoulli_device(shape, 3, 0.6)
     with pytest.raises(oia.OpenImpalaError) as e:
         oia.TortuosityMI355(buf, 1, 0, shape=shape)
     assert e.value.status == oia.OI_HIP_ERROR and "out of memory" in str(e.value)
     buf.free()
-    free1, _ = oia.device_memory()
-    assert free0 - free1 < (1 << 30)
+    assert oia.dev_live() == live0
     ph = oia.gen_bernoulli_device((48, 48, 48), 3, 0.7)
     t = oia.TortuosityMI355(ph, 1, 0, shape=(48, 48, 48))
     assert t.value() > 1.0
     t.destroy(); ph.free()
+    assert oia.dev_live() == live0
+
+
+def test_an_allocation_that_fails_at_any_point_of_the_build_leaves_nothing_behind(sample):
+    """The n-th device allocation of a handle's construction fails (oi_debug_fail_alloc_after), for every n until the build goes
+    through: each failure is OI_HIP_ERROR, and the ledger is back at its starting point every time -- no array of a half-built
+    handle (tortuosity single-kernel / multigrid, homogenization) outlives the error."""
+    sub = np.ascontiguousarray(sample[:40, :44, :48])
+    live0 = oia.dev_live()
+    makers = (lambda: oia.TortuosityMI355(sub, 1, 0, eps=1e-8, kernel=oia.KERNEL_FUSED1),
+              lambda: oia.TortuosityMI355(sub, 1, 2, eps=1e-8),
+              lambda: oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-8, precond=oia.PRECOND_MG))
+    try:
+        for make in makers:
+            for n in range(1, 400):
+                oia.debug_fail_alloc_after(n)
+                try:
+                    h = make()
+                except oia.OpenImpalaError as e:
+                    assert e.status == oia.OI_HIP_ERROR, (n, str(e))
+                    assert oia.dev_live() == live0, (n, oia.dev_live(), live0)
+                    continue
+                oia.debug_fail_alloc_after(0)
+                h.destroy()
+                assert oia.dev_live() == live0
+                assert n > 10   # (a handle makes more than ten allocations: the hook did bite)
+                break
+            else:
+                raise AssertionError("the build never went through")
+    finally:
+        oia.debug_fail_alloc_after(0)
 
 
 def test_device_pool_keeps_and_returns_blocks(sample):
@@ -119,9 +147,9 @@ def test_device_pool_keeps_and_returns_blocks(sample):
         return out
 
     assert not oia.dev_pool_stats()["enabled"]
+    live0 = oia.dev_live()
     plain = solve_all()
-    time.sleep(0.3)   # (the driver reports freed arrays a little later: the reference reading is taken when it has settled)
-    free_off = max(oia.device_memory()[0] for _ in range(3))
+    assert oia.dev_live() == live0
     try:
         oia.dev_pool(True)
         first = solve_all()
@@ -129,7 +157,7 @@ def test_device_pool_keeps_and_returns_blocks(sample):
         again = solve_all()   # every array of this pass comes out of the pool
         st2 = oia.dev_pool_stats()
         assert st1["enabled"] and st1["held_blocks"] > 10 and st2["hits"] > st1["hits"] + 30 and st2["misses"] - st1["misses"] < 10, (st1, st2)
-        assert oia.device_memory()[0] < free_off - (st2["held_bytes"] >> 1)   # (the pool holds what the driver does not have)
+        assert oia.dev_live() == live0 and st2["held_bytes"] > 0   # (pooled blocks are not live; the pool accounts for them)
         for a, b, c in zip(plain[:3], first[:3], again[:3]):
             assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1] and a[2] == b[2] == c[2]
             assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], c[3])
@@ -138,99 +166,107 @@ def test_device_pool_keeps_and_returns_blocks(sample):
         assert released == st2["held_bytes"] and oia.dev_pool_stats()["held_blocks"] == 0
     finally:
         oia.dev_pool(False)
-    time.sleep(0.3)
-    assert oia.device_memory()[0] > free_off - (64 << 20)
+    assert oia.dev_live() == live0 and oia.dev_pool_stats()["held_bytes"] == 0
+
+
+def test_an_allocation_the_driver_refuses_gets_the_pool_back_first(sample):
+    """Pool ON and holding the arrays of a destroyed handle; the driver refuses an allocation of the NEXT handle that does not come
+    from the pool (a vector slot of the single-kernel iteration: oi_tort.cpp vecset_alloc; oi_dev_malloc): the pool is handed back
+    to the driver and the request repeated -- the build goes through where round 4 reported 'out of device memory'."""
+    sub = np.ascontiguousarray(sample[:64, :72, :80])
+    live0 = oia.dev_live()
+    try:
+        oia.dev_pool(True)
+        t = oia.TortuosityMI355(sub, 1, 0, eps=1e-9)
+        tau = t.value()
+        t.destroy()
+        held = oia.dev_pool_stats()["held_bytes"]
+        assert held > 0 and oia.dev_live() == live0
+        # the first driver allocations of a single-kernel handle built next (its record array, then the vector set, which is
+        # never pooled) are refused once each, while the pool still holds the multigrid handle's vectors
+        for n in (1, 2, 3):
+            oia.dev_pool_trim()
+            t = oia.TortuosityMI355(sub, 1, 0, eps=1e-9); t.destroy()       # refill the pool
+            assert oia.dev_pool_stats()["held_bytes"] > 0
+            oia.debug_fail_alloc_after(n)
+            t1 = oia.TortuosityMI355(sub, 1, 0, eps=1e-9, kernel=oia.KERNEL_FUSED1)
+            oia.debug_fail_alloc_after(0)
+            assert t1.value() == pytest.approx(tau, rel=1e-7)
+            t1.destroy()
+        # with nothing to give back the refusal is the error it was
+        oia.dev_pool_trim()
+        oia.debug_fail_alloc_after(1)
+        with pytest.raises(oia.OpenImpalaError):
+            oia.TortuosityMI355(sub, 1, 0, eps=1e-9, kernel=oia.KERNEL_FUSED1)
+        oia.debug_fail_alloc_after(0)
+        oia.dev_pool_trim()
+        assert oia.dev_live() == live0
+        t = oia.TortuosityMI355(sub, 1, 0, eps=1e-9); t.destroy()
+        buf = None
+        oia.debug_fail_alloc_after(1)
+        buf = oia.gen_bernoulli_device((32, 32, 32), 1, 0.5)    # oi_dev_malloc: the same path
+        oia.debug_fail_alloc_after(0)
+        buf.free()
+    finally:
+        oia.debug_fail_alloc_after(0)
+        oia.dev_pool(False)
+    assert oia.dev_live() == live0 and oia.dev_pool_stats()["held_bytes"] == 0
 
 
 RELEASE_VARIANTS = (("mg", dict()), ("cg1", dict(kernel=oia.KERNEL_FUSED1)), ("lean_jacobi", dict(kernel=oia.KERNEL_LEAN, precond=oia.PRECOND_JACOBI)),
                     ("fused", dict(kernel=oia.KERNEL_FUSED, precond=oia.PRECOND_NONE)), ("unfused_mg", dict(kernel=oia.KERNEL_UNFUSED, precond=oia.PRECOND_MG)))
 
 
-def release_cycle(sub, deltas=None):
-    """One handle of every variant (and a homogenization handle), created, solved and destroyed; `deltas` collects the
-    free-memory change over each of them (what a leaking destroy of ONE variant would show)."""
-    # (the homogenization handle FIRST: its arrays are the ones hipMemGetInfo reports free late -- while the next handle is at
-    # work, see the test below -- so that the reading at the END of a cycle follows a handle whose release shows at once;
-    # with it last, GPUTEST_r02 and one round-4 run caught the end-of-cycle readings in both states, 46 MiB apart)
-    for name, kw in (("effdiff", None),) + RELEASE_VARIANTS:
-        before = oia.device_memory()[0]
-        if kw is None:
-            h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-8, precond=oia.PRECOND_MG)
-            assert h.solve(0)[0]
-            h.destroy()
-        else:
-            t = oia.TortuosityMI355(sub, 1, 0, eps=1e-8, **kw)
-            assert t.value() > 1.0 and t.stats().bytes_device > 0
-            t.destroy()
-        if deltas is not None:
-            deltas.setdefault(name, []).append(before - oia.device_memory()[0])
-
-
 def test_handles_release_their_device_memory(sample):
-    """A REV study creates and destroys hundreds of handles: every variant gives its device memory back.
-
-    What a leak looks like and what it does not.  GPUTEST_r02 failed the first form of this test (two single readings, 8 MiB
-    bound) with free memory moving by -8, -8, 0, 0, -18 MiB between cycles, in 2 MiB multiples and NOT monotone.  The record
-    of tools/release_probe.py (profiles/r03/release_probe.txt: free memory around every handle kind, 14 cycles) shows what
-    that was: hipMemGetInfo reports the arrays of a destroyed handle as free only some time AFTER its hipFree calls have
-    returned -- the homogenization handle's ~45 MiB (its eight vectors) come back while the NEXT handle is at work (-42 ...
-    -46 MiB over the handle that follows, every cycle), the driver releases freed buffers behind the caller's back -- and the
-    reading at the end of a cycle is the same for all 14 cycles to 2 MiB (293 998 MiB, 294 042 when the release had already
-    happened).  So one reading is a sample of a quantity that swings by a handle's size; a destroy that forgets an array
-    loses that array EVERY cycle (a vector of this sub-volume is 6 MB; the smallest device array of a handle takes a 2 MiB
-    granule).  Hence: many cycles, and the decline from the lowest reading of the first five cycles to the lowest of the last
-    five must stay below what a granule per cycle would lose; the per-variant changes are printed with a failure.  Round 4: a run whose
-    first readings were all 294 094 MiB and some later ones 294 048 -- the same two states, sorted in time -- tripped that
-    bound (then 25 MiB over 30 cycles) with every per-variant change at 0; the cycle now STARTS with the homogenization handle,
-    so that its late release falls inside the cycle, and the bound (64 MiB over 60 cycles) lies between the 46 MiB the two
-    states differ by and the 110 MiB a single granule per cycle would cost."""
+    """A REV study creates and destroys hundreds of handles: every variant gives ALL its device memory back, and while it is alive
+    it holds exactly what its stats account for.  Read from the library's allocation ledger (oi_dev_live_bytes / _blocks: every
+    device allocation of the library is entered there when made and struck when freed), so the assertions are equalities -- the
+    earlier form of this test sampled hipMemGetInfo, which reports freed arrays late, and needed 60 cycles and a 64 MiB window."""
     sub = np.ascontiguousarray(sample[:96, :90, :88])
-    for _ in range(3):  # first uses: streams, library workspaces, the runtime's own pools settle
-        release_cycle(sub)
-    free, deltas = [], {}
-    ncycles = 60   # (a 2 MiB granule lost per cycle is 110 MiB between the two windows; the two-state swing of the readings is 46)
-    for _ in range(ncycles):
-        release_cycle(sub, deltas)
-        free.append(oia.device_memory()[0])
-    report = {k: [d >> 20 for d in v] for k, v in deltas.items()}
-    drop = min(free[:5]) - min(free[-5:])
-    assert drop < 64 << 20, (drop >> 20, [f >> 20 for f in free], report)
+    live0 = oia.dev_live()
+    for name, kw in (("effdiff", None),) + RELEASE_VARIANTS:
+        for cycle in range(2):
+            if kw is None:
+                h = oia.EffectiveDiffusivityMI355(sub, 1, eps=1e-8, precond=oia.PRECOND_MG)
+                assert h.solve(0)[0]
+                assert oia.dev_live()[0] > live0[0]
+                h.destroy()
+            else:
+                t = oia.TortuosityMI355(sub, 1, 0, eps=1e-8, **kw)
+                # alive, before the solve: the handle holds what it says it holds, to the byte
+                assert oia.dev_live()[0] - live0[0] == int(t.stats().bytes_device), (name, oia.dev_live()[0] - live0[0], t.stats().bytes_device)
+                assert t.value() > 1.0
+                assert oia.dev_live()[0] - live0[0] == int(t.stats().bytes_device), name   # (the solve's scratch is gone again)
+                t.solution(); t.mask(); t.codes()
+                assert t.checkMatrixProperties()
+                assert oia.dev_live()[0] - live0[0] == int(t.stats().bytes_device), name
+                t.destroy()
+            assert oia.dev_live() == live0, (name, cycle, oia.dev_live(), live0)
 
 
 def test_searching_single_kernel_handles_release_their_arenas(oi_option):
     """A single-kernel CG handle whose vectors exceed the placement threshold builds slot arenas (and, for the search, maps
     spare slots and a distance between the two arena halves): all of it is given back -- also the spare slots the search
-    did not choose, while the handle is still alive."""
+    did not choose, while the handle is still alive (ledger equalities)."""
     shape = (384, 384, 400)
+    live0 = oia.dev_live()
     ph = oia.gen_bernoulli_device(shape, 7, 0.75)
-    free = []
-    held = []
+    live_ph = oia.dev_live()
+    assert live_ph[0] - live0[0] == int(np.prod(shape)) and live_ph[1] == live0[1] + 1
     oi_option("place_alloc_budget_s", 1e9, reset=0.5)   # (spare slots whatever the driver's clearing of them costs)
-    for n in range(5):
+    for n in range(3):
+        oia.dev_peak_bytes(reset=True)
         t = oia.TortuosityMI355(ph, 1, 0, shape=shape, kernel=oia.KERNEL_FUSED1, eps=1e-3, maxiter=50)
         pl = t.placement()
         # the search did run: in full for the first handle; the later ones may take its placement from the process cache
         # (one verification cycle) -- they allocate and free the same spare slots either way
         assert pl["nslots"] > 6 and (pl["tried"] > 1 or (n > 0 and pl["cache_hit"])), pl
         assert pl["peak_device_bytes"] > t.stats().bytes_device + 2 * 400e6, pl
+        # the ledger saw that peak too (spare slots + spacer), and what is alive now is what the handle accounts for
+        assert oia.dev_peak_bytes() - live_ph[0] >= pl["peak_device_bytes"]
+        assert oia.dev_live()[0] - live_ph[0] == int(t.stats().bytes_device)
         t.cg_begin(); t.cg_iterate(4); t.cg_finish()
-        # (the driver reports the spare slots the search has freed a little later -- once, in 14 full runs of the suite, all six were
-        # still counted as used when the handle had finished its first iterations: the reading is the best of half a second)
-        best = 0
-        for _ in range(10):
-            best = max(best, oia.device_memory()[0])
-            time.sleep(0.05)
-        held.append((best, t.stats().bytes_device))
         t.destroy()
-        free.append(oia.device_memory()[0])
+        assert oia.dev_live() == live_ph
     ph.free()
-    # (a reading right after a destroy may lag by a whole handle -- the driver reports freed arrays a little later, see
-    # test_handles_release_their_device_memory -- so the test is on the highest readings: no handle left memory behind for good)
-    time.sleep(0.5)
-    final = oia.device_memory()[0] - int(np.prod(shape))   # (the phase buffer has just gone back too)
-    top = sorted(free[1:])[-2:]
-    assert top[1] - top[0] < (64 << 20) and top[1] - final < (64 << 20), ([f >> 20 for f in free], final >> 20)
-    # while alive a handle holds what it accounts for -- the spare slots of the search have been released (the driver may
-    # report them free a little later: the bound leaves room for two of the six spare slots of 0.47 GB)
-    for alive, accounted in held[1:]:
-        assert free[-1] - alive < accounted + (1 << 30), (free[-1] - alive, accounted)
+    assert oia.dev_live() == live0
