@@ -47,4 +47,20 @@ struct oi_comm {
 
 namespace oi {
 void set_error(const char* fmt, ...);
+// A rank-local step (allocations, a set-up kernel) sits between two collectives of a set-up: if it fails on ONE rank and that rank
+// simply returns, its neighbours wait in the next collective for good.  So the outcome of such a step is max-reduced before anyone
+// goes on: every rank gets OI_OK, or every rank returns -- the failing one with its own status and message, the others with
+// OI_HIP_ERROR and "another slab failed during <what>".  Without a communicator it is the identity.
+inline oi_status agree_status(oi_comm* comm, oi_status local, hipStream_t s, const char* what) {
+  if (!comm || comm->size <= 1) return local;
+  int bad = local != OI_OK ? 1 : 0;
+  const oi_status rc = comm->allreduce_max_i32_host(&bad, 1, s);
+  if (local != OI_OK) return local;
+  if (rc != OI_OK) return rc;
+  if (bad) {
+    set_error("slab %d of %d: another slab failed during %s", comm->rank, comm->size, what);
+    return OI_HIP_ERROR;
+  }
+  return OI_OK;
+}
 }

@@ -349,32 +349,42 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   // the reference's default budget is 1000 multigrid-preconditioned iterations (:120); CG on this
   // well-conditioned system needs ~100, so the same default is generous
   h->maxiter = o.maxiter > 0 ? o.maxiter : 1000 + 4 * (nx + ny + nz);
-  HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  // A ring of slabs builds in lock-step: every stretch of rank-local work (allocations, set-up kernels) ends in oi::agree_status,
+  // so a slab that cannot get its memory takes its neighbours out with an error instead of leaving them in the next collective.
+  const hipError_t es = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   hipStream_t s = h->stream;
-  HIPC(oi::dev_malloc((void**)&h->code, (size_t)g.nvec));
-  for (int k = 0; k < 3; ++k) HIPC(oi::dev_malloc((void**)&h->chi[k], sizeof(double) * g.nvec));
-  HIPC(oi::dev_malloc((void**)&h->partials, sizeof(double) * 9 * g.tune.max_blocks));
-  HIPC(oi::dev_malloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
-  HIPC(oi::dev_malloc((void**)&h->scal, sizeof(double) * 16));
-  HIPC(oi::dev_malloc((void**)&h->ctrl, sizeof(Ctrl)));
-  HIPC(oi::dev_malloc((void**)&h->counter, sizeof(unsigned long long)));
-  HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
-  HIPC(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), s));
-  for (int k = 0; k < 3; ++k) HIPC(hipMemsetAsync(h->chi[k], 0, sizeof(double) * g.nvec, s));
   const size_t n = (size_t)nx * ny * nzl;
-  uint8_t* tmp = nullptr;
-  const uint8_t* dphase = phase;
-  if (!on_device) {
-    HIPC(oi::dev_malloc((void**)&tmp, n));
-    HIPC(hipMemcpyAsync(tmp, phase, n, hipMemcpyHostToDevice, s));
-    dphase = tmp;
-  }
-  hipLaunchKernelGGL(k_ed_codes, dim3(nblocks((long long)n, 8192)), dim3(256), 0, s, g, dphase, phase_id, h->code, h->counter);
+  auto local_codes = [&]() -> oi_status {
+    HIPC(es);
+    HIPC(oi::dev_malloc((void**)&h->code, (size_t)g.nvec));
+    for (int k = 0; k < 3; ++k) HIPC(oi::dev_malloc((void**)&h->chi[k], sizeof(double) * g.nvec));
+    HIPC(oi::dev_malloc((void**)&h->partials, sizeof(double) * 9 * g.tune.max_blocks));
+    HIPC(oi::dev_malloc((void**)&h->hist, sizeof(double) * H_STRIDE * (h->maxiter + 2)));
+    HIPC(oi::dev_malloc((void**)&h->scal, sizeof(double) * 16));
+    HIPC(oi::dev_malloc((void**)&h->ctrl, sizeof(Ctrl)));
+    HIPC(oi::dev_malloc((void**)&h->counter, sizeof(unsigned long long)));
+    HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
+    HIPC(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), s));
+    for (int k = 0; k < 3; ++k) HIPC(hipMemsetAsync(h->chi[k], 0, sizeof(double) * g.nvec, s));
+    uint8_t* tmp = nullptr;
+    const uint8_t* dphase = phase;
+    if (!on_device) {
+      HIPC(oi::dev_malloc((void**)&tmp, n));
+      const hipError_t eu = hipMemcpyAsync(tmp, phase, n, hipMemcpyHostToDevice, s);
+      if (eu != hipSuccess) { (void)oi::dev_free(tmp); HIPC(eu); }
+      dphase = tmp;
+    }
+    hipLaunchKernelGGL(k_ed_codes, dim3(nblocks((long long)n, 8192)), dim3(256), 0, s, g, dphase, phase_id, h->code, h->counter);
+    const hipError_t ek = hipStreamSynchronize(s);
+    if (tmp) (void)oi::dev_free(tmp);
+    HIPC(ek);
+    return OI_OK;
+  };
+  OIC(oi::agree_status(h->comm, local_codes(), s, "the allocation of the code bytes and the solution fields"));
   OIC(wrap_z(h.get(), h->code, (size_t)g.plane));
   unsigned long long cnt = 0;
   HIPC(hipMemcpyAsync(&cnt, h->counter, sizeof(cnt), hipMemcpyDeviceToHost, s));
   HIPC(hipStreamSynchronize(s));
-  if (tmp) HIPC(oi::dev_free(tmp));
   if (h->comm) OIC(h->comm->allreduce_sum_u64_host(&cnt, 1, s));
   h->n_active = (long long)cnt;
   // one multigrid cycle per PCG iteration (what PFMG is to the reference's FlexGMRES, EffectiveDiffusivityHypre.cpp:
@@ -395,61 +405,72 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   if (can) {
     const int LW = (g.pitch + kLV - 1) / kLV;
     const long long nlines = (long long)(nzl + 2) * ny * LW;
-    {
+    unsigned long long* d8 = nullptr;  // scratch of the ring's length proof
+    bool images = false;
+    int rot = 0;
+    auto local_lines = [&]() -> oi_status {
       HIPC(oi::dev_malloc((void**)&h->lineoff, sizeof(int) * (size_t)nlines));
       HIPC(oi::dev_malloc((void**)&h->plane_first_dev, sizeof(long long) * ((size_t)nzl + 3)));
       HIPC(oi::dev_malloc(&h->seg, sizeof(uint2) * (size_t)(nzl + 2) * ny * ((g.pitch + 127) / 128)));
+      if (h->comm) HIPC(oi::dev_malloc((void**)&d8, 8 * sizeof(unsigned long long)));
       HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, h->seg, s));
       h->plane_first.resize((size_t)nzl + 3);
       HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (nzl + 3), hipMemcpyDeviceToHost));
       const std::vector<long long>& pf = h->plane_first;
       // (the ghost planes carry the code bytes of their images: the same line lists, or the layout is not what wrap_lines assumes)
-      bool images = pf[1] - pf[0] == pf[nzl + 1] - pf[nzl] && pf[nzl + 2] - pf[nzl + 1] == pf[2] - pf[1];
+      images = pf[1] - pf[0] == pf[nzl + 1] - pf[nzl] && pf[nzl + 2] - pf[nzl + 1] == pf[2] - pf[1];
       g.live_lines = (float)((double)pf[nzl + 2] / (double)nlines);
-      int rot = fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, 0) && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg) ? 1 : 0;
-      if (h->comm) {
-        unsigned long long* d8 = nullptr;
-        HIPC(oi::dev_malloc((void**)&d8, 8 * sizeof(unsigned long long)));
-        int agree = 0;
-        const oi_status st8 = ring_lengths_agree(h.get(), d8, &agree);
-        (void)oi::dev_free(d8);
-        OIC(st8);
-        images = agree != 0;
+      rot = fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, 0) && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg) ? 1 : 0;
+      return OI_OK;
+    };
+    oi_status st = oi::agree_status(h->comm, local_lines(), s, "the set-up of the compacted line lists");
+    if (st == OI_OK && h->comm) {
+      int agree = 0;
+      st = ring_lengths_agree(h.get(), d8, &agree);
+      images = agree != 0;
+      if (st == OI_OK) {
         int no = (rot && images) ? 0 : 1;  // (the live-line share drives launch shapes: one value on every rank)
-        OIC(h->comm->allreduce_max_i32_host(&no, 1, s));
+        st = h->comm->allreduce_max_i32_host(&no, 1, s);
         rot = no ? 0 : 1;
       }
-      h->rot = images && rot;
-      if (h->rot) {
-        h->nvec_cg = std::max<long long>(16, (long long)kLV * pf[nzl + 2]);
-      } else {
-        (void)oi::dev_free(h->lineoff); (void)oi::dev_free(h->plane_first_dev); (void)oi::dev_free(h->seg);
-        h->lineoff = nullptr; h->plane_first_dev = nullptr; h->seg = nullptr;
-        g.live_lines = 0.f;
-      }
+    }
+    if (d8) (void)oi::dev_free(d8);
+    OIC(st);
+    h->rot = images && rot;
+    if (h->rot) {
+      h->nvec_cg = std::max<long long>(16, (long long)kLV * h->plane_first[nzl + 2]);
+    } else {
+      (void)oi::dev_free(h->lineoff); (void)oi::dev_free(h->plane_first_dev); (void)oi::dev_free(h->seg);
+      h->lineoff = nullptr; h->plane_first_dev = nullptr; h->seg = nullptr;
+      g.live_lines = 0.f;
     }
   }
-  HIPC(oi::dev_malloc((void**)&h->r, sizeof(double) * h->nvec_cg));
-  HIPC(oi::dev_malloc((void**)&h->p, sizeof(double) * h->nvec_cg));
-  HIPC(oi::dev_malloc((void**)&h->q, sizeof(double) * h->nvec_cg));
-  if (h->rot) HIPC(oi::dev_malloc((void**)&h->r2, sizeof(double) * h->nvec_cg));
+  // whether the fused two-kernel iteration runs (and needs a second p buffer) is known before the vectors are allocated:
+  // the LDS-tiled kernels of the flow-through path wrap x / y by index -> their fused two-kernel iteration.  Odd extents included
+  // (round 3): the coarse parent of the image planes beyond an odd nz is the coarse ghost plane (cplane_of in k_mg_fine), and with an
+  // odd nx the pair (nx - 1, pad) keeps the wrapped column 0 in its second LDS slot.  Without multigrid: plain CG (precond = none /
+  // jacobi is not offered here), the same two-kernel iteration with z = r
+  h->fused = want_mg ? !g.tune.mg_plain : (h->n_active > 0 && nx >= 4 && ny >= 2 && !g.tune.mg_plain);
+  auto local_vectors = [&]() -> oi_status {
+    HIPC(oi::dev_malloc((void**)&h->r, sizeof(double) * h->nvec_cg));
+    HIPC(oi::dev_malloc((void**)&h->p, sizeof(double) * h->nvec_cg));
+    HIPC(oi::dev_malloc((void**)&h->q, sizeof(double) * h->nvec_cg));
+    if (h->rot) HIPC(oi::dev_malloc((void**)&h->r2, sizeof(double) * h->nvec_cg));
+    if (want_mg) {
+      HIPC(oi::dev_malloc((void**)&h->z, sizeof(double) * h->nvec_cg));
+      HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
+    }
+    if (h->fused) {
+      HIPC(oi::dev_malloc((void**)&h->p2, sizeof(double) * h->nvec_cg));
+      HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
+    }
+    return OI_OK;
+  };
+  OIC(oi::agree_status(h->comm, local_vectors(), s, "the allocation of the CG vectors"));
   if (want_mg) {
-    HIPC(oi::dev_malloc((void**)&h->z, sizeof(double) * h->nvec_cg));
-    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
     size_t mg_bytes = 0;
-    h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);
+    h->mg = oi::mg_setup(g, h->code, h->comm, 1, s, &mg_bytes);  // (agrees on its own allocations)
     if (!h->mg) return OI_HIP_ERROR;
-    // the LDS-tiled kernels of the flow-through path wrap x / y by index -> their fused two-kernel iteration (needs a second p
-    // buffer).  Odd extents included (round 3): the coarse parent of the image planes beyond an odd nz is the coarse ghost plane
-    // (cplane_of in k_mg_fine), and with an odd nx the pair (nx - 1, pad) keeps the wrapped column 0 in its second LDS slot
-    h->fused = !g.tune.mg_plain;
-  } else if (h->n_active > 0 && nx >= 4 && ny >= 2 && !g.tune.mg_plain) {
-    // plain CG (precond = none / jacobi is not offered here): the same two-kernel iteration with z = r
-    h->fused = true;
-  }
-  if (h->fused) {
-    HIPC(oi::dev_malloc((void**)&h->p2, sizeof(double) * h->nvec_cg));
-    HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
   }
   *out = h.release();
   return OI_OK;
@@ -485,20 +506,27 @@ extern "C" oi_status oi_effdiff_solve(oi_effdiff* h, int dir_k, int* converged, 
     if (relres) *relres = 0.0;
     return OI_OK;
   }
-  HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * (h->maxiter + 2), s));
-  // (rotated iteration: r2 and p are written whole by launch 0 before anything reads them -- checked with both filled with NaNs
-  // before 450 solves of 150 shapes, tools/homog_oddnx_probe.py; r is cleared because k_ed_rhs_lines leaves the pad voxel of an odd
-  // nx alone -- garbage there enters ||r||^2 --, and what launch 0 READS beside r -- q_{-1} and p_{-1}, multiplied by alpha = beta = 0
-  // -- must be finite)
-  HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * h->nvec_cg, s));
-  if (!h->rot) HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * h->nvec_cg, s));
-  if (h->p2) HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
-  HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * h->nvec_cg, s));
-  HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));
   const long long n = (long long)g.nzl * g.ny * g.nx;
   const int nb0 = nblocks(n, 2048);
-  if (h->rot) hipLaunchKernelGGL(k_ed_rhs_lines, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, h->r, h->lineoff, (g.pitch + kLV - 1) / kLV, h->partials);
-  else hipLaunchKernelGGL(k_ed_rhs, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, chi, h->r, h->p, h->partials);
+  // (rank-local start of a solve; its outcome is agreed on before the first collective, so that a slab whose device has failed
+  // does not leave its neighbours waiting in the all-reduce of ||b||)
+  auto local_start = [&]() -> oi_status {
+    HIPC(hipMemsetAsync(h->hist, 0, sizeof(double) * H_STRIDE * (h->maxiter + 2), s));
+    // (rotated iteration: r2 and p are written whole by launch 0 before anything reads them -- checked with both filled with NaNs
+    // before 450 solves of 150 shapes, tools/homog_oddnx_probe.py; r is cleared because k_ed_rhs_lines leaves the pad voxel of an odd
+    // nx alone -- garbage there enters ||r||^2 --, and what launch 0 READS beside r -- q_{-1} and p_{-1}, multiplied by alpha = beta = 0
+    // -- must be finite)
+    HIPC(hipMemsetAsync(h->r, 0, sizeof(double) * h->nvec_cg, s));
+    if (!h->rot) HIPC(hipMemsetAsync(h->p, 0, sizeof(double) * h->nvec_cg, s));
+    if (h->p2) HIPC(hipMemsetAsync(h->p2, 0, sizeof(double) * h->nvec_cg, s));
+    HIPC(hipMemsetAsync(h->q, 0, sizeof(double) * h->nvec_cg, s));
+    HIPC(hipMemsetAsync(chi, 0, sizeof(double) * g.nvec, s));
+    if (h->rot) hipLaunchKernelGGL(k_ed_rhs_lines, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, h->r, h->lineoff, (g.pitch + kLV - 1) / kLV, h->partials);
+    else hipLaunchKernelGGL(k_ed_rhs, dim3(nb0), dim3(256), 0, s, g, h->code, dir_k, chi, h->r, h->p, h->partials);
+    HIPC(hipGetLastError());
+    return OI_OK;
+  };
+  OIC(oi::agree_status(h->comm, local_start(), s, "the start of a cell-problem solve"));
   Ctrl c;
   c.done = 0; c.pad = 0; c.tol2 = std::numeric_limits<double>::infinity();  // set once ||b|| is known
   HIPC(hipMemcpyAsync(h->ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice, s));

@@ -1265,14 +1265,13 @@ static bool finish_child_array(MgHierarchy* mg, const MgLevelHost& C, bool paren
   return ghost_exchange(mg, C, a, sizeof(float), s, imaged);  // neighbours' planes, or the periodic images, or nothing to do
 }
 
-#define MGC(call)                                                            \
+#define MGS(call)                                                            \
   do {                                                                       \
     hipError_t e_ = (call);                                                  \
     if (e_ != hipSuccess) {                                                  \
       oi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-      (void)hipGetLastError(); /* reported: do not leave it for the next launch check to find */ \
-      mg_destroy(mg);                                                        \
-      return nullptr;                                                        \
+      (void)hipGetLastError();                                               \
+      return OI_HIP_ERROR;                                                   \
     }                                                                        \
   } while (0)
 
@@ -1280,8 +1279,6 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   MgHierarchy* mg = new MgHierarchy();
   mg->comm = (comm && comm->size > 1) ? comm : nullptr;
   mg->periodic = periodic != 0;
-  int pnx = g.nx, pny = g.ny, pnz = g.nz, pz0 = g.z0, pnzl = g.nzl;
-  bool prep = false;  // parent replicated?
   long long replicate_cells = kReplicateCells;
   if (g.tune.mg_replicate_cells > 0) replicate_cells = g.tune.mg_replicate_cells;  // tests: distribute small levels too
   if (g.tune.mg_wmask >= 0) mg->wmask = (unsigned)g.tune.mg_wmask;                   // experiments with the cycle shape
@@ -1293,91 +1290,116 @@ MgHierarchy* mg_setup(const Geom& g, const uint8_t* code, oi_comm* comm, int per
   mg->coarsest_plain = g.tune.mg_coarsest_plain != 0;
   mg->coarse_tiled = g.tune.mg_coarse_tiled;
   mg->fused_images = g.tune.mg_fused_images != 0;
-  for (int l = 0; l < 24; ++l) {
-    MgLevelHost L;
-    L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
-    L.d.sz = (long long)L.d.nx * L.d.ny;
-    L.d.nzg = L.nz;
-    L.d.periodic = periodic ? 1 : 0;
-    L.d.omega = (g.tune.mg_omega_coarse > 0.f && g.tune.mg_omega_coarse <= 1.f) ? g.tune.mg_omega_coarse : mg->omega;
-    L.compact = l < kCompactLevels;
-    // keep the slab partition while every rank's slab starts on an even plane, holds at least two
-    // planes and the level is worth distributing; otherwise this and all deeper levels are replicated
-    L.replicated = prep;
-    if (mg->comm && !prep) {
-      int viol = ((pz0 & 1) || pnzl < 2 || L.d.sz * L.nz <= replicate_cells) ? 1 : 0;
-      if (mg->comm->allreduce_max_i32_host(&viol, 1, s) != OI_OK) { mg_destroy(mg); return nullptr; }
-      L.replicated = viol != 0;
-    }
-    if (mg->comm && !L.replicated) {
-      L.d.z0 = pz0 >> 1;
-      L.d.nzl = ((pz0 + pnzl + 1) >> 1) - L.d.z0;
-    } else {
-      L.d.z0 = 0;
-      L.d.nzl = L.nz;
-    }
-    L.d.zimg = (periodic && (!mg->comm || L.replicated)) ? 1 : 0;  // the cycle's kernels write the z images of what they store
-    L.n = L.d.sz * (L.d.nzl + 2);
-    const size_t wb = L.compact ? 1 : 4, db = L.compact ? 2 : 4;
-    MGC(oi::dev_malloc(&L.wx, wb * L.n)); MGC(oi::dev_malloc(&L.wy, wb * L.n)); MGC(oi::dev_malloc(&L.wz, wb * L.n));
-    MGC(oi::dev_malloc(&L.diag, db * L.n));
-    float** vecs[] = {&L.b, &L.b2, &L.r, &L.x2, &L.xs};
-    for (float** v : vecs) {
-      MGC(oi::dev_malloc((void**)v, sizeof(float) * L.n));
-      MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
-    }
-    mg->bytes += (size_t)L.n * (3 * wb + db + 5 * sizeof(float));
-    if (mg->nu_coarse > 1) {
-      float** more[] = {&L.t, &L.t2};
-      for (float** v : more) {
-        MGC(oi::dev_malloc((void**)v, sizeof(float) * L.n));
-        MGC(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
+  // ---- 1. plan ----
+  {
+    int pnx = g.nx, pny = g.ny, pnz = g.nz, pz0 = g.z0, pnzl = g.nzl;
+    bool prep = false;  // parent replicated?
+    for (int l = 0; l < 24; ++l) {
+      MgLevelHost L;
+      L.d.nx = (pnx + 1) / 2; L.d.ny = (pny + 1) / 2; L.nz = (pnz + 1) / 2;
+      L.d.sz = (long long)L.d.nx * L.d.ny;
+      L.d.nzg = L.nz;
+      L.d.periodic = periodic ? 1 : 0;
+      L.d.omega = (g.tune.mg_omega_coarse > 0.f && g.tune.mg_omega_coarse <= 1.f) ? g.tune.mg_omega_coarse : mg->omega;
+      L.compact = l < kCompactLevels;
+      // keep the slab partition while every rank's slab starts on an even plane, holds at least two
+      // planes and the level is worth distributing; otherwise this and all deeper levels are replicated
+      L.replicated = prep;
+      if (mg->comm && !prep) {
+        int viol = ((pz0 & 1) || pnzl < 2 || L.d.sz * L.nz <= replicate_cells) ? 1 : 0;
+        if (mg->comm->allreduce_max_i32_host(&viol, 1, s) != OI_OK) { mg_destroy(mg); return nullptr; }
+        L.replicated = viol != 0;
       }
-      mg->bytes += (size_t)L.n * 2 * sizeof(float);
+      if (mg->comm && !L.replicated) {
+        L.d.z0 = pz0 >> 1;
+        L.d.nzl = ((pz0 + pnzl + 1) >> 1) - L.d.z0;
+      } else {
+        L.d.z0 = 0;
+        L.d.nzl = L.nz;
+      }
+      L.d.zimg = (periodic && (!mg->comm || L.replicated)) ? 1 : 0;  // the cycle's kernels write the z images of what they store
+      L.n = L.d.sz * (L.d.nzl + 2);
+      mg->levels.push_back(L);
+      pnx = L.d.nx; pny = L.d.ny; pnz = L.nz; pz0 = L.d.z0; pnzl = L.d.nzl; prep = L.replicated;
+      const long long cells = L.d.sz * L.nz;
+      if (cells <= kCoarsestCells || (L.d.nx == 1 && L.d.ny == 1 && L.nz == 1)) break;
     }
+  }
+  // ---- 2. allocate (rank-local), then agree ----
+  float* t[4] = {nullptr, nullptr, nullptr, nullptr};  // float scratch of the compact levels' operators (sized for the largest)
+  auto free_scratch = [&] { for (auto& p : t) { if (p) (void)oi::dev_free(p); p = nullptr; } };
+  auto allocate = [&]() -> oi_status {
+    long long tn = 0;
+    for (MgLevelHost& L : mg->levels) {
+      const size_t wb = L.compact ? 1 : 4, db = L.compact ? 2 : 4;
+      MGS(oi::dev_malloc(&L.wx, wb * L.n)); MGS(oi::dev_malloc(&L.wy, wb * L.n)); MGS(oi::dev_malloc(&L.wz, wb * L.n));
+      MGS(oi::dev_malloc(&L.diag, db * L.n));
+      float** vecs[] = {&L.b, &L.b2, &L.r, &L.x2, &L.xs};
+      for (float** v : vecs) {
+        MGS(oi::dev_malloc((void**)v, sizeof(float) * L.n));
+        MGS(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
+      }
+      mg->bytes += (size_t)L.n * (3 * wb + db + 5 * sizeof(float));
+      if (mg->nu_coarse > 1) {
+        float** more[] = {&L.t, &L.t2};
+        for (float** v : more) {
+          MGS(oi::dev_malloc((void**)v, sizeof(float) * L.n));
+          MGS(hipMemsetAsync(*v, 0, sizeof(float) * L.n, s));
+        }
+        mg->bytes += (size_t)L.n * 2 * sizeof(float);
+      }
+      if (L.compact) tn = std::max(tn, L.n);
+    }
+    if (tn > 0)
+      for (auto& p : t) MGS(oi::dev_malloc((void**)&p, sizeof(float) * tn));
+    return OI_OK;
+  };
+  if (oi::agree_status(mg->comm, allocate(), s, "the allocation of the multigrid hierarchy") != OI_OK) {
+    free_scratch();
+    mg_destroy(mg);
+    return nullptr;
+  }
+  // ---- 3. build ----
+  bool ok = true;
+  for (size_t l = 0; l < mg->levels.size() && ok; ++l) {
+    MgLevelHost& L = mg->levels[l];
+    const bool prep = l > 0 && mg->levels[l - 1].replicated;
+    const int pz0 = l > 0 ? mg->levels[l - 1].d.z0 : g.z0, pnzl = l > 0 ? mg->levels[l - 1].d.nzl : g.nzl;
     // operator: owned contributions into float arrays, summed / exchanged, then (compact levels) narrowed
-    float* t[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (L.compact) {
-      for (auto& p : t) MGC(oi::dev_malloc((void**)&p, sizeof(float) * L.n));
-    } else {
-      t[0] = (float*)L.wx; t[1] = (float*)L.wy; t[2] = (float*)L.wz; t[3] = (float*)L.diag;
-    }
-    for (auto p : t) MGC(hipMemsetAsync(p, 0, sizeof(float) * L.n, s));
+    float* a[4] = {t[0], t[1], t[2], t[3]};
+    if (!L.compact) { a[0] = (float*)L.wx; a[1] = (float*)L.wy; a[2] = (float*)L.wz; a[3] = (float*)L.diag; }
+    for (auto p : a) ok = ok && hipMemsetAsync(p, 0, sizeof(float) * L.n, s) == hipSuccess;
+    if (!ok) break;
     int kfirst = 1, nplanes = L.d.nzl;
     if (L.replicated && !prep && mg->comm) child_span(L, pz0, pnzl, &kfirst, &nplanes);
     if (L.blocks(nplanes) > 0) {
       if (l == 0) {
-        hipLaunchKernelGGL(k_mg_build1, dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s, g, code, L.d, kfirst, t[0], t[1], t[2], t[3]);
+        hipLaunchKernelGGL(k_mg_build1, dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s, g, code, L.d, kfirst, a[0], a[1], a[2], a[3]);
       } else {
-        const MgLevelHost& P = mg->levels.back();
+        const MgLevelHost& P = mg->levels[l - 1];
         if (P.compact)
           hipLaunchKernelGGL((k_mg_build<uint8_t, uint16_t>), dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s,
-                             P.dev<uint8_t, uint16_t>(), L.d, kfirst, t[0], t[1], t[2], t[3]);
+                             P.dev<uint8_t, uint16_t>(), L.d, kfirst, a[0], a[1], a[2], a[3]);
         else
           hipLaunchKernelGGL((k_mg_build<float, float>), dim3(L.blocks(nplanes)), dim3(L.bx()), 0, s, P.dev<float, float>(),
-                             L.d, kfirst, t[0], t[1], t[2], t[3]);
+                             L.d, kfirst, a[0], a[1], a[2], a[3]);
       }
     }
-    bool ok = true;
     if (L.replicated) {
-      for (auto p : t) ok = ok && finish_child_array(mg, L, prep, p, s);
+      for (auto p : a) ok = ok && finish_child_array(mg, L, prep, p, s);
     } else {  // the cycle reads the diagonal and the +z weights of the ghost planes
-      ok = finish_child_array(mg, L, prep, t[2], s) && finish_child_array(mg, L, prep, t[3], s);
+      ok = finish_child_array(mg, L, prep, a[2], s) && finish_child_array(mg, L, prep, a[3], s);
     }
-    if (L.compact) {
-      if (ok)
-        hipLaunchKernelGGL(k_mg_compact, dim3(nblk(L.n)), dim3(256), 0, s, L.n, t[0], t[1], t[2], t[3], (uint8_t*)L.wx,
-                           (uint8_t*)L.wy, (uint8_t*)L.wz, (uint16_t*)L.diag);
-      (void)hipStreamSynchronize(s);
-      for (auto p : t) (void)oi::dev_free(p);
-    }
-    mg->levels.push_back(L);
-    if (!ok) { mg_destroy(mg); return nullptr; }
-    pnx = L.d.nx; pny = L.d.ny; pnz = L.nz; pz0 = L.d.z0; pnzl = L.d.nzl; prep = L.replicated;
-    const long long cells = L.d.sz * L.nz;
-    if (cells <= kCoarsestCells || (L.d.nx == 1 && L.d.ny == 1 && L.nz == 1)) break;
+    if (L.compact && ok)
+      hipLaunchKernelGGL(k_mg_compact, dim3(nblk(L.n)), dim3(256), 0, s, L.n, a[0], a[1], a[2], a[3], (uint8_t*)L.wx,
+                         (uint8_t*)L.wy, (uint8_t*)L.wz, (uint16_t*)L.diag);
   }
-  MGC(hipStreamSynchronize(s));
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    if (ok) oi::set_error("multigrid set-up: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    ok = false;
+  }
+  free_scratch();
+  if (!ok) { mg_destroy(mg); return nullptr; }
   if (bytes_out) *bytes_out = mg->bytes;
   return mg;
 }

@@ -732,39 +732,43 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     HIPC(hipEventCreateWithFlags(&h->ev_interior, hipEventDisableTiming));
   }
 
-  OIC(dmalloc(h, &h->open, (size_t)g.nwords));
-  OIC(dmalloc(h, &h->active, (size_t)g.nwords));
-  OIC(dmalloc(h, &h->rhi, (size_t)g.nwords));
-  OIC(dmalloc(h, &h->counters, 8));
-  OIC(dmalloc(h, &h->changed, 1));
-  OIC(dmalloc(h, &h->scal, 8));
-  OIC(dmalloc(h, &h->partials, (size_t)8 * g.tune.max_blocks));
-  // slice sums + ticket of k_finalize1_sliced: their own array (the ticket must stay zero between launches, so nothing else may
-  // ever write there -- round 3 carved it out of the tail of `partials`, safe only while no kernel used the full stride)
-  OIC(dmalloc(h, &h->fin_scratch, (size_t)kFinScratch));
-  HIPC(hipMemsetAsync(h->fin_scratch, 0, sizeof(double) * kFinScratch, h->stream));
-  OIC(dmalloc(h, &h->ctrl, 1));
-  HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
-  HIPC(hipHostMalloc((void**)&h->h_counters, 8 * sizeof(unsigned long long)));
-  HIPC(hipHostMalloc((void**)&h->h_changed, sizeof(int)));
-  HIPC(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double)));
-  HIPC(hipMemsetAsync(h->open, 0, sizeof(uint64_t) * g.nwords, s));
-  HIPC(hipMemsetAsync(h->active, 0, sizeof(uint64_t) * g.nwords, s));
-  HIPC(hipMemsetAsync(h->rhi, 0, sizeof(uint64_t) * g.nwords, s));
-  HIPC(hipMemsetAsync(h->counters, 0, 8 * sizeof(unsigned long long), s));
-
-  // phase bytes -> open bits (+ phase voxel count)
+  // Slabs build in lock-step: every stretch of rank-local work (allocations, set-up kernels) between two collectives ends in
+  // oi::agree_status, so a slab that cannot get its memory takes its neighbours out with an error instead of leaving them waiting.
   const size_t nphase = (size_t)g.nx * g.ny * g.nzl;
-  const uint8_t* dphase = phase;
-  uint8_t* tmp = nullptr;
-  if (!on_device) {
-    HIPC(oi::dev_malloc((void**)&tmp, nphase));
-    HIPC(hipMemcpyAsync(tmp, phase, nphase, hipMemcpyHostToDevice, s));
-    dphase = tmp;
-  }
-  { PROF(K_PACK); launch_pack_open(dphase, g, h->phase_id, h->open, &h->counters[3], s); }
-  HIPC(hipStreamSynchronize(s));
-  if (tmp) HIPC(oi::dev_free(tmp));
+  auto local_bits = [&]() -> oi_status {
+    OIC(dmalloc(h, &h->open, (size_t)g.nwords));
+    OIC(dmalloc(h, &h->active, (size_t)g.nwords));
+    OIC(dmalloc(h, &h->rhi, (size_t)g.nwords));
+    OIC(dmalloc(h, &h->counters, 8));
+    OIC(dmalloc(h, &h->changed, 1));
+    OIC(dmalloc(h, &h->scal, 8));
+    OIC(dmalloc(h, &h->partials, (size_t)8 * g.tune.max_blocks));
+    // slice sums + ticket of k_finalize1_sliced: their own array (the ticket must stay zero between launches, so nothing else may
+    // ever write there -- round 3 carved it out of the tail of `partials`, safe only while no kernel used the full stride)
+    OIC(dmalloc(h, &h->fin_scratch, (size_t)kFinScratch));
+    HIPC(hipMemsetAsync(h->fin_scratch, 0, sizeof(double) * kFinScratch, h->stream));
+    OIC(dmalloc(h, &h->ctrl, 1));
+    HIPC(hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl)));
+    HIPC(hipHostMalloc((void**)&h->h_counters, 8 * sizeof(unsigned long long)));
+    HIPC(hipHostMalloc((void**)&h->h_changed, sizeof(int)));
+    HIPC(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double)));
+    HIPC(hipMemsetAsync(h->open, 0, sizeof(uint64_t) * g.nwords, s));
+    HIPC(hipMemsetAsync(h->active, 0, sizeof(uint64_t) * g.nwords, s));
+    HIPC(hipMemsetAsync(h->rhi, 0, sizeof(uint64_t) * g.nwords, s));
+    HIPC(hipMemsetAsync(h->counters, 0, 8 * sizeof(unsigned long long), s));
+    // phase bytes -> open bits (+ phase voxel count)
+    const uint8_t* dphase = phase;
+    DevTmp<uint8_t> tmp;
+    if (!on_device) {
+      HIPC(oi::dev_malloc((void**)&tmp.p, nphase));
+      HIPC(hipMemcpyAsync(tmp.p, phase, nphase, hipMemcpyHostToDevice, s));
+      dphase = tmp.p;
+    }
+    { PROF(K_PACK); launch_pack_open(dphase, g, h->phase_id, h->open, &h->counters[3], s); }
+    HIPC(hipStreamSynchronize(s));
+    return OI_OK;
+  };
+  OIC(oi::agree_status(h->comm, local_bits(), s, "the allocation of the mask bits"));
   h->st.t_upload_s = now_s() - t0;
 
   // flood fill from both faces (generateActivityMask, TortuosityHypre.cpp:394-558)
@@ -828,10 +832,14 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
 
   // the matrix: one code byte per voxel
   const double t2 = now_s();
-  OIC(dmalloc(h, &h->code, (size_t)g.nvec));
-  HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
-  HIPC(hipMemsetAsync(h->counters, 0, 8 * sizeof(unsigned long long), s));
-  { PROF(K_CODES); launch_codes(g, h->active, h->code, &h->counters[0], s); }
+  auto local_codes = [&]() -> oi_status {
+    OIC(dmalloc(h, &h->code, (size_t)g.nvec));
+    HIPC(hipMemsetAsync(h->code, 0, (size_t)g.nvec, s));
+    HIPC(hipMemsetAsync(h->counters, 0, 8 * sizeof(unsigned long long), s));
+    { PROF(K_CODES); launch_codes(g, h->active, h->code, &h->counters[0], s); }
+    return OI_OK;
+  };
+  OIC(oi::agree_status(h->comm, local_codes(), s, "the allocation of the code bytes"));
   OIC(exchange_planes(h, h->code, (size_t)g.plane));
   HIPC(hipMemcpyAsync(h->h_counters, h->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIPC(hipStreamSynchronize(s));
@@ -843,7 +851,7 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
 
   h->maxiter = h->opts.maxiter > 0 ? h->opts.maxiter : 40 * (g.nx + g.ny + g.nz);
   h->hist_cap = h->maxiter + 2;
-  OIC(dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap));
+  OIC(oi::agree_status(h->comm, dmalloc(h, &h->hist, (size_t)H_STRIDE * h->hist_cap), s, "the allocation of the iteration history"));
   // (x of the single-kernel variant may join the vector arena, see alloc_vector_slots)
   h->nvec_cg = g.nvec;
   const bool want_mg = h->opts.precond == OI_PRECOND_MG;
@@ -858,41 +866,57 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     int dense = ((h->cg1 || mg_compact) && nlines < (1ll << 31)) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&dense, 1, s));
     if (!dense) {
-      OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
-      OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));
-      OIC(dmalloc(h, &h->seg, (size_t)(g.nzl + 2) * g.ny * ((g.pitch + 127) / 128)));  // segment records (k_cg1b, both forms)
-      HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, h->seg, s));
-      h->plane_first.resize((size_t)g.nzl + 3);
-      HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
-      h->nvec_cg = std::max<long long>(16, (long long)oi::kLV * h->plane_first[g.nzl + 2]);
-      g.live_lines = (float)((double)h->plane_first[g.nzl + 2] / (double)nlines);
+      auto local_lines = [&]() -> oi_status {
+        OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
+        OIC(dmalloc(h, &h->plane_first_dev, (size_t)g.nzl + 3));
+        OIC(dmalloc(h, &h->seg, (size_t)(g.nzl + 2) * g.ny * ((g.pitch + 127) / 128)));  // segment records (k_cg1b, both forms)
+        HIPC(launch_build_lines(g, h->code, h->lineoff, h->plane_first_dev, h->seg, s));
+        h->plane_first.resize((size_t)g.nzl + 3);
+        HIPC(hipMemcpy(h->plane_first.data(), h->plane_first_dev, sizeof(long long) * (g.nzl + 3), hipMemcpyDeviceToHost));
+        h->nvec_cg = std::max<long long>(16, (long long)oi::kLV * h->plane_first[g.nzl + 2]);
+        g.live_lines = (float)((double)h->plane_first[g.nzl + 2] / (double)nlines);
+        return OI_OK;
+      };
+      OIC(oi::agree_status(h->comm, local_lines(), s, "the set-up of the compacted line lists"));
       OIC(check_plane_message_lengths(h, s));
     }
   }
   if (h->cg1) {
-    OIC(dmalloc(h, &h->rec, (size_t)kRec1Stride * h->hist_cap));
     // (on slabs every rank must take the same decision: the search runs iterations, and those have collectives inside)
     int no_search = (g.tune.place_trials > 0 && h->hist_cap >= 4 && (size_t)h->nvec_cg * sizeof(double) >= ((size_t)g.tune.place_min_mb << 20)) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&no_search, 1, s));
-    OIC(vecset_alloc(h, !no_search));
-    const int first[6] = {0, 1, 2, 3, 4, 5};
-    assign_slots(h, first);
-    if (!h->vs.x) OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+    auto local_vectors = [&]() -> oi_status {
+      OIC(dmalloc(h, &h->rec, (size_t)kRec1Stride * h->hist_cap));
+      OIC(vecset_alloc(h, !no_search));
+      const int first[6] = {0, 1, 2, 3, 4, 5};
+      assign_slots(h, first);
+      if (!h->vs.x) OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+      return OI_OK;
+    };
+    OIC(oi::agree_status(h->comm, local_vectors(), s, "the allocation of the CG vectors"));
   } else {
-    OIC(dmalloc(h, &h->x, (size_t)g.nvec));
-    OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
-    if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)h->nvec_cg));
-    for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
-      HIPC(oi::dev_malloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
-      h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
-    }
+    auto local_vectors = [&]() -> oi_status {
+      OIC(dmalloc(h, &h->x, (size_t)g.nvec));
+      OIC(dmalloc(h, &h->r, (size_t)h->nvec_cg));
+      if (!h->lean) OIC(dmalloc(h, &h->q, (size_t)h->nvec_cg));
+      for (int b = 0; b < (h->fused ? 2 : 1); ++b) {
+        HIPC(oi::dev_malloc(&h->p[b], (size_t)h->nvec_cg * h->p_elem));
+        h->bytes_device += (size_t)h->nvec_cg * h->p_elem;
+      }
+      if (want_mg) {
+        OIC(dmalloc(h, &h->z, (size_t)h->nvec_cg));
+        HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
+      }
+      return OI_OK;
+    };
+    OIC(oi::agree_status(h->comm, local_vectors(), s, "the allocation of the CG vectors"));
   }
   if (want_mg && h->fused && h->lineoff) {
     // the rotated iteration (residual update fused into the pre-smoother): every slab must be able to run it
     int cannot = (fused_descr_ok(g, h->lineoff, h->plane_first_dev, h->seg, h->jacobi ? 1 : 0) && h->mg_tiled && (g.z0 & 1) == 0 && !g.tune.mg_norot) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&cannot, 1, s));
     h->rot = !cannot;
-    if (h->rot) OIC(dmalloc(h, &h->r2, (size_t)h->nvec_cg));
+    if (h->rot) OIC(oi::agree_status(h->comm, dmalloc(h, &h->r2, (size_t)h->nvec_cg), s, "the allocation of the second residual buffer"));
   }
   if (want_mg && g.tune.mg_nu_coarse == 0) {
     // sweeps per coarse-level visit by the structure (every slab the same: the cycle has collectives inside)
@@ -901,10 +925,8 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
     g.tune.mg_nu_coarse = one ? 1 : 2;
   }
   if (want_mg) {
-    OIC(dmalloc(h, &h->z, (size_t)h->nvec_cg));
-    HIPC(hipMemsetAsync(h->z, 0, sizeof(double) * h->nvec_cg, s));
     size_t mg_bytes = 0;
-    h->mg = mg_setup(g, h->code, h->comm, 0, s, &mg_bytes);
+    h->mg = mg_setup(g, h->code, h->comm, 0, s, &mg_bytes);  // (agrees on its own allocations)
     if (!h->mg) return OI_HIP_ERROR;
     h->bytes_device += mg_bytes;
     if (h->opts.verbose > 1)

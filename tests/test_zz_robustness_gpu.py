@@ -270,3 +270,63 @@ def test_searching_single_kernel_handles_release_their_arenas(oi_option):
         assert oia.dev_live() == live_ph
     ph.free()
     assert oia.dev_live() == live0
+
+
+def _slab_builds_with_a_refused_allocation(make, nranks, nz, n_fail):
+    """`nranks` host threads build one slab each; the driver refuses allocation number `n_fail` (whichever slab asks for it).
+    Returns (number of slabs that failed, their messages); asserts that nobody hangs and nothing leaks."""
+    import threading
+    comms = oia.Comm.create_local(nranks)
+    live1 = oia.dev_live()
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            z0, z1 = oia.slab_range(nz, nranks, r)
+            h = make(comms[r], z0, z1)
+            out[r] = h
+        except oia.OpenImpalaError as e:
+            err[r] = str(e)
+
+    oia.debug_fail_alloc_after(n_fail)
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    oia.debug_fail_alloc_after(0)
+    assert not any(t.is_alive() for t in th), f"slab threads hung with allocation {n_fail} refused"
+    failed = [e for e in err if e is not None]
+    # all or nothing: the slabs agree on the outcome of every set-up step
+    assert len(failed) in (0, nranks), (n_fail, err)
+    for h in out:
+        if h is not None:
+            h.destroy()
+    assert oia.dev_live() == live1, (n_fail, oia.dev_live(), live1)
+    for c in comms:
+        c.destroy()
+    return len(failed), failed
+
+
+def test_a_slab_that_cannot_allocate_takes_its_neighbours_out_with_an_error(sample):
+    """ADVICE r4 (oi_effdiff.hip ring set-up; the same pattern in the flow-through build and the multigrid hierarchy): an allocation
+    that fails on ONE in-process rank used to leave its peers in the next collective for good.  Every rank-local stretch of a set-up
+    now ends in an agreement (oi::agree_status): all slabs return an error -- the failing one its own, the others 'another slab
+    failed' -- nobody waits, nothing is left allocated."""
+    sub = np.ascontiguousarray(sample[:48, :40, :44])
+    nz = sub.shape[0]
+    live0 = oia.dev_live()
+    makers = {
+        "tortuosity mg": lambda c, z0, z1: oia.TortuosityMI355(np.ascontiguousarray(sub[z0:z1]), 1, 0, eps=1e-8, comm=c, z0=z0, nz_global=nz),
+        "tortuosity cg1": lambda c, z0, z1: oia.TortuosityMI355(np.ascontiguousarray(sub[z0:z1]), 1, 2, eps=1e-8, kernel=oia.KERNEL_FUSED1, comm=c, z0=z0, nz_global=nz),
+        "homogenization ring": lambda c, z0, z1: oia.EffectiveDiffusivityMI355(np.ascontiguousarray(sub[z0:z1]), 1, eps=1e-8, precond=oia.PRECOND_MG, comm=c, z0=z0, nz_global=nz),
+    }
+    for name, make in makers.items():
+        seen_other = False
+        for n_fail in list(range(1, 60, 3)) + list(range(60, 400, 17)):
+            nfailed, msgs = _slab_builds_with_a_refused_allocation(make, 2, nz, n_fail)
+            if nfailed == 0:
+                break   # the build makes fewer allocations than that: every step has been covered
+            seen_other = seen_other or any("another slab failed" in m for m in msgs)
+        else:
+            raise AssertionError(f"{name}: the build never went through")
+        assert seen_other, name   # (at least once the failure was somebody else's)
+    assert oia.dev_live() == live0
