@@ -311,12 +311,31 @@ struct LocalComm : oi_comm {
   oi_status allreduce_sum_f32(float* dev, size_t n, hipStream_t s) override {
     if (size == 1) return OI_OK;
     if (size > oi::kMaxSumRanks) return OI_BAD_ARG;
+    // (the scratch grows on demand: a rank that cannot get it must not leave the others at the barrier -- everybody learns of it
+    // at the first rendezvous and everybody returns the error)
+    int failed = 0;
     if (sh->big_cap[rank] < n) {
-      HIPC(hipStreamSynchronize(s));
-      if (sh->big[rank]) HIPC(oi::dev_free(sh->big[rank]));
+      if (hipStreamSynchronize(s) != hipSuccess) failed = 1;
+      if (sh->big[rank]) (void)oi::dev_free(sh->big[rank]);
       sh->big[rank] = nullptr;
-      HIPC(oi::raw_malloc((void**)&sh->big[rank], sizeof(float) * n));
-      sh->big_cap[rank] = n;
+      sh->big_cap[rank] = 0;
+      if (!failed && oi::raw_malloc((void**)&sh->big[rank], sizeof(float) * n) != hipSuccess) {
+        (void)hipGetLastError();
+        sh->big[rank] = nullptr;
+        failed = 1;
+      }
+      if (!failed) sh->big_cap[rank] = n;
+    }
+    sh->hi32[rank * 16] = failed;
+    sh->barrier();
+    int any = 0;
+    for (int r = 0; r < size; ++r) any |= sh->hi32[r * 16];
+    sh->barrier();  // (everyone has read the flags before anyone's next collective overwrites them)
+    if (any) {
+      oi::set_error(failed ? "in-process transport: no device memory for the %zu-byte scratch of a large all-reduce (slab %d)"
+                           : "in-process transport: another slab could not allocate the scratch of a large all-reduce (%zu bytes; this is slab %d)",
+                    sizeof(float) * n, rank);
+      return OI_HIP_ERROR;
     }
     sh->send_lo[rank] = dev;
     HIPC(hipEventRecord(sh->ev_ready[rank], s));

@@ -272,12 +272,12 @@ def test_searching_single_kernel_handles_release_their_arenas(oi_option):
     assert oia.dev_live() == live0
 
 
-def _slab_builds_with_a_refused_allocation(make, nranks, nz, n_fail):
+def _slab_builds_with_a_refused_allocation(name, make, nranks, nz, n_fail):
     """`nranks` host threads build one slab each; the driver refuses allocation number `n_fail` (whichever slab asks for it).
     Returns (number of slabs that failed, their messages); asserts that nobody hangs and nothing leaks."""
     import threading
-    comms = oia.Comm.create_local(nranks)
     live1 = oia.dev_live()
+    comms = oia.Comm.create_local(nranks)
     out, err = [None] * nranks, [None] * nranks
 
     def work(r):
@@ -289,20 +289,20 @@ def _slab_builds_with_a_refused_allocation(make, nranks, nz, n_fail):
             err[r] = str(e)
 
     oia.debug_fail_alloc_after(n_fail)
-    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]   # (daemon: a hang fails the test, not the exit)
     [t.start() for t in th]
     [t.join(timeout=120) for t in th]
     oia.debug_fail_alloc_after(0)
-    assert not any(t.is_alive() for t in th), f"slab threads hung with allocation {n_fail} refused"
+    assert not any(t.is_alive() for t in th), f"{name}: slab threads hung with allocation {n_fail} refused"
     failed = [e for e in err if e is not None]
     # all or nothing: the slabs agree on the outcome of every set-up step
     assert len(failed) in (0, nranks), (n_fail, err)
     for h in out:
         if h is not None:
             h.destroy()
-    assert oia.dev_live() == live1, (n_fail, oia.dev_live(), live1)
     for c in comms:
         c.destroy()
+    assert oia.dev_live() == live1, (n_fail, oia.dev_live(), live1)   # (the transport's staging buffers went with it)
     return len(failed), failed
 
 
@@ -322,7 +322,7 @@ def test_a_slab_that_cannot_allocate_takes_its_neighbours_out_with_an_error(samp
     for name, make in makers.items():
         seen_other = False
         for n_fail in list(range(1, 60, 3)) + list(range(60, 400, 17)):
-            nfailed, msgs = _slab_builds_with_a_refused_allocation(make, 2, nz, n_fail)
+            nfailed, msgs = _slab_builds_with_a_refused_allocation(name, make, 2, nz, n_fail)
             if nfailed == 0:
                 break   # the build makes fewer allocations than that: every step has been covered
             seen_other = seen_other or any("another slab failed" in m for m in msgs)
