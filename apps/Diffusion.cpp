@@ -8,8 +8,8 @@
 // through the TortuosityMI355 mirror of OpenImpala::TortuosityHypre.
 //
 // Scope: calculation_method = flow_through (the hot path) and homogenization (first cut of
-// the "next" row: three periodic cell problems + D_eff tensor, single GPU).  The REV
-// sampling study (rev.do_study) is not implemented.
+// the "next" row: three periodic cell problems + D_eff tensor, one GPU or a ring of z-slabs), the REV
+// sampling study (rev.do_study), the chi_k / potential plotfiles and the CathodeWrite exporters (cathode.*).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -31,6 +31,7 @@
 
 #include "../include/TortuosityMI355.H"
 #include "Inputs.H"
+#include "CathodeWrite.H"
 #include "Plotfile.H"
 
 namespace {
@@ -201,6 +202,24 @@ int main(int argc, char* argv[]) {
       else if (hl == "none" || hl == "jacobi") hopts.precond = OI_PRECOND_NONE;  // (the diagonal is constant: Jacobi = none)
       else throw std::runtime_error("gpu.precond must be mg, jacobi or none (got '" + hp + "')");
     }
+    // ---- cathode.*: the reference's CathodeWrite exporters (src/io/CathodeWrite.cpp; no caller in the reference -- wired here behind
+    // keys of their own).  cathode.dandeliion_file / cathode.pybamm_file name the files (in the results directory); the solid volume
+    // fraction is the analysed phase's unless cathode.volume_fraction_solid gives one ----
+    auto write_cathode_files = [&](double vf_phase) {
+      std::string f_dl, f_pb;
+      in.query("cathode.dandeliion_file", f_dl);
+      in.query("cathode.pybamm_file", f_pb);
+      if (f_dl.empty() && f_pb.empty()) return;
+      OpenImpala::CathodeParams cp;
+      cp.volume_fraction_solid = vf_phase;
+      in.query("cathode.volume_fraction_solid", cp.volume_fraction_solid);
+      in.query("cathode.particle_radius", cp.particle_radius);
+      in.query("cathode.conductivity", cp.active_material_conductivity);
+      in.query("cathode.max_concentration", cp.max_concentration);
+      const OpenImpala::CathodeWrite w(cp);
+      if (!f_dl.empty() && !w.writeDandeLiionParameters((results_dir / f_dl).string())) std::cerr << "Warning: DandeLiion parameter file not written\n";
+      if (!f_pb.empty() && !w.writePyBammParameters((results_dir / f_pb).string())) std::cerr << "Warning: PyBamm parameter file not written\n";
+    };
     const char* axis_names[3] = {"X", "Y", "Z"};
     // gpu.ngpus > 1 for the FULL-domain cell problems: z-slabs on a RING of ranks (periodic z: the first and the last slab are
     // neighbours), one host thread per slab, RCCL over xGMI or -- gpu.transport = local -- all slabs on one GPU (rehearsal)
@@ -209,7 +228,23 @@ int main(int argc, char* argv[]) {
     in.query("gpu.ngpus", h_ngpus);
     in.query("gpu.transport", h_transport);
     // three chi_k solves + tensor on one (sub-)volume; false when a solve does not converge (:545-548)
-    auto homogenize_ring = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9]) -> bool {
+    // chi_k plotfile of the reference (EffectiveDiffusivityHypre.cpp:648-680): <dir>/effdiff_chi_dir<k> with the components
+    // {"chi_k", "active_mask_from_solver"} -- the mask of the cell problem is phase == phase_id
+    auto write_chi_plotfile = [&](const std::string& dir, int k, const uint8_t* ph, int nx, int ny, int nz, const std::vector<double>& chi, int vb) {
+      std::error_code ec;
+      std::filesystem::create_directories(dir, ec);
+      if (vb > 0) std::cout << "  Writing solution plotfile for chi_k in direction " << k << "..." << std::endl;
+      std::vector<double> mask_d((size_t)nx * ny * nz);
+      for (size_t t = 0; t < mask_d.size(); ++t) mask_d[t] = ph[t] == (uint8_t)phase_id ? 1.0 : 0.0;
+      const std::string full = dir + "/effdiff_chi_dir" + std::to_string(k);
+      if (!OpenImpala::writeSingleLevelPlotfile(full, nx, ny, nz, {chi.data(), mask_d.data()}, {"chi_k", "active_mask_from_solver"}, box_size))
+        std::cerr << "Warning: could not write plotfile " << full << "\n";
+      else if (vb > 0)
+        std::cout << "  Plotfile written to " << full << std::endl;
+    };
+    // (plot_dirs: null, or the three directories the chi_k plotfiles go to)
+    auto homogenize_ring = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9],
+                               const std::vector<std::string>* plot_dirs) -> bool {
       const int N = h_ngpus;
       if (N > 64 || N > nz) throw std::runtime_error("gpu.ngpus must be between 1 and min(64, nz)");
       if (h_transport != "rccl" && h_transport != "local") throw std::runtime_error("gpu.transport must be rccl or local");
@@ -237,6 +272,10 @@ int main(int argc, char* argv[]) {
       double rel3[3] = {0, 0, 0};
       std::vector<double> Ds((size_t)9 * N, 0.0);
       const size_t plane = (size_t)nx * ny;
+      std::vector<double> chi_full[3];   // every slab writes its planes of chi_k here when plotfiles are wanted
+      if (plot_dirs)
+        for (auto& c : chi_full) c.assign(plane * nz, 0.0);
+      std::vector<int> got_chi(3 * N, 0);
       auto work = [&](int r) {
         oi_effdiff* eh = nullptr;
         do {
@@ -256,6 +295,7 @@ int main(int argc, char* argv[]) {
             if (cs != OI_OK) { errors[r] = std::string(oi_status_string(cs)) + ": " + oi_last_error(); allconv[r] = 0; break; }
             if (r == 0) { conv3[k] = conv; it3[k] = iters; rel3[k] = rel; }
             if (!conv) allconv[r] = 0;
+            else if (plot_dirs) got_chi[3 * r + k] = oi_effdiff_get_chi(eh, k, chi_full[k].data() + plane * zb[r]) == OI_OK;
           }
           if (errors[r].empty() && allconv[r]) {
             cs = oi_effdiff_tensor(eh, Ds.data() + (size_t)9 * r);
@@ -282,10 +322,18 @@ int main(int argc, char* argv[]) {
           if (!conv3[k]) break;
         }
       }
+      if (plot_dirs)
+        for (int k = 0; k < 3 && conv3[k]; ++k) {
+          bool all = true;
+          for (int r = 0; r < N; ++r) all = all && got_chi[3 * r + k];
+          if (all) write_chi_plotfile((*plot_dirs)[k], k, ph, nx, ny, nz, chi_full[k], vb);
+          else std::cerr << "Warning: could not read chi_" << axis_names[k] << " back from every slab; no plotfile\n";
+        }
       for (int t = 0; t < 9; ++t) D[t] = Ds[t];
       return allconv[0] != 0;
     };
-    auto homogenize = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9]) -> bool {
+    auto homogenize = [&](const uint8_t* ph, int nx, int ny, int nz, int vb, const char* what, double D[9],
+                          const std::vector<std::string>* plot_dirs) -> bool {
       oi_tort_opts o = hopts;
       o.verbose = vb;
       oi_effdiff* eh = nullptr;
@@ -311,7 +359,14 @@ int main(int argc, char* argv[]) {
           std::cout << "  Solver iterations: " << iters << "\n  Final Relative Residual Norm: " << std::scientific << rel
                     << std::defaultfloat << "\n  Solver Converged Status: " << (conv ? "Yes" : "No") << "\n  [wall] solve: " << since(t_solve)
                     << " s\n";
-        if (!conv) ok = false;
+        if (!conv) {
+          ok = false;
+          if (plot_dirs) std::cerr << "Warning: Skipping plotfile write for chi_k because solver did not converge and had active cells.\n";  // :681-684
+        } else if (plot_dirs) {
+          std::vector<double> chi((size_t)nx * ny * nz);
+          if (oi_effdiff_get_chi(eh, k, chi.data()) == OI_OK) write_chi_plotfile((*plot_dirs)[k], k, ph, nx, ny, nz, chi, vb);
+          else std::cerr << "Warning: could not read chi_" << axis_names[k] << " back: " << oi_last_error() << "\n";
+        }
       }
       if (ok) {
         const auto t_ten = std::chrono::steady_clock::now();
@@ -376,7 +431,11 @@ int main(int argc, char* argv[]) {
             for (double& v : D) v = std::numeric_limits<double>::quiet_NaN();  // :465-466
             bool ok = false;
             try {
-              ok = homogenize(sub.data(), len[0], len[1], len[2], rev_verbose >= 2 ? rev_verbose : 0, "REV", D);
+              // Diffusion.cpp:432-440: <results>/REV_Sample<s>_Size<len_x>_Dir<k>/effdiff_chi_dir<k> when rev.write_plotfiles is set
+              std::vector<std::string> rev_dirs;
+              for (int k = 0; k < 3; ++k)
+                rev_dirs.push_back((results_dir / ("REV_Sample" + std::to_string(s_idx + 1) + "_Size" + std::to_string(len[0]) + "_Dir" + std::to_string(k))).string());
+              ok = homogenize(sub.data(), len[0], len[1], len[2], rev_verbose >= 2 ? rev_verbose : 0, "REV", D, rev_write_plotfiles != 0 ? &rev_dirs : nullptr);
               if (!ok && rev_verbose >= 1) std::cout << "    REV Chi solve FAILED" << std::endl;
             } catch (const std::exception& e) {
               std::cout << "    REV Chi solve EXCEPTION: " << e.what() << std::endl;  // :459-461
@@ -405,8 +464,12 @@ int main(int argc, char* argv[]) {
       (void)solver_from_string(solver_str);  // invalid names abort in the reference (:45-58)
       double D[9];
       if (h_ngpus < 1) throw std::runtime_error("gpu.ngpus must be between 1 and min(64, nz)");
-      if (h_ngpus > 1 ? homogenize_ring(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D)
-                      : homogenize(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D)) {
+      // Diffusion.cpp:531-545: <results>/FullDomain_chi_<X|Y|Z>/effdiff_chi_dir<k> when write_plotfile is set
+      std::vector<std::string> full_dirs;
+      for (int k = 0; k < 3; ++k) full_dirs.push_back((results_dir / (std::string("FullDomain_chi_") + axis_names[k])).string());
+      const std::vector<std::string>* pd = write_plotfile != 0 ? &full_dirs : nullptr;
+      if (h_ngpus > 1 ? homogenize_ring(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D, pd)
+                      : homogenize(vol.phase.data(), vol.nx, vol.ny, vol.nz, verbose, "Full Domain", D, pd)) {
         std::cout << "Full Domain Effective Diffusivity Tensor D_eff / D_material:\n";  // :573-582
         for (int r = 0; r < 3; ++r) {
           std::cout << "  [";
@@ -421,6 +484,7 @@ int main(int argc, char* argv[]) {
       } else {
         std::cout << "Full domain D_eff calculation skipped due to chi_k non-convergence.\n";  // :587-589
       }
+      write_cathode_files((double)std::count(vol.phase.begin(), vol.phase.end(), (std::uint8_t)phase_id) / (double)std::max<std::size_t>(1, vol.phase.size()));
       const double secs_h = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
       std::cout << std::endl << "Total run time (seconds) = " << std::defaultfloat << secs_h << std::endl;
       return 0;
@@ -495,6 +559,7 @@ int main(int argc, char* argv[]) {
     OpenImpala::volumeFraction(vol.phase.data(), vol.phase.size(), phase_id, phase_voxels, total_voxels);
     const double volume_fraction = total_voxels > 0 ? static_cast<double>(phase_voxels) / static_cast<double>(total_voxels) : 0.0;
     std::cout << "  Volume Fraction = " << std::fixed << std::setprecision(8) << volume_fraction << "\n";
+    write_cathode_files(volume_fraction);
 
     std::string direction_str;
     in.get("direction", direction_str);  // mandatory in this branch (:633)

@@ -374,3 +374,46 @@ def read_tiff_stack(path):
 def read_tiff_phase(path, threshold=0.5):
     raw, _ = read_tiff_stack(path)
     return (raw > threshold).astype(np.uint8)
+
+
+# ---- CathodeWrite text exporters (reference src/io/CathodeWrite.cpp) ----------------------------------------------------------
+# Test infrastructure like everything in this file: tests/test_cathode_cpu.py compares apps/CathodeWrite.H's files with these.
+
+def cathode_dandeliion_text(vf_solid, radius, conductivity, cmax):
+    """CathodeWrite::writeDandeLiionParameters (CathodeWrite.cpp:35-103): scientific notation, 8 digits (:62);
+    el = 1 - vf_solid (:48), bet = 3 vf_solid / R or 0 for a vanishing radius (:52-57), B = el / 1.94 (:59)."""
+    e = lambda v: "%.8e" % v
+    el = 1.0 - vf_solid
+    bet = 3.0 * vf_solid / radius if radius > np.finfo(np.float64).eps else 0.0
+    bar = "#" * 59
+    return "\n".join([
+        bar, "# Cathode parameter container (Generated by CathodeWrite) #", "# Units should correspond to DandeLiion expectations.     #", bar, "",
+        "N = 55                # Number of mesh nodes in liquid (Example value)",
+        "M = 50                # Number of mesh nodes in solid (Example value)", "",
+        "R = " + e(radius) + "          # Particle radius, m", "",
+        "el      = " + e(el) + "        # Volume fraction of electrolyte, Calculated (1 - vf_solid)",
+        "bet     = " + e(bet) + "  # BET surface area, m^-1 (Verify formula: 3*vf_solid/R ?)",
+        "B       = " + e(el / 1.94) + "   # Permeability factor of electrolyte (Verify formula: el/1.94 ?)",
+        "cmax    = " + e(cmax) + "   # Maximum concentration of Li ions in solid, mol m^-3",
+        "sigma_s = " + e(conductivity) + "    # Solid conductivity, S m^-1", bar, ""])
+
+
+def cathode_pybamm_text(vf_solid, radius, conductivity, cmax):
+    """CathodeWrite::writePyBammParameters (CathodeWrite.cpp:106-175): fixed notation, 8 decimals (:135)."""
+    f = lambda v: "%.8f" % v
+    el = 1.0 - vf_solid
+    area = 3.0 * vf_solid / radius if radius > np.finfo(np.float64).eps else 0.0
+    c = ",OpenImpala Calculated Parameter,"
+    return "\n".join([
+        "Name [units],Value,Reference,Notes", "# Parameter file generated by CathodeWrite,,,", "# Units should correspond to PyBamm expectations,,,",
+        ",,,", "# Electrode properties,,,",
+        "Positive electrode conductivity [S.m-1]," + f(conductivity) + c,
+        "Maximum concentration in positive electrode [mol.m-3]," + f(cmax) + c,
+        "Positive electrode diffusivity [m2.s-1],[function]lico2_diffusivity_Dualfoil1998,,Requires Function Definition in PyBamm",
+        "Positive electrode OCP [V],[function]lico2_ocp_Dualfoil1998,,", ",,,", "# Microstructure,,,",
+        "Positive electrode porosity," + f(el) + c + "electrolyte volume fraction (1 - vf_solid)",
+        "Positive electrode active material volume fraction," + f(vf_solid) + c,
+        "Positive particle radius [m]," + f(radius) + c,
+        "Positive electrode surface area density [m-1]," + f(area) + c + "Calculated as 3*vf_solid/R (Verify formula)", ",,,",
+        "# Interfacial reactions,,,", "Positive electrode cation signed stoichiometry,-1,,", "Positive electrode electrons in reaction,1,,",
+        ",,,", ",,,", ""])

@@ -328,3 +328,77 @@ tau_tolerance = 1e-5
     assert r.returncode == 1 and "Tortuosity mismatch" in r.stdout and "TEST RESULT: FAIL" in r.stdout
     r = subprocess.run([exe, _inputs(tmp_path, text), "threshold_val=5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "Phase field uniform after thresholding." in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ngpus", [1, 2])
+def test_homogenization_writes_the_chi_plotfiles_and_the_cathode_files(app, tmp_path, ngpus):
+    """write_plotfile = 1 in the default (homogenization) branch: <results>/FullDomain_chi_<X|Y|Z>/effdiff_chi_dir<k> with the
+    components {chi_k, active_mask_from_solver} (Diffusion.cpp:531-545, EffectiveDiffusivityHypre.cpp:648-680) -- chi_k against the
+    oracle's solution of the same cell problem (both have zero mean over the phase), from one GPU and from a ring of two slabs;
+    cathode.* keys: the CathodeWrite exporters with the analysed phase's volume fraction."""
+    import numpy as np
+    from oracle import oracle as o
+    tif = os.path.join(GOLDEN, "SampleData_2Phase_squared.tif")  # 64^3
+    phase = o.read_tiff_phase(tif)
+    text = f"""
+filename = SampleData_2Phase_squared.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+hypre.eps = 1e-10
+write_plotfile = 1
+box_size = 32
+gpu.ngpus = {ngpus}
+gpu.transport = local
+cathode.dandeliion_file = cathode_dandeliion.txt
+cathode.pybamm_file = cathode_pybamm.csv
+cathode.particle_radius = 2.5e-6
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text), "verbose=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    chis = [o.effdiff_solve(phase, 1, k, 1e-11)[0] for k in range(3)]
+    mask = (phase == 1)
+    for k, ax in enumerate("XYZ"):
+        pf = read_plotfile(tmp_path / "res" / f"FullDomain_chi_{ax}" / f"effdiff_chi_dir{k}")
+        assert pf["vars"] == ["chi_k", "active_mask_from_solver"] and pf["domain"] == (64, 64, 64) and pf["nboxes"] == 8
+        assert np.array_equal(pf["data"][1], mask.astype(np.float64))
+        got, want = pf["data"][0], np.asarray(chis[k]).reshape(phase.shape)
+        assert np.all(got[~mask] == 0.0)
+        # the cell problem fixes chi up to a constant on the phase: compare after removing each field's mean there
+        np.testing.assert_allclose(got[mask] - got[mask].mean(), want[mask] - want[mask].mean(), rtol=0, atol=5e-7)
+        assert f"Plotfile written to {tmp_path}/res/FullDomain_chi_{ax}/effdiff_chi_dir{k}" in r.stdout
+    vf = float(mask.mean())
+    assert (tmp_path / "res" / "cathode_dandeliion.txt").read_text() == o.cathode_dandeliion_text(vf, 2.5e-6, 100.0, 51000.0)
+    assert (tmp_path / "res" / "cathode_pybamm.csv").read_text() == o.cathode_pybamm_text(vf, 2.5e-6, 100.0, 51000.0)
+
+
+@pytest.mark.gpu
+def test_rev_study_writes_plotfiles_per_sample_and_direction(app, tmp_path):
+    """rev.write_plotfiles = 1 (Diffusion.cpp:432-449): <results>/REV_Sample<s>_Size<n>_Dir<k>/effdiff_chi_dir<k> for every sample."""
+    import numpy as np
+    from oracle import oracle as o
+    phase = o.read_tiff_phase(os.path.join(GOLDEN, "SampleData_2Phase_squared.tif"))
+    text = f"""
+filename = SampleData_2Phase_squared.tif
+data_path = {GOLDEN}
+results_path = {tmp_path}/res
+calculation_method = skip_if_rev
+hypre.eps = 1e-10
+rev.do_study = 1
+rev.num_samples = 1
+rev.sizes = "24 32"
+rev.write_plotfiles = 1
+box_size = 16
+"""
+    r = subprocess.run([app, _inputs(tmp_path, text)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split(",") for l in open(tmp_path / "res" / "rev_study_Deff.csv").read().splitlines()[1:]]
+    assert len(rows) == 2
+    for row in rows:
+        sx, sy, sz, n = int(row[1]), int(row[2]), int(row[3]), int(row[5])
+        crop = np.ascontiguousarray(phase[sz:sz + n, sy:sy + n, sx:sx + n])
+        for k in range(3):
+            pf = read_plotfile(tmp_path / "res" / f"REV_Sample1_Size{n}_Dir{k}" / f"effdiff_chi_dir{k}")
+            assert pf["domain"] == (n, n, n) and pf["vars"] == ["chi_k", "active_mask_from_solver"]
+            assert np.array_equal(pf["data"][1], (crop == 1).astype(np.float64))
+            assert np.abs(pf["data"][0]).max() > 1e-3   # a solution, not the zero field
