@@ -26,6 +26,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/openimpala_amd.h"
@@ -835,9 +836,12 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
       // bits as the double compare (oi_hostpar.h)
       const uint8_t* base = &h.f[src + X * Y * za * es];
       const uint64_t plane = X * Y;
+      std::atomic<int> unknown{0};
       oi::parallel_for((size_t)(zb - za), [&](size_t k) {
-        (void)oi::threshold_run(base + k * plane * es, (size_t)plane, (int)es, sample_class(d), d.big_endian == host_le(), threshold, out + k * plane);
+        if (!oi::threshold_run(base + k * plane * es, (size_t)plane, (int)es, sample_class(d), d.big_endian == host_le(), threshold, out + k * plane))
+          unknown.store(1);
       });
+      if (unknown.load()) return fail("element type the threshold pass does not know");
     }
   } else if (d.layout == 2) {
     if (d.chunk_rank != 4) return fail("chunk rank does not match the dataset rank");
@@ -856,6 +860,8 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
     auto take_chunk = [&](const uint64_t* offs, uint64_t addr, uint64_t nbytes) {
         if (offs[0] >= zb || offs[0] + cz <= za) return true;  // chunk outside the requested planes
         if (offs[1] >= Y || offs[2] >= X) return true;          // (a corrupted index: nothing of it lies inside the dataset)
+        // chunks lie on the chunk grid; an index entry that does not (crafted or corrupt) could overlap another chunk's box
+        if (offs[0] % cz || offs[1] % cy || offs[2] % cx) { cerr = "chunk offset off the chunk grid"; return false; }
         if (!h.ok(addr, nbytes)) { cerr = "chunk outside the file"; return false; }
         if (!d.f_deflate && nbytes < cbytes) { cerr = "short chunk"; return false; }
         chunks.push_back(ChunkRec{{offs[0], offs[1], offs[2]}, addr, nbytes});
@@ -866,14 +872,28 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
     } else if (d.chunk_btree != kUndef) {
       good = for_each_chunk(h, d, h.base + d.chunk_btree, take_chunk);
     }
+    if (good && chunks.size() > 1) {
+      // every chunk writes its own box of `out` -- on several threads, so two index entries for ONE box (a crafted or corrupt
+      // index) would race where the sequential loop of round 3 let the last one win: refused
+      std::vector<size_t> order(chunks.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+      auto key = [&](size_t i) { return std::tie(chunks[i].offs[0], chunks[i].offs[1], chunks[i].offs[2]); };
+      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key(a) < key(b); });
+      for (size_t i = 1; i < order.size() && good; ++i)
+        if (key(order[i - 1]) == key(order[i])) { good = false; cerr = "chunk listed twice in the index"; }
+    }
     if (good) {
       std::mutex mu;
       std::atomic<int> bad{0};
       const int cls = sample_class(d);
       const bool swap = d.big_endian == host_le();
-      oi::parallel_for(chunks.size(), [&](size_t ci) {
+      // inflate / un-shuffle scratch: one pair per worker, owned by this call (released when it returns)
+      struct Scratch { std::vector<uint8_t> raw, tmp; };
+      std::vector<Scratch> scratch(oi::parallel_workers(chunks.size()));
+      oi::parallel_for_w(chunks.size(), [&](size_t ci, unsigned w) {
         if (bad.load()) return;
-        thread_local std::vector<uint8_t> raw, tmp, row;
+        std::vector<uint8_t>& raw = scratch[w].raw;
+        std::vector<uint8_t>& tmp = scratch[w].tmp;
         const ChunkRec& c = chunks[ci];
         const uint8_t* src = &h.f[c.addr];
         if (d.f_deflate) {
@@ -900,8 +920,12 @@ extern "C" oi_status oi_read_hdf5_planes(const char* path, const char* dataset, 
         for (uint64_t k = 0; k < cz && c.offs[0] + k < zb; ++k) {
           if (c.offs[0] + k < za) continue;
           for (uint64_t j = 0; j < cy && c.offs[1] + j < Y; ++j)
-            (void)oi::threshold_run(src + ((k * cy + j) * cx) * es, (size_t)nxr, (int)es, cls, swap, threshold,
-                                    out + ((c.offs[0] + k - za) * Y + c.offs[1] + j) * X + c.offs[2]);
+            if (!oi::threshold_run(src + ((k * cy + j) * cx) * es, (size_t)nxr, (int)es, cls, swap, threshold,
+                                   out + ((c.offs[0] + k - za) * Y + c.offs[1] + j) * X + c.offs[2])) {
+              std::lock_guard<std::mutex> lk(mu);
+              if (!bad.exchange(1)) cerr = "element type the threshold pass does not know";
+              return;
+            }
         }
       });
       if (bad.load()) good = false;

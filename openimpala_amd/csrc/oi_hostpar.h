@@ -8,11 +8,14 @@
 #pragma once
 #include <sched.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -31,29 +34,53 @@ inline unsigned host_threads() {
   return h ? h : 1;
 }
 
-// f(i) for every i in [0, n), items handed out one at a time (pages and chunks differ in cost); f must be safe to run
-// concurrently for different i.  At most 16 threads, at most n.
+// threads parallel_for uses for n items: at most 16, at most n, at most the host cores this process may use
+inline unsigned parallel_workers(size_t n) {
+  return (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)host_threads(), (size_t)16, n}));
+}
+
+// f(i, w) for every i in [0, n), items handed out one at a time (pages and chunks differ in cost); w < parallel_workers(n) names
+// the thread that runs the item (scratch buffers per worker, owned by the caller); f must be safe to run concurrently for
+// different i.  An exception thrown by f (bad_alloc of a scratch buffer ...) stops the hand-out and is rethrown here, on the
+// calling thread, after every worker has been joined -- as the sequential loops this replaces let the caller's handler see it.
 template <typename F>
-void parallel_for(size_t n, F&& f) {
+void parallel_for_w(size_t n, F&& f) {
   if (n == 0) return;
-  const unsigned nthreads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)host_threads(), (size_t)16, n}));
+  const unsigned nthreads = parallel_workers(n);
   if (nthreads == 1) {
-    for (size_t i = 0; i < n; ++i) f(i);
+    for (size_t i = 0; i < n; ++i) f(i, 0u);
     return;
   }
   std::atomic<size_t> next{0};
-  auto worker = [&]() {
+  std::exception_ptr first;
+  std::mutex first_mutex;
+  auto worker = [&](unsigned w) {
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= n) return;
-      f(i);
+      try {
+        f(i, w);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(first_mutex);
+        if (!first) first = std::current_exception();
+        next.store(n);  // nothing more is handed out
+        return;
+      }
     }
   };
   std::vector<std::thread> pool;
   pool.reserve(nthreads - 1);
-  for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-  worker();
+  try {
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+  } catch (...) {  // (a thread could not be started: the ones that run finish the work)
+  }
+  worker(0);
   for (auto& t : pool) t.join();
+  if (first) std::rethrow_exception(first);
+}
+template <typename F>
+void parallel_for(size_t n, F&& f) {
+  parallel_for_w(n, [&](size_t i, unsigned) { f(i); });
 }
 
 // ---- dst[i] = (double)sample_i > threshold ? 1 : 0 for n samples of one type, bit for bit what the per-sample double

@@ -771,9 +771,10 @@ extern "C" oi_status oi_read_tiff_planes(const char* path, double threshold, int
   std::string first_error;
   std::mutex mu;
   std::atomic<int> failed{0};
-  oi::parallel_for((size_t)nz_local, [&](size_t k) {
+  std::vector<std::vector<uint8_t>> bufs(oi::parallel_workers((size_t)nz_local));  // decode scratch per worker, owned by this call
+  oi::parallel_for_w((size_t)nz_local, [&](size_t k, unsigned w) {
     if (failed.load()) return;
-    thread_local std::vector<uint8_t> buf;
+    std::vector<uint8_t>& buf = bufs[w];
     const oi_status s1 = decode_page(path, f, pages[z0 + k], p0, z0 + k, threshold, out + k * W * H, buf);
     if (s1 != OI_OK) {
       std::lock_guard<std::mutex> lk(mu);
@@ -840,13 +841,14 @@ extern "C" oi_status oi_read_tiff_sequence(const char* base_pattern, int num_fil
   std::string first_error;
   std::mutex mu;
   std::atomic<int> failed{0};
-  oi::parallel_for((size_t)(num_files - 1), [&](size_t kk) {
+  std::vector<std::vector<uint8_t>> bufs(oi::parallel_workers((size_t)(num_files - 1)));  // decode scratch per worker, owned by this call
+  oi::parallel_for_w((size_t)(num_files - 1), [&](size_t kk, unsigned w) {
     if (failed.load()) return;
     const int k = (int)kk + 1;
     const std::string name = name_of(k);
     File f;
     std::vector<Ifd> pages;
-    thread_local std::vector<uint8_t> buf;
+    std::vector<uint8_t>& buf = bufs[w];
     oi_status st = open_tiff(name.c_str(), f, pages);
     if (st == OI_OK) st = decode_page(name.c_str(), f, pages[0], p0, (size_t)k, threshold, out + (size_t)k * p0.w * p0.h, buf);
     if (st != OI_OK) {

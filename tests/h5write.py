@@ -31,8 +31,10 @@ def _datatype(dt):
     return cls + struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
 
 
-def write_h5(path, arr, names=("image",), chunks=None, gzip=False, shuffle=False):
-    """arr: 3-D numpy array (Z, Y, X); names: group path ending in the dataset name."""
+def write_h5(path, arr, names=("image",), chunks=None, gzip=False, shuffle=False, craft=None):
+    """arr: 3-D numpy array (Z, Y, X); names: group path ending in the dataset name.
+    craft (chunked only): "duplicate" lists the first chunk's box twice in the index, "misaligned" moves the second chunk off the
+    chunk grid -- what a corrupt or hostile file could hold; the reader must refuse both."""
     arr = np.ascontiguousarray(arr)
     es = arr.dtype.itemsize
     blob = bytearray(b"\0" * 96)  # superblock (filled last)
@@ -64,6 +66,11 @@ def write_h5(path, arr, names=("image",), chunks=None, gzip=False, shuffle=False
                     if gzip:
                         raw = zlib.compress(raw, 4)
                     entries.append(((z0, y0, x0), put(raw), len(raw)))
+        if craft == "duplicate":
+            entries[1] = (entries[0][0], entries[1][1], entries[1][2])
+        elif craft == "misaligned":
+            (z0, y0, x0), a_, n_ = entries[1]
+            entries[1] = ((z0, y0, max(1, x0 - 1)), a_, n_)
         node = struct.pack("<4sBBHQQ", b"TREE", 1, 0, len(entries), UNDEF, UNDEF)
         for (z0, y0, x0), addr, nbytes in entries:
             node += struct.pack("<IIQQQQ", nbytes, 0, z0, y0, x0, 0) + struct.pack("<Q", addr)

@@ -6,8 +6,10 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import h5write
+import openimpala_amd as oia
 from conftest import GOLDEN
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,6 +67,22 @@ def test_corrupted_hdf5_files_are_errors(tmp_path):
     h5write.write_h5(str(a), arr)
     h5write.write_h5(str(b), arr, chunks=(4, 10, 14), gzip=True, shuffle=True)
     run_batch(tmp_path, "hdf5", "image", [a.read_bytes(), b.read_bytes()], 45)
+
+
+def test_crafted_hdf5_chunk_indices_are_refused(tmp_path):
+    """chunks are decoded on several threads, each writing 'its own box' of the output -- an index that lists one box twice
+    (or a chunk off the chunk grid, overlapping its neighbour) would make two threads write the same bytes.  Both are refused with
+    an I/O error; the clean file of the same data still reads."""
+    arr = (np.random.default_rng(4).random((12, 20, 28)) * 60000).astype(np.uint16)
+    ok = tmp_path / "ok.h5"
+    h5write.write_h5(str(ok), arr, chunks=(4, 10, 14), gzip=True, shuffle=True)
+    assert np.array_equal(oia.HDF5Reader(str(ok), "image").threshold(30000.0), (arr > 30000).astype(np.uint8))
+    for craft, msg in (("duplicate", "listed twice"), ("misaligned", "off the chunk grid")):
+        bad = tmp_path / f"{craft}.h5"
+        h5write.write_h5(str(bad), arr, chunks=(4, 10, 14), gzip=True, shuffle=True, craft=craft)
+        with pytest.raises(oia.OpenImpalaError) as e:
+            oia.HDF5Reader(str(bad), "image").threshold(30000.0)
+        assert e.value.status == oia.OI_IO_ERROR and msg in str(e.value), str(e.value)
 
 
 def _classic_tiff(width, height, strip_offset, strip_bytes, bps=1, pages=1):

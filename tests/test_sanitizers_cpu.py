@@ -83,6 +83,10 @@ def test_parallel_readers_under_thread_sanitizer(tmp_path):
 
     assert run_tsan([reader, "tiff", "-", os.path.join(GOLDEN, "SampleData_2Phase_stack_3d_1bit.tif")]).startswith("ok 100 100 100")
     assert run_tsan([reader, "hdf5", "image", str(h5), os.path.join(GOLDEN, "SampleData_2Phase_3d.hdf5")]).startswith("ok 56 48 40")
+    # a crafted index that lists one chunk box twice: refused before any thread decodes (no race on the shared box)
+    dup = tmp_path / "dup.h5"
+    h5write.write_h5(str(dup), vol, chunks=(8, 16, 16), gzip=True, shuffle=True, craft="duplicate")
+    assert run_tsan([reader, "hdf5", "image", str(dup)]).startswith("err")
     assert run_tsan([reader, "raw", "56,48,40,5", str(raw)]).startswith("ok 56 48 40")
     assert run_tsan([reader, "dat", "-", str(dat)]).startswith("ok 56 48 40")
 
