@@ -258,6 +258,9 @@ int oi_tort_line_voxels(void);
  *   "mg_plain" "mg_novec4" "mg_debug"   multigrid cross-check kernels / per-level norms
  *   "mg_replicate_cells" "mg_wmask" "mg_scale"   multigrid level distribution and cycle shape
  *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
+ *   "ring_lines_rccl" homogenization on a ring of GPUs over RCCL: 1 = compacted line lists travel between the slabs (variable-length
+ *                   ring exchange), 0 (default) = dense vectors and whole ghost planes.  UNVALIDATED: neither ring exchange has run on
+ *                   more than one GPU (no multi-GPU node in any round); the default is the simpler of the two
  *   "place_trials"  single-kernel CG: vector placements timed when a handle is built (default 48; 0 = six slots in
  *                   order, no search; see oi_tort_placement)
  *   "cg1_kernel"    single-kernel CG, compacted layout: 0 = k_cg1b (descriptor-addressed accesses, default), 1 = k_cg1

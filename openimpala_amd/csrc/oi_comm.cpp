@@ -409,6 +409,7 @@ oi_status oi_comm_create(oi_comm** out, const void* id, int nranks, int rank, in
   c->rank = rank;
   c->size = nranks;
   c->device = device;
+  c->kind = 1;
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   NCCLC(ncclCommInitRank(&c->nccl, nranks, uid, rank));
@@ -455,6 +456,7 @@ oi_status oi_comm_create_local(oi_comm** out_array, int nranks, int device) {
     c->rank = r;
     c->size = nranks;
     c->device = device;
+    c->kind = 2;
     c->sh = sh;
     out_array[r] = c;
   }
@@ -467,9 +469,8 @@ int oi_comm_size(const oi_comm* c) { return c ? c->size : 1; }
 
 oi_status oi_comm_info(const oi_comm* c, int* kind, int* ranks_collective, int* ranks_p2p, int* exchange_overlaps) {
   if (!c) { oi::set_error("%s: null communicator", __func__); return OI_BAD_ARG; }
-  int k = 2, nc = c->size, np = c->size;
+  int k = c->kind, nc = c->size, np = c->size;
   if (const RcclComm* r = dynamic_cast<const RcclComm*>(c)) {
-    k = 1;
     NCCLC(ncclCommCount(r->nccl, &nc));
     NCCLC(ncclCommCount(r->nccl_p2p, &np));
   }

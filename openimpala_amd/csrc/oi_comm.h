@@ -14,6 +14,7 @@
 
 struct oi_comm {
   int rank = 0, size = 1, device = 0;
+  int kind = 0;  // 1 = RCCL (one process or host thread per GPU), 2 = in-process (host threads on one GPU)
   // true when the plane exchanges may run on a second stream WHILE a collective of this communicator is in flight
   // on another (RCCL: they use a communicator of their own; two operations of one RCCL communicator must not overlap)
   bool exchange_overlaps = true;

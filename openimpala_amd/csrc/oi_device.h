@@ -70,6 +70,10 @@ struct Tune {
   float place_alloc_budget_s = 0.5f;  // spare slots (and the spacer) are allocated only while the set's allocations have
                          // taken less than this (the driver clears memory other processes have used: seconds for tens of GB)
   int place_cache = 1;   // reuse the placement an earlier handle of this process found for the same set of allocations
+  int ring_lines_rccl = 0;  // homogenization on a ring of GPUs over RCCL: 1 = compacted line lists travel (oi_comm::exchange_ring_v), 0 = the
+                         // dense vectors and whole ghost planes (exchange_ring).  0 until exchange_ring_v has run on more than one GPU: no
+                         // multi-GPU node has been available to any round, and the variable-length ring exchange is the code with the
+                         // posting-order argument and the skipped empty messages.  The in-process transport always compacts.
   int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
   int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
 };

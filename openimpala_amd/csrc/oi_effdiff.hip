@@ -395,7 +395,9 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   // periodic instantiations): one GPU, any extents
   // (a ring of slabs: every rank takes the same decision -- the iteration has collectives inside -- and the neighbours agree on
   // the line lists they will exchange)
-  int can = (want_mg && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g) &&
+  // (over RCCL the compacted ring exchange stays off until it has run on more than one GPU: Tune::ring_lines_rccl)
+  const bool ring_lines = !h->comm || h->comm->kind != 1 || g.tune.ring_lines_rccl;
+  int can = (want_mg && ring_lines && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g) &&
              (long long)(nzl + 2) * ny * ((g.pitch + kLV - 1) / kLV) < (1ll << 31)) ? 1 : 0;
   if (h->comm) {
     int cannot = can ? 0 : 1;

@@ -2216,6 +2216,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_coarsest_plain") t.mg_coarsest_plain = iv != 0;
   else if (k == "mg_nu_coarse") t.mg_nu_coarse = iv >= 2 ? 2 : (iv == 1 ? 1 : 0);
   else if (k == "force_comm") t.force_comm = iv != 0;
+  else if (k == "ring_lines_rccl") t.ring_lines_rccl = iv != 0;
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;
   else if (k == "place_spacer_gb") t.place_spacer_gb = (float)value;
@@ -2250,7 +2251,7 @@ extern "C" oi_status oi_tort_retune(oi_tort* h) {
   t.cg1_xskip = h->cg_active ? old.cg1_xskip : t.cg1_xskip;  // frozen while a CG run is in flight
   t.mg_plain = old.mg_plain; t.mg_novec4 = old.mg_novec4;
   t.mg_replicate_cells = old.mg_replicate_cells; t.mg_wmask = old.mg_wmask; t.mg_scale = old.mg_scale; t.mg_nu_coarse = old.mg_nu_coarse; t.mg_omega = old.mg_omega; t.mg_omega_coarse = old.mg_omega_coarse; t.mg_coarsest_plain = old.mg_coarsest_plain; t.mg_post_kernel = old.mg_post_kernel; t.mg_xfirst = old.mg_xfirst; t.mg_xpair = old.mg_xpair; t.mg_blocked = old.mg_blocked; t.mg_coarse_tiled = old.mg_coarse_tiled; t.mg_fused_images = old.mg_fused_images; t.cg1_fin_sliced = old.cg1_fin_sliced;
-  t.force_comm = old.force_comm;
+  t.force_comm = old.force_comm; t.ring_lines_rccl = old.ring_lines_rccl;
   t.place_trials = old.place_trials; t.place_slots = old.place_slots; t.place_spacer_gb = old.place_spacer_gb;
   t.place_min_mb = old.place_min_mb; t.place_extent_gb = old.place_extent_gb; t.place_cache = old.place_cache;
   t.place_alloc_budget_s = old.place_alloc_budget_s;
