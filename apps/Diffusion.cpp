@@ -164,9 +164,17 @@ int main(int argc, char* argv[]) {
       // this program builds solver object after solver object (one per direction, one per REV sample, as the reference does):
       // the device arrays of a destroyed one are kept for the next instead of going back to the driver, whose clearing of
       // recycled memory can cost seconds per allocation on MI355X (gpu.pool = 0 turns that off)
+      // What the pool may hold is bounded (gpu.pool_cap_gb; default a quarter of the card): blocks no later request fits would
+      // otherwise pile up over a REV study.  An allocation the driver refuses gives the pool back and is repeated in any case.
       int use_pool = 1;
+      double pool_cap_gb = -1.0;
       in.query("gpu.pool", use_pool);
-      oi_dev_pool(use_pool, 0.0);
+      in.query("gpu.pool_cap_gb", pool_cap_gb);
+      if (pool_cap_gb < 0.0) {
+        size_t free_b = 0, total_b = 0;
+        pool_cap_gb = oi_dev_mem_info(&free_b, &total_b) == OI_OK ? (double)total_b / 4e9 : 64.0;
+      }
+      oi_dev_pool(use_pool, pool_cap_gb);
       vol = load_volume(input_path, threshold, in);
       if (verbose >= 1)
         std::cout << "  Read + threshold: " << vol.nx << " x " << vol.ny << " x " << vol.nz << " voxels in " << std::defaultfloat
