@@ -203,10 +203,16 @@ def make_structure(oia, args, shape, z0, nzl):
 
 
 def kernels_sha():
-    """hash of the kernel source a PMC companion run must match (profiles/pmc_summary.json)"""
+    """hash of the kernel sources a PMC companion run must match (profiles/pmc_summary.json): every device source of the product library"""
+    import glob
     import hashlib
-    with open(os.path.join(ROOT, "openimpala_amd", "csrc", "oi_kernels.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "openimpala_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "oi_k_*.hip")) + [os.path.join(csrc, n) for n in ("oi_kern.h", "oi_device.h", "oi_mg.hip", "oi_effdiff.hip")]):
+        if os.path.basename(f) == "oi_k_xcheck.hip":
+            continue
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()
 
 
 def pmc_traffic(key):

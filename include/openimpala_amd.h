@@ -381,6 +381,10 @@ int oi_device_count(void);
 const char* oi_last_error(void); /* thread-local text of the last failure */
 const char* oi_status_string(oi_status s);
 int oi_abi_version(void);
+/* 1 in the TEST library (libopenimpala_amd_xcheck.so, `make xcheck`): the superseded kernels kept as bit-identity references of the shipped
+ * ones are present (k_cg1: the single-kernel iteration on dense vectors / option cg1_kernel = 1; k_fused_a on compacted vectors: option
+ * fused_kernel = 1).  0 in the product library, which answers OI_BAD_ARG to configurations that need them. */
+int oi_build_has_xcheck(void);
 
 /* ---- readers (src/io): file -> thresholded 0/1 phase bytes, voxel > thr -> 1 ----
  * oi_read_*: *phase is malloc'ed by the library (release with oi_free_host).

@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_comm_info oi_gen_bernoulli_device "
     "oi_gen_spheres_device oi_gen_blobs_device oi_blobs_level oi_dev_malloc oi_dev_mem_info oi_dev_stream_copy_bench oi_dev_free oi_dev_pool oi_dev_pool_trim oi_dev_pool_stats oi_dev_live_bytes oi_dev_live_blocks oi_dev_peak_bytes oi_debug_fail_alloc_after oi_dev_upload oi_dev_download oi_device_count "
-    "oi_last_error oi_status_string oi_abi_version oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host oi_read_set_pinned"
+    "oi_last_error oi_status_string oi_abi_version oi_build_has_xcheck oi_read_tiff oi_read_tiff_planes oi_read_tiff_sequence oi_read_raw oi_read_raw_planes oi_read_hdf5 oi_read_hdf5_planes oi_read_dat oi_free_host oi_read_set_pinned"
 ).split()
 
 
@@ -95,6 +95,7 @@ def lib():
     vp, i, d, u64, i64p = C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.POINTER(C.c_int64)
     pp = C.POINTER(C.c_void_p)
     L.oi_abi_version.restype = i
+    L.oi_build_has_xcheck.restype = i
     L.oi_last_error.restype = C.c_char_p
     L.oi_status_string.restype = C.c_char_p
     L.oi_status_string.argtypes = [i]
@@ -410,6 +411,12 @@ def dev_pool_stats():
     held, blocks, hits, misses, on = C.c_double(), C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_int()
     _check(lib().oi_dev_pool_stats(C.byref(held), C.byref(blocks), C.byref(hits), C.byref(misses), C.byref(on)))
     return {"held_bytes": int(held.value), "held_blocks": blocks.value, "hits": hits.value, "misses": misses.value, "enabled": bool(on.value)}
+
+
+def has_xcheck():
+    """True when the loaded library is the TEST build (libopenimpala_amd_xcheck.so: OI_LIB_PATH points at it) with the superseded
+    cross-check kernels; the product library answers OI_BAD_ARG to configurations that need them."""
+    return bool(lib().oi_build_has_xcheck())
 
 
 def dev_live():

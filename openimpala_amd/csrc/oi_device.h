@@ -34,7 +34,7 @@ struct Tune {
   int cg1_compact = 1;   // single-kernel variant: r, q, p stored as compacted live lines
   int cg1_seg = 1;       // k_cg1b: line slots from per-row segment records (scalar loads) instead of the per-line table
   int cg1_nt = 1;        // k_cg1b (all forms): 1 = the streamed vectors take nontemporal accesses (which ones: kNtSt* / kNtLd* in
-                         // oi_kernels.hip, chosen by in-process A/B, profiles/r04/k_cg1b_cache_policies_*.txt); 0 = default policy
+                         // oi_k_cg1b.hip, chosen by in-process A/B, profiles/r04/k_cg1b_cache_policies_*.txt); 0 = default policy
   int dense_nt = 31;     // LDS-tiled / flat kernels of the dense layouts (homogenization, two-kernel and unfused variants): nontemporal stores of
                          // p_out (1), x (2), q (4), r (8), the smoother's output (16).  All on: -2 % on the homogenization iteration at 1024^3
                          // (19.08 -> 18.7 ms, profiles/r04/homogenization_dense_kernels_nontemporal.txt; single bits within the noise); 0: A/B
@@ -207,7 +207,7 @@ struct MgCoarse {
 bool fused_descr_ok(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg, int jacobi);
 // a periodic problem (Geom::periodic) may take those forms (their periodic instantiations) on a slab with an even first plane
 bool periodic_tiles_ok(const Geom& g);
-// residual update + fine pre-smoother + restriction in one pass (k_cg1b FORM 2); see oi_kernels.hip
+// residual update + fine pre-smoother + restriction in one pass (k_cg1b FORM 2); see oi_k_cg1b.hip
 int launch_mg_pre_update(const Geom& g, const uint8_t* code, const double* r_in, double* r_out, const double* q, const double* hist, int k,
                          MgCoarse c, float* bcoarse, double omega, double* partials, const Ctrl* ctrl, const int* lineoff,
                          const long long* plane_first, const void* seg, hipStream_t s);
@@ -218,15 +218,19 @@ int launch_mg_post(const Geom& g, const uint8_t* code, const double* b, MgCoarse
                    double* partials, const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
                    double* x = nullptr, const void* p_prev = nullptr, int p_f32 = 0, const double* hist = nullptr, int k = 0,
                    const void* p_prev2 = nullptr /* != null: the x update is pairwise -- even k >= 2 only, alpha_{k-2} p_{k-2} then alpha_{k-1} p_{k-1} */);
-// fine-level halves of the multigrid cycle on the LDS tile (see oi_kernels.hip)
+// fine-level halves of the multigrid cycle on the LDS tile (see oi_k_dense.hip)
 // mode 1 pre (out = residual), 2 post (out = z, partials z.b), 3 pre with the restriction fused in
 // (bcoarse = fp32 right-hand side of the first coarse level, nothing else stored; needs an even g.z0)
 int launch_mg_fine(int mode, const Geom& g, const uint8_t* code, const double* b, MgCoarse c, double omega, double scale,
                    double* out, float* bcoarse, double* partials, const Ctrl* ctrl, const int* lineoff /* b, out compacted */,
                    hipStream_t s);
-// single-kernel CG iteration (see oi_kernels.hip): rec = per-iteration scalar records of 8 doubles
+// single-kernel CG iteration (see oi_k_cg1b.hip): rec = per-iteration scalar records of 8 doubles
 struct Cg1Grid { int R, NW, tiles_x, tiles_y, zchunk, nzc, blocks; };
 Cg1Grid cg1_grid(const Geom& g, bool descr, int split, int part);
+// true in the TEST library (make xcheck, -DOI_XCHECK=1): the superseded kernels kept as bit-identity references are present --
+// k_cg1 (the branching first form of the single-kernel iteration: dense vectors, option cg1_kernel = 1) and k_fused_a on compacted
+// vectors (option fused_kernel = 1, other tile heights).  The product library refuses configurations that need them.
+bool xcheck_built();
 int launch_cg1(const Geom& g, const uint8_t* code, double* x, const double* r_in, double* r_out, const double* q_in,
                double* q_out, const void* p_in, void* p_out, int p_f32, int jacobi, double* rec, int k,
                double* partials, Ctrl* ctrl, int split, int part, int partial_base, const int* lineoff, const long long* plane_first,
@@ -272,7 +276,7 @@ void launch_sum_f32_ranks(float* dst, const float* const* srcs_host, int nsrc, s
 void launch_pitch_copy_in(const Geom& g, const double* dense, double* vec, hipStream_t s);
 void launch_pitch_copy_out(const Geom& g, const double* vec, double* dense, hipStream_t s);
 void launch_codes_out(const Geom& g, const uint8_t* code, uint8_t* dense, hipStream_t s);
-// one relaxation sweep of the (sequentially defined) remspot pass, see oi_kernels.hip
+// one relaxation sweep of the (sequentially defined) remspot pass, see oi_k_setup.hip
 // (arrays with one ghost plane below and above the nzl owned planes; cut*[c] != 0: cell c starts a box along that axis)
 void launch_remspot_sweep(const uint8_t* old, uint8_t* cur, int nx, int ny, int nzl, int z0, int nz, const uint8_t* cutx,
                           const uint8_t* cuty, const uint8_t* cutz, int* changed, hipStream_t s);

@@ -1,7 +1,7 @@
 // oi_effdiff.hip -- homogenization path (the reference's default calculation_method):
 // periodic cell problems chi_k and the D_eff tensor, on the same HBM layout and CG
 // building blocks as the tortuosity path: unfused iteration (periodic apply +
-// the flat vector kernels of oi_kernels.hip); z-slabs over a RING of ranks (rank 0 and the last
+// the flat vector kernels of oi_k_dense.hip); z-slabs over a RING of ranks (rank 0 and the last
 // rank are neighbours: periodic z), one p-plane ring exchange and two scalar all-reduces per iteration.
 //
 // Replaces OpenImpala::EffectiveDiffusivityHypre (src/props/EffectiveDiffusivityHypre.cpp:
@@ -397,7 +397,9 @@ static oi_status effdiff_create_common(oi_effdiff** out, oi_comm* comm, const ui
   // the line lists they will exchange)
   // (over RCCL the compacted ring exchange stays off until it has run on more than one GPU: Tune::ring_lines_rccl)
   const bool ring_lines = !h->comm || h->comm->kind != 1 || g.tune.ring_lines_rccl;
-  int can = (want_mg && ring_lines && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g) &&
+  // (k_fused_a on compacted vectors is a cross-check kernel of the test library: the product compacts where k_cg1b FORM 1 runs)
+  const bool descr_first = (g.tune.fused_kernel == 0 && g.tune.fused_rows == 2 && 8ll * g.plane < 0x7fff0000ll) || oi::xcheck_built();
+  int can = (want_mg && ring_lines && descr_first && !g.tune.mg_plain && g.tune.cg1_compact && !g.tune.mg_norot && periodic_tiles_ok(g) &&
              (long long)(nzl + 2) * ny * ((g.pitch + kLV - 1) / kLV) < (1ll << 31)) ? 1 : 0;
   if (h->comm) {
     int cannot = can ? 0 : 1;

@@ -858,13 +858,21 @@ static oi_status build(oi_tort* h, const uint8_t* phase, bool on_device) {
   h->mg_tiled = g.tune.mg_plain ? 0 : 1;
   // the multigrid-preconditioned two-kernel iteration takes the compacted layout when its fine-level
   // kernels are the tiled ones with the restriction fused in (even first plane, see mg_vcycle)
-  const bool mg_compact = want_mg && h->fused && h->mg_tiled && (g.z0 & 1) == 0;
+  // (... and when the descriptor-addressed first kernel can serve them: k_fused_a on compacted vectors is a cross-check kernel of
+  // the test library -- other tile heights, option fused_kernel -- the product keeps such handles on dense vectors)
+  const bool mg_descr = g.tune.fused_kernel == 0 && g.tune.fused_rows == 2 && 8ll * g.plane < 0x7fff0000ll;
+  const bool mg_compact = want_mg && h->fused && h->mg_tiled && (g.z0 & 1) == 0 && (mg_descr || oi::xcheck_built());
   if ((h->cg1 || (want_mg && h->fused)) && g.tune.cg1_compact) {
     // r, q, p (and z): only the kLV-voxel lines that hold a free voxel
     const long long nlines = (long long)(g.nzl + 2) * g.ny * ((g.pitch + oi::kLV - 1) / oi::kLV);
     // neighbours exchange ghost planes as line lists: every slab takes the same layout
     int dense = ((h->cg1 || mg_compact) && nlines < (1ll << 31)) ? 0 : 1;
     if (h->comm) OIC(h->comm->allreduce_max_i32_host(&dense, 1, s));
+    if (dense && h->cg1 && !oi::xcheck_built()) {
+      oi::set_error("the single-kernel CG iteration needs the compacted line layout (%lld lines of %d voxels do not fit 31 bits, or a slab could "
+                    "not take it): choose kernel = fused, unfused or lean for this volume", nlines, oi::kLV);
+      return OI_BAD_ARG;
+    }
     if (!dense) {
       auto local_lines = [&]() -> oi_status {
         OIC(dmalloc(h, &h->lineoff, (size_t)nlines));
@@ -980,6 +988,13 @@ static oi_status create_common(oi_tort** out, oi_comm* comm, const uint8_t* phas
   h->lean = o.kernel == OI_KERNEL_LEAN;
   h->fused = o.kernel != OI_KERNEL_UNFUSED && !h->lean;
   h->cg1 = o.kernel == OI_KERNEL_FUSED1 || o.kernel == OI_KERNEL_AUTO;  // fastest variant is the default
+  if (h->cg1 && o.precond != OI_PRECOND_MG && !oi::xcheck_built() && (!tune0.cg1_compact || tune0.cg1_kernel != 0)) {
+    // the branching first form of that iteration (k_cg1: dense vectors, cg1_kernel = 1) is a superseded kernel kept as the
+    // bit-identity reference of the shipped one, in the test library only
+    oi::set_error("the single-kernel CG iteration on dense vectors / with cg1_kernel = 1 runs k_cg1, a cross-check kernel of the test "
+                  "library (make xcheck): not in this build");
+    return OI_BAD_ARG;
+  }
   if (o.kernel < OI_KERNEL_AUTO || o.kernel > OI_KERNEL_LEAN) {
     oi::set_error("unknown kernel variant %d", o.kernel);
     return OI_BAD_ARG;
@@ -2177,6 +2192,7 @@ extern "C" const char* oi_status_string(oi_status s) {
   return "?";
 }
 extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
+extern "C" int oi_build_has_xcheck(void) { return oi::xcheck_built() ? 1 : 0; }
 extern "C" void oi_tort_set_tuning(int fused_tile_rows, int fused_zchunk) {
   oi::Tune t = oi::default_tune();
   if (fused_tile_rows == 8 || fused_tile_rows == 16 || fused_tile_rows == 32) t.fused_rows = fused_tile_rows / 8;
@@ -2220,9 +2236,12 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;
   else if (k == "place_spacer_gb") t.place_spacer_gb = (float)value;
-  else if (k == "cg1_kernel") t.cg1_kernel = iv;
+  else if (k == "cg1_kernel" || k == "fused_kernel") {
+    // 1 selects a superseded kernel (k_cg1 / k_fused_a on compacted vectors) kept as the bit-identity reference: test library only
+    if (iv != 0 && !oi::xcheck_built()) { oi::set_error("%s: '%s' = %d selects a cross-check kernel of the test library (make xcheck), not in this build", __func__, key, iv); return OI_BAD_ARG; }
+    if (k == "cg1_kernel") t.cg1_kernel = iv; else t.fused_kernel = iv;
+  }
   else if (k == "cg1_seg") t.cg1_seg = iv != 0;
-  else if (k == "fused_kernel") t.fused_kernel = iv;
   else if (k == "mg_norot") t.mg_norot = iv != 0;
   else if (k == "mg_xpair") t.mg_xpair = iv != 0;
   else if (k == "mg_blocked") t.mg_blocked = iv != 0;

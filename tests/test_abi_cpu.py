@@ -28,6 +28,24 @@ def test_library_exports_every_declared_symbol():
     assert L.oi_abi_version() == oia.ABI_VERSION
 
 
+def test_the_product_library_carries_no_cross_check_kernels():
+    """`make` builds the product, `make xcheck` the test library: same exports, and only the latter holds the superseded kernels
+    (k_cg1 in any instantiation); cross-check options are refused by the product without touching a device."""
+    import subprocess
+    assert oia.lib().oi_build_has_xcheck() == 0
+    with pytest.raises(oia.OpenImpalaError) as e:
+        oia.set_option("cg1_kernel", 1)
+    assert e.value.status == oia.OI_BAD_ARG
+    libs = {n: os.path.join(ROOT, "openimpala_amd", n) for n in ("libopenimpala_amd.so", "libopenimpala_amd_xcheck.so")}
+    if not os.path.exists(libs["libopenimpala_amd_xcheck.so"]):
+        pytest.skip("test library not built (make -C openimpala_amd/csrc xcheck)")
+    syms = {n: subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True, check=True).stdout for n, p in libs.items()}
+    exported = {n: {l.split()[-1] for l in s.splitlines() if " T " in l and l.split()[-1].startswith("oi_")} for n, s in syms.items()}
+    assert exported["libopenimpala_amd.so"] == exported["libopenimpala_amd_xcheck.so"]
+    has = {n: (b"k_cg1I" in open(p, "rb").read()) for n, p in libs.items()}   # (mangled oi::k_cg1<...>; k_cg1b mangles as 6k_cg1b)
+    assert has == {"libopenimpala_amd.so": False, "libopenimpala_amd_xcheck.so": True}, has
+
+
 def test_struct_layouts_match_header():
     # sizes as the C compiler lays the structs out (natural alignment, no packing)
     assert oia.Opts.__dict__ is not None

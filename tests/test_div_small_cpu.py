@@ -1,5 +1,5 @@
 """The Jacobi form of the single-kernel iteration forms r / c and q / c (c = 1 .. 6 neighbours) as  q = RN(a y), r = fma(-c, q, a),
-q' = fma(r, y, q)  with y = RN(1 / c) from a table (oi_kernels.hip: div_small) and claims the bits of the IEEE division (Markstein's
+q' = fma(r, y, q)  with y = RN(1 / c) from a table (oi_k_cg1b.hip: div_small) and claims the bits of the IEEE division (Markstein's
 correction; |1/c - y| <= 2^-54 / c makes q faithful for these divisors).  The same three operations on the host, with hardware fma,
 against `a / c` (the GPU side of the claim: test_single_kernel_iteration_two_kernels_are_bit_identical, whose other kernel divides)."""
 import os

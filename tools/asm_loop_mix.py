@@ -1,5 +1,5 @@
 """Instruction mix of the hottest loop of a kernel: python tools/asm_loop_mix.py <kernel.s> <mangled-name prefix> ...
-(produce the .s with: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -S --cuda-device-only -o k.s oi_kernels.hip)"""
+(produce the .s with: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -S --cuda-device-only -o k.s oi_k_cg1b.hip)"""
 import re, sys
 from collections import Counter
 lines = open(sys.argv[1]).read().split('\n')

@@ -90,7 +90,9 @@ def main(out):
         import hashlib
         import json
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        sha = hashlib.sha256(open(os.path.join(root, "openimpala_amd", "csrc", "oi_kernels.hip"), "rb").read()).hexdigest()
+        sys.path.insert(0, root)
+        import bench
+        sha = bench.kernels_sha()   # (one definition: every device source of the product library)
         tagname = os.environ.get("OI_PMC_KEY", "1024:1")
         js = {f"{k}:{tagname}": {"hbm_bytes_per_launch": v, "kernels_sha256": sha, "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
                                  "separate passes, KiB -> bytes, mean over launches"} for k, v in traffic.items()}

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import openimpala_amd as oia
 n = 1024
 shape = (n, n, n)
-# (ids of the table in launch_cg1b_k, oi_kernels.hip, as it stands at the end of round 4; the earlier sweeps -- every load / store policy,
+# (ids of the table in launch_cg1b_k, oi_k_cg1b.hip, as it stands at the end of round 4; the earlier sweeps -- every load / store policy,
 # per stored array, combinations -- used other tables: their records in profiles/r04/k_cg1b_cache_policies_sweep1..5*.txt name the entries)
 names = {0: "default policy everywhere", 1: "shipped: r p x stored nt, x p(k-2) loaded nt", 2: "shipped, own instantiation", 3: "VAR 1: whole-line flag constant",
          4: "VAR 2: no halo ROW reads (wrong results)", 5: "VAR 4: no halo COLUMN reads (wrong results)", 6: "VAR 6: neither (wrong results)",

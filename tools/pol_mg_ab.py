@@ -1,5 +1,5 @@
 """EXPERIMENT build (-DOI_EXP_CACHEPOL): cache policies of FORM 1 / 2 / 3 of k_cg1b (multigrid-PCG iteration), ONE handle, alternating.
-Policy id i selects entry i of each form's own (load mask, store mask) list in oi_kernels.hip."""
+Policy id i selects entry i of each form's own (load mask, store mask) list in oi_k_cg1b.hip."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import openimpala_amd as oia

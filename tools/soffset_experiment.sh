@@ -8,8 +8,8 @@ cd "$(dirname "$0")/../openimpala_amd/csrc"
 for v in A:1 B:2; do
   tag=${v%%:*}; val=${v##*:}
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter --offload-arch=gfx950 -ffp-contract=off -DOI_SOFFSET_TEST=$val \
-      -c oi_kernels.hip -o /tmp/oi_kernels_soff$tag.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/libopenimpala_amd_soff$tag.so /tmp/oi_kernels_soff$tag.o oi_tort.o oi_comm.o \
-      oi_io.o oi_hdf5.o oi_effdiff.o oi_mg.o -L/opt/rocm/lib -lrccl -lz -Wl,-rpath,/opt/rocm/lib
+      -c oi_k_cg1b.hip -o /tmp/oi_k_cg1b_soff$tag.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/libopenimpala_amd_soff$tag.so /tmp/oi_k_cg1b_soff$tag.o oi_k_setup.o oi_k_dense.o \
+      oi_k_reduce.o oi_tort.o oi_comm.o oi_io.o oi_hdf5.o oi_effdiff.o oi_mg.o oi_pool.o -L/opt/rocm/lib -lrccl -lz -Wl,-rpath,/opt/rocm/lib
 done
 ls -la ../../tools/libopenimpala_amd_soff*.so
