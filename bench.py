@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--kernel", default="fused1", choices=["fused1", "fused", "unfused", "lean"],
                     help="lean = capacity mode (x, r, p only; 25 B/voxel of HBM)")
     ap.add_argument("--precond", default="none", choices=["none", "jacobi"])
-    ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solve")
+    ap.add_argument("--no-solve", action="store_true", help="skip the wall-time-to-1e-6 solves")
+    ap.add_argument("--no-cg-solve", action="store_true", help="skip the plain-CG solve to 1e-6 only (profiling runs of the multigrid path)")
     ap.add_argument("--solve-budget-s", type=float, default=150.0)
     ap.add_argument("--run-budget-s", type=float, default=600.0,
                     help="wall-clock cap on start-up + warm-up + timed region (a collective that never returns at N > 1): past it "
@@ -593,7 +594,7 @@ def main():
 
     # ---- wall time to relative residual 1e-6 (second half of the BASELINE metric) ----
     solve = None
-    if not args.no_solve:
+    if not args.no_solve and not args.no_cg_solve:
         t.reset_kernel_times()
         barrier()
         t.set_eps(1e-6)
@@ -622,10 +623,12 @@ def main():
         t.destroy()
         bufm, _ = make_structure(oia, args, shape, z0, nzl)
         kwm = dict(eps=1e-6, precond=oia.PRECOND_MG, profile=1, maxiter=1000, device=local_rank)
+        t_mg_create = time.perf_counter()
         if comm is not None:
             tm = oia.TortuosityMI355(bufm, 1, direction, 0.0, 1.0, shape=(nzl, n, n), comm=comm, z0=z0, nz_global=nz, **kwm)
         else:
             tm = oia.TortuosityMI355(bufm, 1, direction, 0.0, 1.0, shape=shape, **kwm)
+        t_mg_create = time.perf_counter() - t_mg_create
         bufm.free()
         barrier()
         m0 = time.perf_counter()
@@ -638,11 +641,44 @@ def main():
         barrier()
         m1 = time.perf_counter() - m0
         mk = tm.kernel_times()
+        mg_create_s = t_mg_create
         solve_mg = {"eps": 1e-6, "preconditioner": "2x2x2 aggregation multigrid cycle per PCG iteration", "converged": bool(mdone),
                     "iterations": mits, "relres": mrel, "seconds": m1, "setup_seconds": tm.stats().t_setup_s,
+                    # the DEFAULT handle of the ABI (precond = mg): no placement search on this path
+                    "create_total_s": mg_create_s, "mask_s": tm.stats().t_mask_s,
                     "device_GB": tm.stats().bytes_device / 1e9,
                     "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in mk.items()
-                                              if k in ("mg_vcycle", "fused_a", "update_r", "apply", "update_p", "update_xr")}}
+                                              if k in ("mg_vcycle", "mg_post", "fused_a", "update_r", "apply", "update_p", "update_xr")}}
+        # ---- where the default path stands against the roofline: the three fine kernels of an iteration are forms of the descriptor-
+        # addressed kernel (k_cg1b FORM 1 / 2 / 3) on compacted vectors; algorithmic bytes = the code byte of every voxel + the form's
+        # vector bytes for every voxel of a STORED line (FORM 1 z 8 + p 8 read, p 8 + q 8 written; FORM 2 r 8 +
+        # q 8 read, r 8 written, 0.5 coarse right-hand side; FORM 3 b 8 + 0.5 coarse correction read, z 8 written, and on every
+        # second launch x 8 + two p 8 + 8 read, x 8 written = 32, i.e. 16 per launch on average); HIP events on the solver's stream;
+        # traffic from the committed PMC passes of the same kernel sources (tools/rocprof_mg.sh), null otherwise
+        if all(k in mk for k in ("fused_a", "update_r", "mg_vcycle", "mg_post")):   # ("mg_post" is timed only in the rotated iteration on compacted vectors)
+            livem = tm.live_fraction(oia.line_voxels())
+            voxl = n * n * nzl
+            per = {"form1_first_kernel": ("fused_a", 32.0, "mg_form1"), "form2_residual_presmoother_restriction": ("update_r", 24.5, "mg_form2"),
+                   "form3_post_smoother_incl_pairwise_x": ("mg_post", 32.5, "mg_form3")}
+            roof = {}
+            for name, (kk, bv, pkey) in per.items():
+                ms_k = mk[kk][0] / max(1, mk[kk][1])
+                ab = (1.0 + bv * livem) * voxl
+                tr = pmc_traffic(f"{pkey}:{n}:{world}")
+                if pkey == "mg_form3":   # (two instantiations alternate: with and without the x update)
+                    tx = pmc_traffic(f"mg_form3x:{n}:{world}")
+                    tr = 0.5 * (tr + tx) if tr is not None and tx is not None else None
+                roof[name] = {"ms_per_launch": ms_k, "algorithmic_bytes_per_launch": ab, "achieved": ab / ms_k / 1e6, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": ab / ms_k / 1e6 / HBM_PEAK_GBS, "traffic": tr}
+            ms_c = (mk["mg_vcycle"][0] - mk["mg_post"][0]) / max(1, mk["mg_vcycle"][1])
+            roof["coarse_levels"] = {"ms_per_iteration": ms_c, "traffic": pmc_traffic(f"mg_coarse:{n}:{world}"),
+                                     "what": "every level below the fine one (first coarse level: an eighth of the cells, fp32): ~100 launches, latency- and L2-bound; no byte model"}
+            it_ms = sum(mk[k][0] / max(1, mk[k][1]) for k in ("fused_a", "update_r", "mg_vcycle"))
+            roof["iteration"] = {"ms": it_ms, "live_line_fraction": livem, "bound": "hbm",
+                                 "fine_kernels_algorithmic_bytes": sum(v["algorithmic_bytes_per_launch"] for k_, v in roof.items() if k_.startswith("form")),
+                                 "fine_kernels_frac_of_peak": sum(v["algorithmic_bytes_per_launch"] for k_, v in roof.items() if k_.startswith("form"))
+                                 / (sum(v["ms_per_launch"] for k_, v in roof.items() if k_.startswith("form")) * 1e6) / HBM_PEAK_GBS}
+            solve_mg["roofline"] = roof
         tm.destroy()
         t = None
         extras["solve_mg"] = solve_mg

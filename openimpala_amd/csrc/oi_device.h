@@ -108,7 +108,7 @@ struct Ctrl {
 
 enum KernelId {
   K_PACK = 0, K_SEED, K_FLOOD, K_MASK, K_CODES, K_INIT, K_RESID0, K_APPLY, K_UPDATE_P, K_UPDATE_XR,
-  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_CG1, K_MG, K_COUNT
+  K_FUSED_A, K_UPDATE_R, K_AXPY, K_FINALIZE, K_FLUX, K_GEN, K_CG1, K_MG, K_MG_POST /* the fine post-smoother alone: inside K_MG's span */, K_COUNT
 };
 
 // grid cap of the flat (non-tiled) reducing kernels; the z-marching kernels are bounded by Tune::max_blocks

@@ -33,7 +33,7 @@ struct MgXUpdate { double* x; const void* p_prev; int p_f32; const double* hist;
 bool mg_post_descr(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg);  // does the post-smoother run as k_cg1b FORM 3?
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
                                 const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
-                                const MgXUpdate* xu = nullptr);
+                                const MgXUpdate* xu = nullptr, hipEvent_t before_post = nullptr /* recorded between the coarse levels and the post-smoother */);
 int mg_levels(const MgHierarchy* mg);
 int mg_replicated_from(const MgHierarchy* mg);  // first level (1 = first coarse) solved redundantly on every rank, -1 = none
 // partial sums of a.b over the owned planes; returns the number of partials

@@ -1609,7 +1609,7 @@ bool mg_coarse_target(MgHierarchy* mg, MgCoarse* c, float** bcoarse, double* ome
 // post-smoother z = x2 + w (r - A x2) / c with the partial sums of z.r (returns their number, -1 on a transport failure)
 int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* code, const double* r, double* z, double* partials,
                                 const Ctrl* ctrl, const int* lineoff, const long long* plane_first, const void* seg, hipStream_t s,
-                                const MgXUpdate* xu) {
+                                const MgXUpdate* xu, hipEvent_t before_post) {
   MgLevelHost& C = mg->levels[0];
   MgCoarse cref{C.x2, nullptr, C.d.nx, C.d.ny, C.d.z0, C.d.sz, C.d.nzl, mg->periodic ? 1 : 0};
   if (!finish_child_array(mg, C, false, C.b, s)) return -1;
@@ -1620,6 +1620,7 @@ int mg_vcycle_after_restriction(MgHierarchy* mg, const Geom& g, const uint8_t* c
     if (!coarse_cycle(mg, 0, C.b2, C.xs, s)) return -1;
     cref.xc2 = C.xs;
   }
+  if (before_post) (void)hipEventRecord(before_post, s);
   return post_smooth(mg, g, code, r, cref, z, partials, ctrl, lineoff, plane_first, seg, s, xu);
 }
 bool mg_post_descr(const Geom& g, const int* lineoff, const long long* plane_first, const void* seg) {

@@ -55,7 +55,7 @@ static double now_s() {
 
 static const char* kKernelNames[K_COUNT] = {
     "pack_open", "seed", "flood_sweep", "mask_and", "codes", "init_field", "residual0", "apply",
-    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate", "cg1", "mg_vcycle"};
+    "update_p", "update_xr", "fused_a", "update_r", "axpy", "finalize", "flux", "generate", "cg1", "mg_vcycle", "mg_post"};
 
 struct ProfRec {
   int kid;
@@ -1278,7 +1278,14 @@ static oi_status cg_one_iteration(oi_tort* h, int k) {
     // (round 4: pairwise there -- launch k even adds alpha_{k-2} p_{k-2}, still in p_out, and alpha_{k-1} p_{k-1}; odd launches leave x alone)
     const bool xpost = h->xpair || (!g.tune.mg_xfirst && mg_post_descr(g, h->lineoff, h->plane_first_dev, h->seg));
     const MgXUpdate xu{h->x, p_in, h->p_f32 ? 1 : 0, h->hist, k, h->xpair ? p_out : nullptr};
-    { PROF(K_MG); nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s, xpost ? &xu : nullptr); }
+    {
+      PROF(K_MG);
+      // (profiling: the fine post-smoother also on its own -- K_MG's span minus K_MG_POST's is the coarse levels)
+      ProfRec post{K_MG_POST, nullptr, nullptr};
+      if (h->opts.profile) { post.a = prof_event(h); post.b = prof_event(h); }
+      nb = mg_vcycle_after_restriction(h->mg, g, h->code, r_out, h->z, h->partials, h->ctrl, h->lineoff, h->plane_first_dev, h->seg, s, xpost ? &xu : nullptr, post.a);
+      if (post.b) { (void)hipEventRecord(post.b, s); h->prof_pending.push_back(post); }
+    }
     if (nb < 0) return OI_RCCL_ERROR;
     OIC(reduce_to(h, nb, 1, h->hist + H_STRIDE * k + H_RZ, false, 0));
     OIC(exchange_cg_vec(h, h->z, sizeof(double), s));

@@ -15,16 +15,28 @@ def find(d, pat):
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.split("(")[0] if not name.startswith("void oi::k_cg1b<") and not name.startswith("oi::k_cg1b<") else name[:name.index(">(") + 1] if ">(" in name else name
     for tok in ("void ", "oi::"):
         name = name.replace(tok, "")
     return name.strip()
 
 
 def bench_name(kernel):
-    """rocprof kernel name -> the kernel key bench.py uses"""
+    """rocprof kernel name -> the key bench.py uses (k_cg1b by its FORM template argument: 0 the single-kernel CG iteration, 1 / 2 / 3
+    the fine kernels of the multigrid-preconditioned iteration -- FORM 3 with (mg_form3x) and without (mg_form3) the pairwise x update)"""
+    if kernel.startswith("k_cg1b<"):
+        args = [a.strip() for a in kernel[len("k_cg1b<"):].rstrip(">").split(",")]
+        form = int(args[5]) if len(args) > 5 and args[5].lstrip("-").isdigit() else 0
+        nox = len(args) > 9 and args[9] == "true"
+        if form == 0:
+            return "cg1"
+        if form == 3:
+            return "mg_form3" if nox else "mg_form3x"
+        return "mg_form%d" % form
     if kernel.startswith("k_cg1"):
         return "cg1"
+    if kernel.startswith("k_mg_") and not kernel.startswith(("k_mg_fine", "k_mg_dot", "k_mg_build", "k_mg_compact")):
+        return "mg_coarse"   # reported PER ITERATION (all coarse-level launches of one cycle), see main()
     if kernel.startswith("k_apply7"):
         return "apply"
     if kernel.startswith("k_fused_a"):
@@ -59,7 +71,7 @@ def main(out):
             bl = json.loads(open(line).read().strip().splitlines()[-1])
             steps = int(bl["steps"])
             d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace))
-                 if short(r["Kernel_Name"]).startswith("k_cg1")]
+                 if bench_name(short(r["Kernel_Name"])) == "cg1"]
             d.sort()
             last = [x[1] for x in d[-steps:]]
             if last:
@@ -81,11 +93,23 @@ def main(out):
             acc[k][0] += float(r["Counter_Value"])
             acc[k][1] += 1
         print(f"== {counter} per launch (KiB -> bytes, x{scale:g} gfx950 correction) ==")
-        for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:10]:
-            print("%-64s launches %6d  %14.0f bytes/launch" % (k[:64], n, v / n * 1024.0 * scale))
+        for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:14]:
+            print("%-72s launches %6d  %14.0f bytes/launch" % (k[:72], n, v / n * 1024.0 * scale))
+        # per bench key: bytes per launch, averaged over ALL launches of the kernels behind the key; the coarse levels of the multigrid
+        # cycle: bytes per ITERATION = the sum over every coarse-level launch / the number of FORM 2 launches (one per iteration)
+        per_key = defaultdict(lambda: [0.0, 0])
         for k, (v, n) in acc.items():
-            if bench_name(k):
-                traffic[bench_name(k)] += v / n * 1024.0 * scale
+            b = bench_name(k)
+            if b:
+                per_key[b][0] += v
+                per_key[b][1] += n
+        iters = per_key["mg_form2"][1] if "mg_form2" in per_key else 0
+        for b, (v, n) in per_key.items():
+            if b == "mg_coarse":
+                if iters:
+                    traffic[b] += v / iters * 1024.0 * scale
+            elif n:
+                traffic[b] += v / n * 1024.0 * scale
     if traffic:
         import hashlib
         import json
