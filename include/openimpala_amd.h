@@ -192,6 +192,12 @@ void oi_effdiff_destroy(oi_effdiff* h);
 oi_status oi_tort_cg_begin(oi_tort* h);              /* x0 = ramp, r0, p0; resets the iteration count */
 oi_status oi_tort_cg_iterate(oi_tort* h, int n);     /* enqueue n CG iterations (asynchronous) */
 oi_status oi_tort_cg_finish(oi_tort* h);             /* flush the deferred x update, synchronise */
+/* The library's own convergence loop between cg_begin and cg_finish -- what oi_tort_value runs: launches iterations until the device's
+ * stop test fires, opts.maxiter is reached, or (max_launches > 0) that many launches have been issued by this call.  Plain CG: batches
+ * of 32 launches with the flag of the previous batch read while the next one runs; multigrid-preconditioned CG: the batch shrinks to
+ * what the residual still needs (estimated from its contraction so far), so the solve does not end on launches whose coarse levels run
+ * for nothing.  *launches_issued (optional) = launches this call enqueued. */
+oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_issued);
 oi_status oi_tort_sync(oi_tort* h);
 oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* relres, int* converged);
 /* element-wise checks of single kernels against the oracle: v, q are host arrays of

@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "oi_tort_default_opts oi_tort_create oi_tort_create_device oi_tort_create_slab oi_tort_destroy "
     "oi_tort_value oi_tort_check_matrix_properties oi_tort_get_stats oi_tort_get_solution oi_tort_get_mask "
     "oi_volume_fraction oi_remspot oi_effdiff_create oi_effdiff_create_slab oi_effdiff_solve oi_effdiff_get_chi oi_effdiff_tensor "
-    "oi_effdiff_info oi_effdiff_layout oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_finish oi_tort_sync "
+    "oi_effdiff_info oi_effdiff_layout oi_effdiff_destroy oi_tort_set_eps oi_tort_cg_begin oi_tort_cg_iterate oi_tort_cg_run oi_tort_cg_finish oi_tort_sync "
     "oi_tort_cg_state oi_tort_debug_apply oi_tort_debug_get_codes oi_tort_true_residual oi_debug_cg1_grid oi_tort_placement oi_tort_placement_cost oi_tort_bench_stream oi_tort_bench_apply oi_tort_live_fraction oi_tort_kernel_times "
     "oi_kernel_name oi_tort_reset_kernel_times oi_tort_set_tuning oi_tort_set_apply_tuning oi_tort_set_cg1_tuning oi_tort_set_cg1_layout oi_tort_line_voxels oi_tort_set_option oi_tort_retune oi_comm_unique_id oi_comm_create "
     "oi_comm_create_local oi_comm_destroy oi_comm_rank oi_comm_size oi_comm_info oi_gen_bernoulli_device "
@@ -128,6 +128,7 @@ def lib():
     L.oi_tort_cg_begin.argtypes = [vp]
     L.oi_tort_cg_iterate.argtypes = [vp, i]
     L.oi_tort_cg_finish.argtypes = [vp]
+    L.oi_tort_cg_run.argtypes = [vp, i, C.POINTER(i)]
     L.oi_tort_sync.argtypes = [vp]
     L.oi_tort_cg_state.argtypes = [vp, C.POINTER(i), C.POINTER(d), C.POINTER(i)]
     L.oi_tort_debug_apply.argtypes = [vp, vp, vp, i]
@@ -622,6 +623,12 @@ class TortuosityMI355:
 
     def cg_iterate(self, n):
         _check(lib().oi_tort_cg_iterate(self._h, n))
+
+    def cg_run(self, max_launches=0):
+        """The library's own convergence loop (what value() runs between cg_begin and cg_finish); returns the launches it issued."""
+        n = C.c_int()
+        _check(lib().oi_tort_cg_run(self._h, int(max_launches), C.byref(n)))
+        return n.value
 
     def cg_finish(self):
         _check(lib().oi_tort_cg_finish(self._h))

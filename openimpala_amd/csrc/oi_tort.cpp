@@ -1487,44 +1487,90 @@ extern "C" oi_status oi_tort_cg_state(oi_tort* h, int* iterations_done, double* 
   return OI_OK;
 }
 
+// Launches iterations of the open CG run until the device's stop test fires (or maxiter / `max_launches` launches): the loop
+// value() runs between cg_begin and cg_finish, exposed so that a host (bench.py) times exactly what the library does.
+//   * plain / Jacobi CG (thousands of cheap iterations whose kernels return at once after the flag is up): batches of 32 with the
+//     flag of the PREVIOUS batch looked at while the next one runs -- the device never waits for the host;
+//   * multigrid-preconditioned CG (tens of iterations of ~12 ms at 1024^3; the coarse levels of a launch issued after convergence
+//     still run, 1.7 ms each): the host reads the flag and ||r||^2 after every batch (one 50 us bubble per batch), estimates the
+//     contraction per iteration from the last two readings and issues only as many launches as the residual still needs -- the
+//     solve ends with one launch that finds the flag up instead of up to eight.
+extern "C" oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_issued) {
+  if (!h) { oi::set_error("%s: null handle", __func__); return OI_BAD_ARG; }
+  if (!h->cg_active) { oi::set_error("%s: no CG run is open (oi_tort_cg_begin first)", __func__); return OI_BAD_ARG; }
+  HIPC(hipSetDevice(h->device));
+  const int limit = h->maxiter + ((h->cg1 || h->rot) ? 1 : 0);
+  const int first_issued = h->iters_issued;
+  auto budget_left = [&] { return max_launches <= 0 || h->iters_issued - first_issued < max_launches; };
+  const int batch = h->opts.check_every > 0 ? h->opts.check_every : (h->mg ? 4 : 32);
+  oi_status rc = poll_ctrl(h);  // converged before iterating?
+  bool stop = rc == OI_OK && h->h_ctrl->done;
+  if (h->mg) {
+    const double tol2 = (h->opts.eps * h->bnorm) * (h->opts.eps * h->bnorm);
+    int k_prev = -1, next = batch;
+    double rr_prev = 0.0;
+    while (rc == OI_OK && !stop && h->iters_issued < limit && budget_left()) {
+      int n = std::max(1, std::min(next, batch));
+      if (max_launches > 0) n = std::min(n, max_launches - (h->iters_issued - first_issued));
+      rc = oi_tort_cg_iterate(h, n);
+      if (rc != OI_OK) break;
+      rc = poll_ctrl(h);
+      if (rc != OI_OK) break;
+      if (h->h_ctrl->done) { stop = true; break; }
+      // ||r_K||^2 of the last iteration whose residual exists, and how many more the contraction so far asks for
+      const int K = h->rot ? std::max(0, h->iters_issued - 1) : h->iters_issued;
+      if (hipMemcpyAsync(h->h_scal, h->hist + H_STRIDE * K + H_RR, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipStreamSynchronize(h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+      const double rr = h->h_scal[0];
+      next = batch;
+      if (k_prev >= 0 && K > k_prev && rr > 0.0 && rr < rr_prev && tol2 > 0.0 && rr > tol2) {
+        const double per_iter = std::log(rr / rr_prev) / (double)(K - k_prev);  // < 0
+        const double need = std::log(tol2 / rr) / per_iter;                     // iterations until ||r||^2 <= tol2 at that rate
+        // (the rotated iteration sees iteration K's residual in launch K: `need` more launches reach it; one in hand for a slower tail)
+        next = (int)std::ceil(need) + (h->rot ? 1 : 0);
+        if (next < 1) next = 1;
+      }
+      k_prev = K; rr_prev = rr;
+      if (h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] %d launches issued, ||r||^2 = %.3e, next batch %d\n", h->iters_issued, rr, std::min(next, batch));
+    }
+  } else {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    Ctrl* land = nullptr;  // pinned landing pads for the two in-flight polls
+    if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&land, 2 * sizeof(Ctrl)) != hipSuccess) {
+      rc = OI_HIP_ERROR;
+    } else {
+      land[0].done = land[1].done = 0;
+      int nb = 0;
+      while (rc == OI_OK && !stop && h->iters_issued < limit && budget_left()) {
+        int n = batch;
+        if (max_launches > 0) n = std::min(n, max_launches - (h->iters_issued - first_issued));
+        rc = oi_tort_cg_iterate(h, n);
+        if (rc != OI_OK) break;
+        const int slot = nb & 1;
+        if (hipMemcpyAsync(&land[slot], h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipEventRecord(ev[slot], h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+        if (nb > 0) {  // look at the PREVIOUS batch while this one runs
+          if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { rc = OI_HIP_ERROR; break; }
+          if (land[slot ^ 1].done) stop = true;
+        }
+        ++nb;
+        if (h->opts.verbose > 1 && (nb % 16) == 0) fprintf(stderr, "[openimpala_amd] issued %d CG iterations\n", h->iters_issued);
+      }
+    }
+    if (ev[0]) (void)hipEventDestroy(ev[0]);
+    if (ev[1]) (void)hipEventDestroy(ev[1]);
+    if (land) (void)hipHostFree(land);
+    if (rc == OI_HIP_ERROR && !*oi::last_error()) oi::set_error("%s: HIP failure: %s", __func__, hipGetErrorString(hipGetLastError()));
+  }
+  if (launches_issued) *launches_issued = h->iters_issued - first_issued;
+  return rc;
+}
+
 static oi_status solve(oi_tort* h) {
   const double t0 = now_s();
   OIC(oi_tort_cg_begin(h));
-  // multigrid iterations are few and expensive: look at the flag more often
-  int batch = h->opts.check_every > 0 ? h->opts.check_every : (h->mg ? 4 : 32);
-  hipEvent_t ev[2];
-  HIPC(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-  HIPC(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-  // pinned landing pads for the two in-flight polls
-  Ctrl* land = nullptr;
-  HIPC(hipHostMalloc((void**)&land, 2 * sizeof(Ctrl)));
-  land[0].done = land[1].done = 0;
-  int nb = 0;
-  bool stop = false;
-  oi_status rc = OI_OK;
-  // initial check (converged before iterating)
-  rc = poll_ctrl(h);
-  if (rc == OI_OK && h->h_ctrl->done) stop = true;
-  const int limit = h->maxiter + ((h->cg1 || h->rot) ? 1 : 0);
-  while (rc == OI_OK && !stop && h->iters_issued < limit) {
-    rc = oi_tort_cg_iterate(h, batch);
-    if (rc != OI_OK) break;
-    const int slot = nb & 1;
-    if (hipMemcpyAsync(&land[slot], h->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipEventRecord(ev[slot], h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
-    if (nb > 0) {  // look at the PREVIOUS batch while this one runs
-      if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { rc = OI_HIP_ERROR; break; }
-      if (land[slot ^ 1].done) stop = true;
-    }
-    ++nb;
-    if (h->opts.verbose > 1 && (nb % 16) == 0) {
-      fprintf(stderr, "[openimpala_amd] issued %d CG iterations\n", h->iters_issued);
-    }
-  }
-  (void)hipEventDestroy(ev[0]);
-  (void)hipEventDestroy(ev[1]);
-  (void)hipHostFree(land);
-  if (rc != OI_OK) return rc;
+  OIC(oi_tort_cg_run(h, 0, nullptr));
   OIC(oi_tort_cg_finish(h));
   h->st.t_solve_s = now_s() - t0;
   return OI_OK;

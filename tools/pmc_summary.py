@@ -15,6 +15,7 @@ def find(d, pat):
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0] if not name.startswith("void oi::k_cg1b<") and not name.startswith("oi::k_cg1b<") else name[:name.index(">(") + 1] if ">(" in name else name
     for tok in ("void ", "oi::"):
         name = name.replace(tok, "")
