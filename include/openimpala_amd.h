@@ -264,6 +264,8 @@ int oi_tort_line_voxels(void);
  *   "mg_plain" "mg_novec4" "mg_debug"   multigrid cross-check kernels / per-level norms
  *   "mg_replicate_cells" "mg_wmask" "mg_scale"   multigrid level distribution and cycle shape
  *   "force_comm"    keep a one-rank communicator (single-GPU rehearsal of the RCCL path)
+ *   "resid0_bits"   1 (default): cg_begin forms the initial residual from the active bits (the initial field is a function of position
+ *                   and mask); 0: from x through the stencil -- the same bits (cross-check)
  *   "ring_lines_rccl" homogenization on a ring of GPUs over RCCL: 1 = compacted line lists travel between the slabs (variable-length
  *                   ring exchange), 0 (default) = dense vectors and whole ghost planes.  UNVALIDATED: neither ring exchange has run on
  *                   more than one GPU (no multi-GPU node in any round); the default is the simpler of the two

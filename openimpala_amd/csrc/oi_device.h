@@ -74,6 +74,7 @@ struct Tune {
                          // dense vectors and whole ghost planes (exchange_ring).  0 until exchange_ring_v has run on more than one GPU: no
                          // multi-GPU node has been available to any round, and the variable-length ring exchange is the code with the
                          // posting-order argument and the skipped empty messages.  The in-process transport always compacts.
+  int resid0_bits = 1;   // cg_begin: the initial residual from the active bits (k_residual0_ramp); 0: from x through the stencil (cross-check, same bits)
   int force_comm = 0;    // keep a one-rank communicator (single-GPU rehearsal of the RCCL path; env OI_FORCE_COMM)
   int max_blocks = 4096; // capacity (blocks) of the handle's per-block partial-sum array
 };
@@ -154,8 +155,9 @@ void launch_unpack_mask(const Geom& g, const uint64_t* active, uint8_t* mask_out
 
 // r = -A x on free cells, p = z (z = r or r/code), partials {rr, rz}
 // (lineoff != null: r goes to the compacted line layout, see launch_build_lines)
+// (active != null: x is the initial field launch_init_field makes of these bit planes -- the residual is formed from the bits, same bits)
 int launch_residual0(const Geom& g, const uint8_t* code, const double* x, double* r, double* p, int jacobi,
-                     double* partials, const int* lineoff, hipStream_t s);
+                     double* partials, const int* lineoff, hipStream_t s, const uint64_t* active = nullptr);
 // Compacted line layout of the single-kernel iteration: only the aligned kLV-voxel lines (owned and ghost
 // planes) that hold a free voxel are stored, in (plane, row, line) order.  lineoff[(gz * ny + j) * LW + line],
 // LW = ceil(pitch / 16), is a line's slot or -1; plane_first_dev[gz] (gz = 0 .. nzl + 2) the first slot of a plane.

@@ -1194,10 +1194,10 @@ extern "C" oi_status oi_tort_cg_begin(oi_tort* h) {
     HIPC(hipMemsetAsync(h->r2, 0, sizeof(double) * h->nvec_cg, s));
     HIPC(hipMemsetAsync(h->q2, 0, sizeof(double) * h->nvec_cg, s));
     HIPC(hipMemsetAsync(h->rec, 0, sizeof(double) * kRec1Stride * h->hist_cap, s));
-    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, h->lineoff, s); }
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r2, nullptr, h->jacobi, h->partials, h->lineoff, s, g.tune.resid0_bits ? h->active : nullptr); }
     OIC(exchange_cg_vec(h, h->r2, sizeof(double), s));
   } else {
-    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, h->lineoff, s); }
+    { PROF(K_RESID0); nb = launch_residual0(g, h->code, h->x, h->r, (h->fused || h->mg) ? nullptr : (double*)h->p[0], h->jacobi, h->partials, h->lineoff, s, g.tune.resid0_bits ? h->active : nullptr); }
     // hist[k=0] = {-, rr_0, rz_0}; converged before the first iteration -> done = 1
     OIC(reduce_to(h, nb, 2, h->hist + H_RR, true, 1));
     if (h->fused || h->mg) OIC(exchange_cg_vec(h, h->r, sizeof(double), s));
@@ -2285,6 +2285,7 @@ extern "C" oi_status oi_tort_set_option(const char* key, double value) {
   else if (k == "mg_coarsest_plain") t.mg_coarsest_plain = iv != 0;
   else if (k == "mg_nu_coarse") t.mg_nu_coarse = iv >= 2 ? 2 : (iv == 1 ? 1 : 0);
   else if (k == "force_comm") t.force_comm = iv != 0;
+  else if (k == "resid0_bits") t.resid0_bits = iv != 0;
   else if (k == "ring_lines_rccl") t.ring_lines_rccl = iv != 0;
   else if (k == "place_trials") t.place_trials = iv > 0 ? iv : 0;
   else if (k == "place_slots") t.place_slots = iv;

@@ -825,3 +825,30 @@ def test_multigrid_tiled_coarse_post_smoother_is_bit_identical(oi_option, shape,
     assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3] and all(r[0] for r in a[3])
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
 
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_initial_residual_from_the_mask_bits_is_bit_identical(oi_option, direction):
+    """Round 5: cg_begin forms r_0 = -A x_0 from the active BITS (x_0 is the reference's linear ramp on active cells, a function of
+    position and mask: TortuosityHypreFill.F90:233-262) instead of reading x_0 through the stencil -- the same values in the same
+    order of operations: ||r_0||, and the iterate after some launches, equal the stencil form's bit for bit, in every direction, on a
+    ragged shape (odd nx: the pad column), with Jacobi (z_0 = r_0 / c), dense and compacted vectors, and across slabs' ghost planes."""
+    phase = o.gen_spheres((23, 26, 37), 5, 4, 0.5)
+    out = {}
+    for bits in (1, 0):
+        oi_option("resid0_bits", bits, reset=1)
+        res = []
+        for kw in (dict(kernel=oia.KERNEL_FUSED1), dict(kernel=oia.KERNEL_FUSED1, precond=oia.PRECOND_JACOBI), dict(),
+                   dict(kernel=oia.KERNEL_UNFUSED, precond=oia.PRECOND_JACOBI), dict(kernel=oia.KERNEL_LEAN)):
+            t = oia.TortuosityMI355(phase, 1, direction, -1.0, 2.0, eps=1e-300, maxiter=400, **kw)
+            t.cg_begin()
+            its0, rel0, _ = t.cg_state()
+            t.cg_iterate(9); t.sync()
+            its, rel, _ = t.cg_state()
+            t.cg_finish()
+            res.append((its0, rel0, its, rel, t.solution().copy()))
+            t.destroy()
+        out[bits] = res
+    for a, b in zip(out[1], out[0]):
+        assert a[:4] == b[:4] and a[1] > 0.0
+        assert np.array_equal(a[4], b[4])
