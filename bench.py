@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-stored-p variant")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed + RCCL code path even with one rank (rehearsal)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="named process default of the library (oi_tort_set_option) set before any handle is built: measurement runs")
     ap.add_argument("--dry-launch", action="store_true",
                     help="N > 1 without a launcher: start the N child ranks, let them rendezvous over gloo on the CPU and report "
                          "their environment and command line instead of benchmarking (tests/test_bench_launch_cpu.py)")
@@ -340,6 +342,9 @@ def main():
     import openimpala_amd as oia
     if args.force_dist:
         oia.set_option("force_comm", 1)
+    for kv in args.option:
+        key, _, val = kv.partition("=")
+        oia.set_option(key.strip(), float(val))
 
     if use_dist:
         with _StdoutToStderr():

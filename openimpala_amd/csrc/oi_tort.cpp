@@ -1526,8 +1526,10 @@ extern "C" oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_
       if (k_prev >= 0 && K > k_prev && rr > 0.0 && rr < rr_prev && tol2 > 0.0 && rr > tol2) {
         const double per_iter = std::log(rr / rr_prev) / (double)(K - k_prev);  // < 0
         const double need = std::log(tol2 / rr) / per_iter;                     // iterations until ||r||^2 <= tol2 at that rate
-        // (the rotated iteration sees iteration K's residual in launch K: `need` more launches reach it; one in hand for a slower tail)
-        next = (int)std::ceil(need) + (h->rot ? 1 : 0);
+        // (`need` more launches form -- and test -- the residual of iteration K + need in every variant; a tail that contracts more
+        // slowly than the estimate costs one more single-launch batch and its 50 us poll, an over-estimate a launch whose coarse levels
+        // run for nothing)
+        next = (int)std::ceil(need);
         if (next < 1) next = 1;
       }
       k_prev = K; rr_prev = rr;

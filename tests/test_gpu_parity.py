@@ -850,5 +850,5 @@ def test_initial_residual_from_the_mask_bits_is_bit_identical(oi_option, directi
             t.destroy()
         out[bits] = res
     for a, b in zip(out[1], out[0]):
-        assert a[:4] == b[:4] and a[1] > 0.0
+        assert a[:4] == b[:4] and a[3] > 0.0
         assert np.array_equal(a[4], b[4])
