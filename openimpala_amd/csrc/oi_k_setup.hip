@@ -390,16 +390,15 @@ __global__ void __launch_bounds__(256) k_residual0_ramp(Geom g, const uint8_t* _
   const int nd = g.dir == 0 ? g.nx : (g.dir == 1 ? g.ny : g.nz);
   const double extent = (double)(nd - 1);
   const double factor = (extent < 1e-15) ? 0.0 : 1.0 / extent;
-  // what k_init_field stores at (gz, j, i): exactly its expressions
-  auto xval = [&](int gz, int j, int i) -> double {
-    if (i < 0 || i >= g.nx || j < 0 || j >= g.ny) return 0.0;
-    if (!bit_at(active, g, gz, j, i)) return 0.0;
-    const int cd = g.dir == 0 ? i : (g.dir == 1 ? j : g.z0 + gz - 1);
+  // what k_init_field stores on an active cell whose coordinate along the flow axis is cd: exactly its expressions
+  auto ramp = [&](int cd) -> double {
     double v = g.vlo + (g.vhi - g.vlo) * (double)cd * factor;
     if (cd == 0) v = g.vlo;
     else if (cd == nd - 1) v = g.vhi;
     return v;
   };
+  // bit i of a row of the bit planes (0 outside the row)
+  auto bit = [&](const uint64_t* row, int i) -> bool { return i >= 0 && i < g.nx && ((row[i >> 6] >> (i & 63)) & 1ull); };
   double rr = 0.0, rz = 0.0;
   OI_PAIR_LOOP_BEGIN
   if (!cc) {
@@ -408,11 +407,21 @@ __global__ void __launch_bounds__(256) k_residual0_ramp(Geom g, const uint8_t* _
     continue;
   }
   const int gz = (int)(e / g.plane);
+  const uint64_t* rc = active + (long long)gz * g.wplane + (long long)j * g.W;
+  // the field's values this pair's stencil can meet: along the flow axis the coordinate moves by one, across it it does not
+  const int cd0 = g.dir == 0 ? i : (g.dir == 1 ? j : g.z0 + gz - 1);
+  const double v0 = ramp(cd0), v1 = g.dir == 0 ? ramp(cd0 + 1) : v0;            // voxels i and i + 1
+  const double vm = ramp(cd0 - 1), vp = ramp(g.dir == 0 ? cd0 + 2 : cd0 + 1);    // one step down / up the axis (used where that cell is active)
+  const double cx = bit(rc, i) ? v0 : 0.0, cy = bit(rc, i + 1) ? v1 : 0.0;
+  const double xm = bit(rc, i - 1) ? (g.dir == 0 ? vm : v0) : 0.0, xp = bit(rc, i + 2) ? (g.dir == 0 ? vp : v1) : 0.0;
+  const bool jm = j > 0, jp = j < g.ny - 1;
+  const double ym0 = (jm && bit(rc - g.W, i)) ? (g.dir == 1 ? vm : v0) : 0.0, ym1 = (jm && bit(rc - g.W, i + 1)) ? (g.dir == 1 ? vm : v1) : 0.0;
+  const double yp0 = (jp && bit(rc + g.W, i)) ? (g.dir == 1 ? vp : v0) : 0.0, yp1 = (jp && bit(rc + g.W, i + 1)) ? (g.dir == 1 ? vp : v1) : 0.0;
+  const double zm0 = bit(rc - g.wplane, i) ? (g.dir == 2 ? vm : v0) : 0.0, zm1 = bit(rc - g.wplane, i + 1) ? (g.dir == 2 ? vm : v1) : 0.0;
+  const double zp0 = bit(rc + g.wplane, i) ? (g.dir == 2 ? vp : v0) : 0.0, zp1 = bit(rc + g.wplane, i + 1) ? (g.dir == 2 ? vp : v1) : 0.0;
   // apply_pair on the field: ((((xm + xp) + ym) + yp) + zm) + zp per voxel of the pair
-  const double cx = xval(gz, j, i), cy = xval(gz, j, i + 1);
-  const double xm = xval(gz, j, i - 1), xp = xval(gz, j, i + 2);
-  const double s0 = ((((xm + cy) + xval(gz, j - 1, i)) + xval(gz, j + 1, i)) + xval(gz - 1, j, i)) + xval(gz + 1, j, i);
-  const double s1 = ((((cx + xp) + xval(gz, j - 1, i + 1)) + xval(gz, j + 1, i + 1)) + xval(gz - 1, j, i + 1)) + xval(gz + 1, j, i + 1);
+  const double s0 = ((((xm + cy) + ym0) + yp0) + zm0) + zp0;
+  const double s1 = ((((cx + xp) + ym1) + yp1) + zm1) + zp1;
   const double qa = c0 ? (double)c0 * cx - s0 : 0.0, qb = c1 ? (double)c1 * cy - s1 : 0.0;
   const double r0 = c0 ? -qa : 0.0, r1 = c1 ? -qb : 0.0;
   const double z0 = (jacobi && c0) ? r0 / (double)c0 : r0;

@@ -1526,10 +1526,8 @@ extern "C" oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_
       if (k_prev >= 0 && K > k_prev && rr > 0.0 && rr < rr_prev && tol2 > 0.0 && rr > tol2) {
         const double per_iter = std::log(rr / rr_prev) / (double)(K - k_prev);  // < 0
         const double need = std::log(tol2 / rr) / per_iter;                     // iterations until ||r||^2 <= tol2 at that rate
-        // (`need` more launches form -- and test -- the residual of iteration K + need in every variant; a tail that contracts more
-        // slowly than the estimate costs one more single-launch batch and its 50 us poll, an over-estimate a launch whose coarse levels
-        // run for nothing)
-        next = (int)std::ceil(need);
+        // (`need` more launches form -- and test -- the residual of iteration K + need in every variant)
+        next = (int)std::floor(need);  // (rounded DOWN: a launch too few costs one more single-launch batch, a launch too many a whole coarse cycle)
         if (next < 1) next = 1;
       }
       k_prev = K; rr_prev = rr;
