@@ -301,30 +301,40 @@ void launch_codes(const Geom& g, const uint64_t* active, uint8_t* code, unsigned
 // Initial field: the reference's linear ramp on active cells (TortuosityHypreFill.F90:
 // 233-262) with the exact Dirichlet values on the two faces (F90:191-228); ghost planes
 // are filled from the ghost bits so no exchange is needed before the first apply.
+// (one block per row: no 64-bit division per element, 16-byte stores)
 __global__ void __launch_bounds__(256) k_init_field(Geom g, const uint64_t* __restrict__ active,
                                                      double* __restrict__ x) {
   const int nd = g.dir == 0 ? g.nx : (g.dir == 1 ? g.ny : g.nz);
   const double extent = (double)(nd - 1);
   const double factor = (extent < 1e-15) ? 0.0 : 1.0 / extent;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < g.nvec;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(e % g.pitch);
-    const int j = (int)((e / g.pitch) % g.ny);
-    const int gz = (int)(e / g.plane);
+  const long long nrows = (long long)(g.nzl + 2) * g.ny;
+  for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int j = (int)(row % g.ny);
+    const int gz = (int)(row / g.ny);
     const int kz = g.z0 + gz - 1;
-    double v = 0.0;
-    if (i < g.nx && bit_at(active, g, gz, j, i)) {
-      const int cd = g.dir == 0 ? i : (g.dir == 1 ? j : kz);
-      v = g.vlo + (g.vhi - g.vlo) * (double)cd * factor;
-      if (cd == 0) v = g.vlo;
-      else if (cd == nd - 1) v = g.vhi;
+    const uint64_t* bits = active + (long long)gz * g.wplane + (long long)j * g.W;
+    double* xr = x + row * g.pitch;
+    for (int i = 2 * (int)threadIdx.x; i < g.pitch; i += 2 * (int)blockDim.x) {  // pitch is even: whole pairs
+      double v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ii = i + t;
+        v[t] = 0.0;
+        if (ii < g.nx && ((bits[ii >> 6] >> (ii & 63)) & 1ull)) {
+          const int cd = g.dir == 0 ? ii : (g.dir == 1 ? j : kz);
+          v[t] = g.vlo + (g.vhi - g.vlo) * (double)cd * factor;
+          if (cd == 0) v[t] = g.vlo;
+          else if (cd == nd - 1) v[t] = g.vhi;
+        }
+      }
+      st2(xr + i, v[0], v[1]);
     }
-    x[e] = v;
   }
 }
 
 void launch_init_field(const Geom& g, const uint64_t* active, double* x, hipStream_t s) {
-  const int blocks = cap_blocks(g.nvec, 256, 8192);
+  const long long nrows = (long long)(g.nzl + 2) * g.ny;
+  const int blocks = (int)std::min<long long>(nrows, 1 << 20);
   hipLaunchKernelGGL(k_init_field, dim3(blocks), dim3(256), 0, s, g, active, x);
 }
 
@@ -381,9 +391,11 @@ __global__ void __launch_bounds__(256) k_residual0(Geom g, const uint8_t* __rest
 }
 
 // The same residual when x IS the initial field of k_init_field: its values are a function of the position and the active bit, so the
-// seven-point stencil is evaluated from the bit planes (1/8 byte per voxel, cache-served) instead of from x (8 bytes per voxel through
-// seven strided loads) -- same values, same order of operations as k_residual0 on that field, hence the same bits; 5.7 -> ~1.5 ms at
-// 1024^3 (cg_begin of every solve).
+// seven-point stencil is evaluated from the bit planes (1/8 byte per voxel) instead of from x (8 bytes per voxel through seven strided
+// loads): 1.2 GB read instead of 9.7 at 1024^3.  Same values, same order of operations as k_residual0 on that field, hence the same
+// bits (tests: ..._initial_residual_from_the_mask_bits_is_bit_identical).  Along the flow axis a pair's stencil meets four values of
+// the ramp, across it one: they are formed once per pair, the neighbours contribute a bit each.  (Time: 5.4 ms against 5.7 -- the
+// pair loop is bound by its chain of dependent round trips, code byte -> bits -> slot -> store, not by the bytes.)
 __global__ void __launch_bounds__(256) k_residual0_ramp(Geom g, const uint8_t* __restrict__ code, const uint64_t* __restrict__ active,
                                                          double* __restrict__ r, double* __restrict__ p, int jacobi,
                                                          double* __restrict__ partials, const int* __restrict__ lineoff, int LW) {
@@ -397,8 +409,6 @@ __global__ void __launch_bounds__(256) k_residual0_ramp(Geom g, const uint8_t* _
     else if (cd == nd - 1) v = g.vhi;
     return v;
   };
-  // bit i of a row of the bit planes (0 outside the row)
-  auto bit = [&](const uint64_t* row, int i) -> bool { return i >= 0 && i < g.nx && ((row[i >> 6] >> (i & 63)) & 1ull); };
   double rr = 0.0, rz = 0.0;
   OI_PAIR_LOOP_BEGIN
   if (!cc) {
@@ -408,17 +418,27 @@ __global__ void __launch_bounds__(256) k_residual0_ramp(Geom g, const uint8_t* _
   }
   const int gz = (int)(e / g.plane);
   const uint64_t* rc = active + (long long)gz * g.wplane + (long long)j * g.W;
+  // seven words, requested back to back with clamped (always valid) addresses -- a guarded load per neighbour would put seven
+  // memory round trips in a row; what lies outside the row / the plane is masked afterwards
+  const int w0 = i >> 6, wm = max(i - 1, 0) >> 6, wp = min(i + 2, g.nx - 1) >> 6;
+  const bool jm = j > 0, jp = j < g.ny - 1;
+  const uint64_t Wc = rc[w0], Wm = rc[wm], Wp = rc[wp];
+  const uint64_t Wym = (jm ? rc - g.W : rc)[w0], Wyp = (jp ? rc + g.W : rc)[w0];
+  const uint64_t Wzm = (rc - g.wplane)[w0], Wzp = (rc + g.wplane)[w0];
+  const int b0 = i & 63;                 // i is even: voxel i + 1 is bit b0 + 1 of the same word
+  const bool in1 = i + 1 < g.nx;
+  auto at = [](uint64_t w, int b) -> bool { return (w >> b) & 1ull; };
   // the field's values this pair's stencil can meet: along the flow axis the coordinate moves by one, across it it does not
   const int cd0 = g.dir == 0 ? i : (g.dir == 1 ? j : g.z0 + gz - 1);
   const double v0 = ramp(cd0), v1 = g.dir == 0 ? ramp(cd0 + 1) : v0;            // voxels i and i + 1
   const double vm = ramp(cd0 - 1), vp = ramp(g.dir == 0 ? cd0 + 2 : cd0 + 1);    // one step down / up the axis (used where that cell is active)
-  const double cx = bit(rc, i) ? v0 : 0.0, cy = bit(rc, i + 1) ? v1 : 0.0;
-  const double xm = bit(rc, i - 1) ? (g.dir == 0 ? vm : v0) : 0.0, xp = bit(rc, i + 2) ? (g.dir == 0 ? vp : v1) : 0.0;
-  const bool jm = j > 0, jp = j < g.ny - 1;
-  const double ym0 = (jm && bit(rc - g.W, i)) ? (g.dir == 1 ? vm : v0) : 0.0, ym1 = (jm && bit(rc - g.W, i + 1)) ? (g.dir == 1 ? vm : v1) : 0.0;
-  const double yp0 = (jp && bit(rc + g.W, i)) ? (g.dir == 1 ? vp : v0) : 0.0, yp1 = (jp && bit(rc + g.W, i + 1)) ? (g.dir == 1 ? vp : v1) : 0.0;
-  const double zm0 = bit(rc - g.wplane, i) ? (g.dir == 2 ? vm : v0) : 0.0, zm1 = bit(rc - g.wplane, i + 1) ? (g.dir == 2 ? vm : v1) : 0.0;
-  const double zp0 = bit(rc + g.wplane, i) ? (g.dir == 2 ? vp : v0) : 0.0, zp1 = bit(rc + g.wplane, i + 1) ? (g.dir == 2 ? vp : v1) : 0.0;
+  const double cx = at(Wc, b0) ? v0 : 0.0, cy = (in1 && at(Wc, b0 + 1)) ? v1 : 0.0;
+  const double xm = (i > 0 && at(Wm, (i - 1) & 63)) ? (g.dir == 0 ? vm : v0) : 0.0;
+  const double xp = (i + 2 < g.nx && at(Wp, (i + 2) & 63)) ? (g.dir == 0 ? vp : v1) : 0.0;
+  const double ym0 = (jm && at(Wym, b0)) ? (g.dir == 1 ? vm : v0) : 0.0, ym1 = (jm && in1 && at(Wym, b0 + 1)) ? (g.dir == 1 ? vm : v1) : 0.0;
+  const double yp0 = (jp && at(Wyp, b0)) ? (g.dir == 1 ? vp : v0) : 0.0, yp1 = (jp && in1 && at(Wyp, b0 + 1)) ? (g.dir == 1 ? vp : v1) : 0.0;
+  const double zm0 = at(Wzm, b0) ? (g.dir == 2 ? vm : v0) : 0.0, zm1 = (in1 && at(Wzm, b0 + 1)) ? (g.dir == 2 ? vm : v1) : 0.0;
+  const double zp0 = at(Wzp, b0) ? (g.dir == 2 ? vp : v0) : 0.0, zp1 = (in1 && at(Wzp, b0 + 1)) ? (g.dir == 2 ? vp : v1) : 0.0;
   // apply_pair on the field: ((((xm + xp) + ym) + yp) + zm) + zp per voxel of the pair
   const double s0 = ((((xm + cy) + ym0) + yp0) + zm0) + zp0;
   const double s1 = ((((cx + xp) + ym1) + yp1) + zm1) + zp1;

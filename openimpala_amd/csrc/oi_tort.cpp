@@ -1527,8 +1527,9 @@ extern "C" oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_
         const double per_iter = std::log(rr / rr_prev) / (double)(K - k_prev);  // < 0
         const double need = std::log(tol2 / rr) / per_iter;                     // iterations until ||r||^2 <= tol2 at that rate
         // (`need` more launches form -- and test -- the residual of iteration K + need in every variant)
-        next = (int)std::floor(need);  // (rounded DOWN: a launch too few costs one more single-launch batch, a launch too many a whole coarse cycle)
-        if (next < 1) next = 1;
+        // (CG's contraction is not uniform: within a batch and a half of the end the launches go out one by one -- a poll costs
+        // ~0.1 ms, a launch issued after convergence a whole coarse cycle)
+        next = need > (double)batch + 2.0 ? batch : 1;
       }
       k_prev = K; rr_prev = rr;
       if (h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] %d launches issued, ||r||^2 = %.3e, next batch %d\n", h->iters_issued, rr, std::min(next, batch));
