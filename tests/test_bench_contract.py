@@ -39,6 +39,14 @@ def test_bench_line_single_gpu():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
     assert d["time_to_1e-6"]["converged"] and d["time_to_1e-6_multigrid_pcg"]["converged"]
     assert all(d["homogenization"]["converged"])
+    # the default solver path carries its own roofline record (round 5): the three fine kernels of an iteration + the coarse levels
+    m = d["time_to_1e-6_multigrid_pcg"]
+    assert m["launches"] in (m["iterations"], m["iterations"] + 1, m["iterations"] + 2) and m["create_total_s"] > 0
+    rf = m["roofline"]
+    for k in ("form1_first_kernel", "form2_residual_presmoother_restriction", "form3_post_smoother_incl_pairwise_x"):
+        assert {"ms_per_launch", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf[k]) and 0 < rf[k]["frac"] < 1
+    assert rf["coarse_levels"]["ms_per_iteration"] > 0 and rf["iteration"]["ms"] > 0
+    assert d["transport"] is None   # (one GPU, no launcher: no transport to describe)
 
 
 def test_bench_line_through_the_rccl_path():
