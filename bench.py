@@ -464,7 +464,8 @@ def main():
             a.update(b)
         transport = {"kind": info["kind"], "rccl_ranks": [min(t["rccl_ranks_collective"] for t in timed), min(t["rccl_ranks_p2p"] for t in timed)],
                      "exchange_overlaps": all(t["exchange_overlaps"] for t in timed),
-                     "exchange_stream": "own stream, highest priority" if all(t["exchange_overlaps"] for t in timed) else "solver stream",
+                     "exchange_stream": ("own stream" + (f", priority {os.environ['OI_COMM_PRIO']}" if os.environ.get("OI_COMM_PRIO") in ("greatest", "least") else ""))
+                                        if all(t["exchange_overlaps"] for t in timed) else "solver stream",
                      "ms_per_step_per_rank": [t["ms_per_step"] for t in timed]}
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
