@@ -337,7 +337,7 @@ int oi_comm_rank(const oi_comm* c);
 int oi_comm_size(const oi_comm* c);
 /* What the transport really is (a multi-GPU bench line reports it, so that a run is self-describing): kind 1 = RCCL, 2 = in-process;
  * ranks_collective / ranks_p2p = ncclCommCount of the all-reduce communicator and of the plane-exchange communicator (RCCL; the rank
- * count of the group otherwise); exchange_overlaps = 1 when the plane exchange runs on its own (highest-priority) stream beside the
+ * count of the group otherwise); exchange_overlaps = 1 when the plane exchange runs on its own stream beside the
  * scalar all-reduce (it has a communicator of its own), 0 when one communicator serves both and everything stays on one stream. */
 oi_status oi_comm_info(const oi_comm* c, int* kind, int* ranks_collective, int* ranks_p2p, int* exchange_overlaps);
 
