@@ -302,6 +302,8 @@ int oi_tort_line_voxels(void);
  *                   arithmetic, other cache policy); 0 = the default policy everywhere (A/B)
  * The environment variables OI_TILE_MAP, OI_ZCHUNK, OI_APPLY_KERNEL, OI_MG_PLAIN, OI_MG_NOVEC4, OI_MG_DEBUG,
  * OI_MG_REPLICATE_CELLS, OI_MG_WMASK, OI_MG_SCALE, OI_FORCE_COMM, OI_PLACE_TRIALS, OI_PLACE_SLOTS, OI_PLACE_SPACER_GB, OI_PLACE_EXTENT_GB, OI_PLACE_MIN_MB, OI_PLACE_CACHE seed the same defaults, read ONCE per process.
+ * OI_COMM_PRIO=greatest|least (read when a slab handle is built): the ghost-plane exchange stream is made with that stream priority
+ * instead of as an ordinary stream (measured 7-8 % slower on a one-rank rehearsal; for experiments on a multi-GPU node).
  * OI_BAD_ARG for an unknown key. */
 oi_status oi_tort_set_option(const char* key, double value);
 /* copy the current process defaults of the launch shapes into a live handle (layout, multigrid hierarchy and the
