@@ -149,7 +149,10 @@ ncclResult_t run_group(std::vector<Op>& ops) {
     if (m->bytes != o.bytes) {
       fprintf(stderr, "[fake_rccl] rank %d: receive of %zu bytes from rank %d met a send of %zu bytes\n", o.comm->rank, o.bytes, o.peer, m->bytes);
       rc = ncclInvalidArgument;
-    } else if (o.bytes && hipMemcpy(o.buf, m->ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+    } else if (o.bytes && (hipMemcpyAsync(o.buf, m->ptr, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess ||
+                           hipStreamSynchronize(o.stream) != hipSuccess)) {
+      // (on the receive's own stream and waited for: a blocking hipMemcpy between device buffers may return before the bytes have
+      // landed, and the null stream does not order with the solver's non-blocking streams)
       rc = ncclUnhandledCudaError;
     }
     {

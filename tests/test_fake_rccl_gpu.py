@@ -61,17 +61,18 @@ for direction in (0, 2):
                      ("unfused", dict(kernel=oia.KERNEL_UNFUSED, precond=oia.PRECOND_NONE))):
         single = oia.TortuosityMI355(phase, 1, direction, -1.0, 1.0, eps=1e-11, **kw)
         tau1, it1, mask1, x1 = single.value(), single.getSolverIterations(), single.mask(), single.solution()
+        assert single.status == oia.OI_OK, (name, direction, single.status, single.stats().final_relres)
         single.destroy()
         for n in (2, 3, 4):
             def work(r, c):
                 z0, z1 = oia.slab_range(nz, n, r)
                 t = oia.TortuosityMI355(np.ascontiguousarray(phase[z0:z1]), 1, direction, -1.0, 1.0, eps=1e-11, comm=c, z0=z0, nz_global=nz, **kw)
                 ok = t.checkMatrixProperties()
-                res = (t.value(), t.getSolverIterations(), t.mask(), t.solution(), ok, t.status)
+                res = (t.value(), t.getSolverIterations(), t.mask(), t.solution(), ok, t.status, t.stats().final_relres)
                 t.destroy()
                 return res
             res = ranks(n, work)
-            assert all(r[4] and r[5] == oia.OI_OK for r in res), (name, n)
+            assert all(r[4] and r[5] == oia.OI_OK for r in res), (name, direction, n, [(r[4], r[5], r[1], r[6]) for r in res], it1)
             assert all(r[0] == res[0][0] for r in res), (name, n)                      # every rank the same global answer
             assert abs(res[0][0] - tau1) <= 1e-9 * abs(tau1), (name, direction, n, res[0][0], tau1)
             assert all(abs(r[1] - it1) <= 2 for r in res), (name, n, [r[1] for r in res], it1)
