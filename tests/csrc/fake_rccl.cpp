@@ -11,8 +11,13 @@
 // side issued them; a send and its receive must carry the same byte count (a mismatch is reported as an error here, where the real
 // library would hang or corrupt); a collective returns on every rank only when every rank has called it.  A rank that waits longer
 // than 30 s for its peer fails with ncclInternalError instead of hanging (what a dead-lock of the call pattern would look like).
-// What it does NOT model: asynchrony.  Every call synchronises its stream, moves the bytes with blocking device-to-device copies and
-// returns when its operations are complete -- stricter ordering than the real library, so missing event waits cannot show here.
+// Two modes.  Default: every call synchronises its stream, moves the bytes with waited-for device-to-device copies and returns when
+// its operations are complete -- stricter ordering than the real library.  FAKE_RCCL_ASYNC=1: send / receive are enqueued on the
+// caller's streams and ordered by events only, as in the real library (run_group_async); =2 also holds every receive back by 2 ms.
+// How much that proves is limited: a build of the solver WITHOUT its final "solver stream waits for the exchange" still gave the
+// right answers under mode 2 on this box (round 5, gpurun_out only) -- HIP multiplexes the streams of all rank threads onto a few
+// hardware queues, which orders more than the events do -- so the asynchronous mode checks the event bookkeeping for dead-locks
+// and use-after-destroy, not for missing waits.  Not modelled in any mode: the collectives' asynchrony, xGMI, RCCL's own kernels.
 // Test infrastructure only: nothing in the product links or loads it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -20,6 +25,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -34,6 +40,13 @@ struct Msg {
   const void* ptr;
   size_t bytes;
   bool taken = false;
+  // FAKE_RCCL_ASYNC=1: `ready` is recorded on the sender's stream when the send is issued, `done` on the receiver's stream behind its
+  // copy; each side's STREAM waits for the other's event, no host thread waits for the device (see run_group)
+  hipEvent_t ready = nullptr, done = nullptr;
+  ~Msg() {
+    if (ready) (void)hipEventDestroy(ready);
+    if (done) (void)hipEventDestroy(done);
+  }
 };
 struct World {
   int n = 0;
@@ -116,7 +129,88 @@ ncclResult_t gather_all(ncclComm* c, const void* mine, size_t n, std::vector<std
   return ncclSuccess;
 }
 
+int async_level() {
+  static const int v = getenv("FAKE_RCCL_ASYNC") ? atoi(getenv("FAKE_RCCL_ASYNC")) : 0;
+  return v;
+}
+bool async_mode() { return async_level() != 0; }
+// FAKE_RCCL_ASYNC=2: every receive's copy is held back by ~2 ms of spinning on its stream -- a slow link.  A consumer that does not
+// wait for the exchange's stream then reads the OLD plane for certain, instead of winning a race it would lose on a loaded node.
+__global__ void k_fake_delay(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+bool delay_ok(hipStream_t s) {
+  if (async_level() < 2) return true;
+  hipLaunchKernelGGL(k_fake_delay, dim3(1), dim3(1), 0, s, 200000ll);  // wall_clock64 counts at 100 MHz: 2 ms
+  return hipGetLastError() == hipSuccess;
+}
+
+// ASYNCHRONOUS mode (FAKE_RCCL_ASYNC=1): like the real library, a send / receive is work enqueued on the caller's stream.  The sender
+// records an event where the send was issued; the receiver's stream waits for it, copies, and records a second event the sender's
+// stream waits for before anything later on that stream may overwrite the buffer.  No stream is synchronised with the host, so a
+// consumer on ANOTHER stream that does not wait for the exchange's stream (a missing event in the solver) reads stale planes here
+// as it would on a real node.  (The host threads still meet to hand the events over; collectives stay host-synchronous.)
+ncclResult_t run_group_async(std::vector<Op>& ops) {
+  std::vector<std::shared_ptr<Msg>> mine;
+  for (const Op& o : ops) {
+    if (!o.send) continue;
+    World& w = *o.comm->w;
+    auto m = std::make_shared<Msg>();
+    m->ptr = o.buf;
+    m->bytes = o.bytes;
+    if (hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(m->ready, o.stream) != hipSuccess)
+      return ncclUnhandledCudaError;
+    {
+      std::lock_guard<std::mutex> lk(w.m);
+      w.box[{o.comm->rank, o.peer}].push_back(m);
+    }
+    w.cv.notify_all();
+    mine.push_back(m);
+  }
+  ncclResult_t rc = ncclSuccess;
+  for (const Op& o : ops) {
+    if (o.send) continue;
+    World& w = *o.comm->w;
+    std::shared_ptr<Msg> m;
+    {
+      std::unique_lock<std::mutex> lk(w.m);
+      auto& q = w.box[{o.peer, o.comm->rank}];
+      if (!wait_for(w, lk, [&] { return !q.empty(); }, "a send that matches its receive", o.comm->rank)) return ncclInternalError;
+      m = q.front();
+      q.pop_front();
+    }
+    if (m->bytes != o.bytes) {
+      fprintf(stderr, "[fake_rccl] rank %d: receive of %zu bytes from rank %d met a send of %zu bytes\n", o.comm->rank, o.bytes, o.peer, m->bytes);
+      rc = ncclInvalidArgument;
+    } else if (hipStreamWaitEvent(o.stream, m->ready, 0) != hipSuccess ||
+               !delay_ok(o.stream) ||
+               (o.bytes && hipMemcpyAsync(o.buf, m->ptr, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess) ||
+               hipEventRecord(m->done, o.stream) != hipSuccess) {
+      rc = ncclUnhandledCudaError;
+    }
+    {
+      std::lock_guard<std::mutex> lk(w.m);
+      m->taken = true;  // (= the copy is ENQUEUED and `done` recorded behind it)
+    }
+    w.cv.notify_all();
+  }
+  for (size_t k = 0, s = 0; k < ops.size(); ++k) {
+    if (!ops[k].send) continue;
+    World& w = *ops[k].comm->w;
+    auto m = mine[s++];
+    {
+      std::unique_lock<std::mutex> lk(w.m);
+      if (!wait_for(w, lk, [&] { return m->taken; }, "the receive that matches a send", ops[k].comm->rank)) return ncclInternalError;
+    }
+    if (hipStreamWaitEvent(ops[k].stream, m->done, 0) != hipSuccess) rc = ncclUnhandledCudaError;  // the buffer is the sender's again behind this point
+  }
+  return rc;
+}
+
 ncclResult_t run_group(std::vector<Op>& ops) {
+  if (async_mode()) return run_group_async(ops);
   // data the operations read must be complete: the stream(s) they were issued on
   for (const Op& o : ops)
     if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;

@@ -6,8 +6,9 @@ in-process ranks = host threads, NCCL's matching rules for grouped send / receiv
 an error after 30 s) with RTLD_GLOBAL BEFORE the product library, whose calls into librccl then resolve to it.  The UNCHANGED
 RcclComm code -- grouped ghost-plane exchanges of dense and compacted (variable-length) planes on an open chain and on a ring,
 skipped zero-length messages, the split communicator, the scalar and the large all-reduces -- runs with 2, 3 and 4 ranks behind
-oi_tort_create_slab / oi_effdiff_create_slab, and the answers equal the single-domain ones.  What this cannot show: anything that
-depends on RCCL's asynchrony (the double completes every call before it returns) or on xGMI."""
+oi_tort_create_slab / oi_effdiff_create_slab, and the answers equal the single-domain ones -- once with a double that completes every
+call before it returns and once with one whose send / receive are stream-ordered by events only, like the real library's.  What this
+cannot show: the collectives' asynchrony, RCCL's own kernels and resource use, xGMI."""
 import os
 import subprocess
 import sys
@@ -119,7 +120,11 @@ def fake_lib(tmp_path_factory):
     return lib
 
 
-def test_rccl_transport_with_two_three_and_four_ranks_through_the_test_double(fake_lib):
-    p = subprocess.run([sys.executable, "-c", CHILD, fake_lib, ROOT], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+@pytest.mark.parametrize("asynchronous", [0, 1])
+def test_rccl_transport_with_two_three_and_four_ranks_through_the_test_double(fake_lib, asynchronous):
+    """asynchronous = 1: the double's send / receive are enqueued on the caller's streams and ordered by events only (as in the real
+    library), so the solver's own event waits between the exchange stream and the kernels' streams are what keeps the planes current."""
+    p = subprocess.run([sys.executable, "-c", CHILD, fake_lib, ROOT], cwd=ROOT, capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, FAKE_RCCL_ASYNC=str(asynchronous)))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "fake-rccl ok: 30 multi-rank configurations" in p.stdout, p.stdout[-1000:]
