@@ -69,6 +69,10 @@ struct Tune {
   int place_min_mb = 256;  // vectors below this size (they sit in the 256 MB Infinity Cache) are not searched for
   float place_alloc_budget_s = 0.5f;  // spare slots (and the spacer) are allocated only while the set's allocations have
                          // taken less than this (the driver clears memory other processes have used: seconds for tens of GB)
+  float place_retry_gbps = 5150.f;  // fp64 vectors: a kept placement whose kernel moves fewer ALGORITHMIC GB/s than this (one byte per voxel + 60 per
+                         // voxel of a live line) is in the slow plateau some sets of allocations have wherever the vectors lie in them
+                         // (one process in thirteen: 4980-5020 against 5240-5450 GB/s at 1024^3, profiles/r05/placement_slow_plateau.txt)
+                         // -> a second set is allocated and searched, the better kept; 0 = never (env OI_PLACE_RETRY_GBPS)
   int place_cache = 1;   // reuse the placement an earlier handle of this process found for the same set of allocations
   int ring_lines_rccl = 0;  // homogenization on a ring of GPUs over RCCL: 1 = compacted line lists travel (oi_comm::exchange_ring_v), 0 = the
                          // dense vectors and whole ghost planes (exchange_ring).  0 until exchange_ring_v has run on more than one GPU: no

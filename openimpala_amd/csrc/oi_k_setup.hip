@@ -27,6 +27,7 @@ Tune default_tune() {
     if (const char* e = getenv("OI_PLACE_SPACER_GB")) g_tune_defaults.place_spacer_gb = (float)atof(e);
     if (const char* e = getenv("OI_PLACE_EXTENT_GB")) g_tune_defaults.place_extent_gb = (float)atof(e);
     if (const char* e = getenv("OI_PLACE_MIN_MB")) g_tune_defaults.place_min_mb = atoi(e);
+    if (const char* e = getenv("OI_PLACE_RETRY_GBPS")) g_tune_defaults.place_retry_gbps = (float)atof(e);
     if (const char* e = getenv("OI_PLACE_CACHE")) g_tune_defaults.place_cache = atoi(e) != 0;
   }
   return g_tune_defaults;
