@@ -664,6 +664,7 @@ static oi_status place_vectors(oi_tort* h) {
     const bool ok = hipEventRecord(b, s) == hipSuccess && hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     if (ok && ms > 0.f && 2.0 * 48.0 * (double)nd / (ms * 1e-3) < 5.8e12) again = 1;  // bytes per second of the stream
+    if (again && h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] vector placement: the stream of the kept vectors is slow (%.0f GB/s)\n", 2.0 * 48.0 * (double)nd / (ms * 1e-3) / 1e9);
     // (round 5) and by the kernel itself.  The stream does not see the other slow class: sets in which every placement of the
     // vectors sits on a plateau 8 % up (6.46-6.53 ms at 1024^3 where thirty other processes kept 5.92-6.14, the stream of the kept
     // vectors at 6.0-6.1 TB/s like theirs: profiles/r05/placement_slow_plateau.txt; x and the code bytes are not moved by the search).
@@ -676,8 +677,10 @@ static oi_status place_vectors(oi_tort* h) {
       // of vectors, 4070 GB/s for other reasons) is not worth tens of GB of the driver's clearing
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-          6 * h->slot_bytes + h->x_bytes + total_b / 4 <= free_b + oi::dev_pool_held(h->device))
+          6 * h->slot_bytes + h->x_bytes + total_b / 4 <= free_b + oi::dev_pool_held(h->device)) {
         again = 1;
+        if (h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] vector placement: the kept kernel is slow (%.0f algorithmic GB/s)\n", alg_bytes / (h->placement_ms_best * 1e-3) / 1e9);
+      }
       else
         (void)hipGetLastError();
     }
@@ -711,10 +714,12 @@ static oi_status place_vectors(oi_tort* h) {
       vecset_free(old.v);
       h->placement_tried += old.tried;
       if (h->opts.verbose > 1)
-        fprintf(stderr, "[openimpala_amd] vector placement: second set of allocations kept (%.3f ms; the first: %.3f -> %.3f, flat)\n",
+        fprintf(stderr, "[openimpala_amd] vector placement: second set of allocations kept (%.3f ms; the first: %.3f -> %.3f)\n",
                 h->placement_ms_best, old.first, old.best);
     } else {  // the first set stays
       const int tried2 = failed ? 0 : h->placement_tried;
+      if (h->opts.verbose > 1 && !failed && rc == OI_OK)
+        fprintf(stderr, "[openimpala_amd] vector placement: the first set of allocations stays (%.3f ms; the second: %.3f)\n", old.best, h->placement_ms_best);
       vecset_free(h->vs);
       h->vs = old.v;
       h->place_spacer_bytes = old.spacer;
