@@ -284,7 +284,8 @@ int oi_tort_line_voxels(void);
  *   "place_retry_gbps" fp64 vectors: when the kept placement's kernel moves fewer algorithmic GB/s than this (default 5150; one byte per
  *                   voxel + 60 per voxel of a live line), or a plain stream of the kept vectors fewer than 5800, the set of allocations
  *                   is taken to be one of the slow ones (where the driver put it, not which slots were chosen): a second set is
- *                   allocated while the first is held, searched, and the better of the two kept.  0 = the kernel's rate never asks
+ *                   allocated while the first is held, searched, and the better of the two kept.  0 = the kernel's rate never asks; slabs with
+ *                   neighbours are judged by the stream alone
  *   "place_min_mb"  vectors below this size are not searched for (default 256: they sit in the Infinity Cache)
  *   "place_cache"   1 (default): a handle reuses the placement an earlier handle of this process found for the same set of
  *                   allocations after verifying it with one timed cycle

@@ -671,7 +671,9 @@ static oi_status place_vectors(oi_tort* h) {
     // Known since round 2 ("one process in ten"), and one bench line in thirteen carried it.  In algorithmic bytes per second the
     // two groups are 4 % apart at their closest.
     const double alg_bytes = (double)h->g.nx * h->g.ny * h->g.nzl + 60.0 * (double)h->nvec_cg;
-    if (h->g.tune.place_retry_gbps > 0.f && h->placement_ms_best > 0.0 &&
+    // (single-domain handles only: the threshold is calibrated on whole volumes -- a slab's iteration carries its plane exchange, 4.6 TB/s
+    // on the one-rank rehearsal of a 128-plane slab, and would ask for a second search on every rank every time)
+    if (!h->comm && h->g.tune.place_retry_gbps > 0.f && h->placement_ms_best > 0.0 &&
         alg_bytes / (h->placement_ms_best * 1e-3) < (double)h->g.tune.place_retry_gbps * 1e9) {
       // only where a second x + six slots leave a quarter of the card free: a slab that fills the card (configuration 5's share: 135 GB
       // of vectors, 4070 GB/s for other reasons) is not worth tens of GB of the driver's clearing
