@@ -8,7 +8,7 @@
 //               planar config; 1-bit data honours FILLORDER and ignores PHOTOMETRIC;
 //               voxel > threshold -> 1 else 0.
 //               Encodings decoded here (what libtiff decodes for the reference): none, LZW (5),
-//               Deflate (8 / 32946, zlib), PackBits (32773), baseline JPEG (7, with JPEGTables), horizontal predictor (317 = 2), floating-point predictor (317 = 3);
+//               Deflate (8 / 32946, zlib), PackBits (32773), JPEG (7, with JPEGTables; sequential and progressive), horizontal predictor (317 = 2), floating-point predictor (317 = 3);
 //               classic TIFF and BigTIFF, both byte orders.  Anything else is reported, never guessed.
 //   RawReader   (src/io/RawReader.cpp:289-371 getValue, :379-491 threshold).
 #include <fcntl.h>
@@ -176,13 +176,14 @@ bool parse_ifd(const File& f, size_t off, Ifd& ifd, size_t& next) {
   return true;
 }
 
-// ---- baseline JPEG (TIFF compression 7, "new-style" JPEG-in-TIFF; TIFF Technical Note 2) ----
+// ---- JPEG (TIFF compression 7, "new-style" JPEG-in-TIFF; TIFF Technical Note 2) ----
 // What libtiff + libjpeg decode for the reference when a tomogram was saved with JPEG compression: every strip / tile is a JPEG
 // stream of its own (SOI ... EOI), usually abbreviated -- the quantisation and Huffman tables sit once in the JPEGTables tag.
 // Decoded here: sequential DCT, Huffman coding, 8-bit precision, ONE component (the readers take one sample per pixel only),
 // restart intervals; the inverse DCT is libjpeg's default integer one ("islow", Loeffler-Ligtenberg-Moschytz with 13-bit
-// constants: what jpeg_idct_islow and libjpeg-turbo's SIMD versions of it compute).  Progressive, arithmetic-coded, 12-bit and
-// multi-component streams and old-style JPEG (compression 6) are reported.
+// constants: what jpeg_idct_islow and libjpeg-turbo's SIMD versions of it compute); PROGRESSIVE streams (SOF2: spectral selection and
+// successive approximation, round 5) the same way once their scans are in.  Arithmetic-coded, 12-bit and multi-component streams and
+// old-style JPEG (compression 6) are reported.
 struct JpegTables {
   uint16_t q[4][64] = {};   // quantisation tables in natural (de-zigzagged) order
   bool have_q[4] = {false, false, false, false};
@@ -209,16 +210,26 @@ bool jpeg_build_huff(JpegTables::Huff& h) {
 }
 
 // the marker segments of one stream up to (and including the header of) SOS; returns the offset of the entropy-coded data
-struct JpegFrame { int w = 0, h = 0, tq = 0, td = 0, ta = 0; bool have_sof = false; };
-bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& fr, size_t& data_off, bool tables_only, std::string& why) {
-  size_t i = 0;
-  if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) { why = "no SOI marker"; return false; }
-  i = 2;
-  while (i + 4 <= n) {
+// (progressive: the frame is SOF2; ss..se / ah, al = spectral band and successive-approximation bit positions of the scan just parsed;
+// eoi: the stream ended where a further scan was looked for)
+struct JpegFrame { int w = 0, h = 0, tq = 0, td = 0, ta = 0, ss = 0, se = 63, ah = 0, al = 0; bool have_sof = false, progressive = false, eoi = false; };
+// start = 0: a whole stream (SOI first); start > 0: the segments after a scan of a progressive stream, up to the next SOS or EOI
+bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& fr, size_t& data_off, bool tables_only, std::string& why, size_t start = 0) {
+  size_t i = start;
+  if (start == 0) {
+    if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) { why = "no SOI marker"; return false; }
+    i = 2;
+  }
+  while (i + 2 <= n) {
     if (p[i] != 0xFF) { why = "marker expected"; return false; }
     const unsigned m = p[i + 1];
     if (m == 0xFF) { ++i; continue; }  // fill byte
-    if (m == 0xD9) { data_off = i; return tables_only; }  // EOI: fine for a tables-only stream
+    if (m == 0xD9) {  // EOI: fine for a tables-only stream and after a scan
+      data_off = i; fr.eoi = true;
+      if (!tables_only && start == 0) why = "no scan in the JPEG stream";
+      return tables_only || start > 0;
+    }
+    if (i + 4 > n) break;
     if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
     const size_t len = (size_t)p[i + 2] << 8 | p[i + 3];
     if (len < 2 || i + 2 + len > n) { why = "truncated marker segment"; return false; }
@@ -254,8 +265,9 @@ bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& f
         o += (size_t)total;
         if (!jpeg_build_huff(h)) { why = "inconsistent Huffman table"; return false; }
       }
-    } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: sequential, Huffman
-      if (sl < 6) { why = "bad frame header"; return false; }
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {  // SOF0 / SOF1: sequential, SOF2: progressive; Huffman
+      if (sl < 6 || fr.have_sof) { why = "bad frame header"; return false; }
+      fr.progressive = m == 0xC2;
       const int prec = s[0], nc = s[5];
       fr.h = s[1] << 8 | s[2];
       fr.w = s[3] << 8 | s[4];
@@ -263,8 +275,8 @@ bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& f
       if (nc != 1 || sl < 9) { why = std::to_string(nc) + "-component JPEG (one sample per pixel is read)"; return false; }
       fr.tq = s[8] & 3;
       fr.have_sof = true;
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      why = m == 0xC2 ? "progressive JPEG" : "JPEG process SOF" + std::to_string(m - 0xC0) + " (baseline / extended sequential Huffman are read)";
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      why = "JPEG process SOF" + std::to_string(m - 0xC0) + " (sequential and progressive Huffman are read)";
       return false;
     } else if (m == 0xDD) {  // DRI
       if (sl < 2) { why = "bad restart interval"; return false; }
@@ -272,16 +284,71 @@ bool jpeg_parse_segments(const uint8_t* p, size_t n, JpegTables& t, JpegFrame& f
     } else if (m == 0xDA) {  // SOS
       if (sl < 6 || s[0] != 1) { why = "bad scan header"; return false; }
       fr.td = s[2] >> 4; fr.ta = s[2] & 15;
+      fr.ss = s[3]; fr.se = s[4]; fr.ah = s[5] >> 4; fr.al = s[5] & 15;
       if (fr.td > 3 || fr.ta > 3) { why = "bad scan header"; return false; }
       data_off = i + 2 + len;
       return !tables_only;
     }
     i += 2 + len;
   }
-  why = tables_only ? "" : "no scan in the JPEG stream";
+  why = tables_only ? "" : (start ? "JPEG stream ends without EOI" : "no scan in the JPEG stream");
   data_off = n;
   return tables_only;
 }
+
+// the entropy-coded segment: MSB-first bits, FF00 = a data byte FF; at a marker zeros are fed and the caller looks at what it is
+struct JpegBits {
+  const uint8_t* src; size_t n, pos;
+  uint32_t acc = 0; int nbits = 0; bool hit_marker = false;
+  JpegBits(const uint8_t* s, size_t n_, size_t p) : src(s), n(n_), pos(p) {}
+  void fill() {
+    while (nbits <= 24) {
+      unsigned b = 0;
+      if (!hit_marker && pos < n) {
+        b = src[pos];
+        if (b == 0xFF) {
+          if (pos + 1 < n && src[pos + 1] == 0x00) pos += 2;
+          else { hit_marker = true; b = 0; }
+        } else {
+          ++pos;
+        }
+      }
+      acc |= (uint32_t)b << (24 - nbits);
+      nbits += 8;
+    }
+  }
+  int get(int c) {
+    if (c == 0) return 0;
+    if (nbits < c) fill();
+    const int v = (int)(acc >> (32 - c));
+    acc <<= c;
+    nbits -= c;
+    return v;
+  }
+  int decode(const JpegTables::Huff& h) {
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+      code = code << 1 | get(1);
+      if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return -1;
+  }
+  // RSTn: byte-align, skip the marker
+  bool restart() {
+    acc = 0; nbits = 0; hit_marker = false;
+    while (pos + 1 < n && !(src[pos] == 0xFF && src[pos + 1] >= 0xD0 && src[pos + 1] <= 0xD7)) ++pos;
+    if (pos + 1 >= n) return false;
+    pos += 2;
+    return true;
+  }
+  // the marker that ends the scan (anything but FF00 / RSTn / fill bytes): its offset, or n
+  size_t next_marker() const {
+    size_t q = pos;
+    while (q + 1 < n && !(src[q] == 0xFF && src[q + 1] != 0x00 && src[q + 1] != 0xFF && !(src[q + 1] >= 0xD0 && src[q + 1] <= 0xD7))) ++q;
+    return q + 1 < n ? q : n;
+  }
+};
+inline int jpeg_extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
 // libjpeg's jpeg_idct_islow on one dequantised block (natural order), output samples 0..255
 void jpeg_idct_islow(const int* in, uint8_t* out, size_t stride) {
@@ -342,8 +409,114 @@ void jpeg_idct_islow(const int* in, uint8_t* out, size_t stride) {
   }
 }
 
+// The scans of a PROGRESSIVE stream (SOF2, one component): every scan carries one spectral band (DC alone, or AC coefficients ss..se in zigzag
+// order) at one successive-approximation step (first pass: the bits down to `al`; refinement: bit `al`), tables may change between scans.
+// The coefficients of the whole frame are collected, then dequantised and transformed like a sequential frame -- what libjpeg
+// (jdphuff.c: decode_mcu_DC/AC_first/refine) leaves for a complete file; its block smoothing only acts on files whose scans are missing.
+bool unjpeg_progressive(const uint8_t* src, size_t n, JpegTables& t, JpegFrame fr, size_t off, size_t bw, size_t bh, std::vector<int>& coef,
+                        std::string& why) {
+  coef.assign(bw * bh * 64, 0);  // zigzag order inside a block
+  bool dc_seen = false;
+  for (int scans = 0; scans < 4096; ++scans) {
+    if (fr.ss > fr.se || fr.se > 63 || (fr.ss == 0 && fr.se != 0) || fr.al > 13 || (fr.ah != 0 && fr.ah != fr.al + 1)) { why = "bad progressive scan parameters"; return false; }
+    const bool dc = fr.ss == 0, refine = fr.ah != 0;
+    if (dc ? (!refine && !t.dc[fr.td].ok) : !t.ac[fr.ta].ok) { why = "missing Huffman table"; return false; }
+    if (dc && !refine) dc_seen = true;
+    JpegBits br(src, n, off);
+    const int p1 = 1 << fr.al, m1 = -(1 << fr.al);
+    int pred = 0, eobrun = 0;
+    size_t mcu = 0;
+    for (size_t b = 0; b < bw * bh; ++b, ++mcu) {
+      if (t.restart && mcu && mcu % (size_t)t.restart == 0) {
+        if (!br.restart()) { why = "missing restart marker"; return false; }
+        pred = 0; eobrun = 0;
+      }
+      int* c = coef.data() + b * 64;
+      if (dc) {
+        if (!refine) {
+          const int sz = br.decode(t.dc[fr.td]);
+          if (sz < 0 || sz > 11) { why = "corrupt JPEG data (DC)"; return false; }
+          pred += jpeg_extend(br.get(sz), sz);
+          if (pred < -32768 || pred > 32767) { why = "corrupt JPEG data (DC predictor out of range)"; return false; }
+          c[0] = pred * (1 << fr.al);
+        } else if (br.get(1)) {
+          c[0] |= p1;
+        }
+        continue;
+      }
+      const JpegTables::Huff& h = t.ac[fr.ta];
+      if (!refine) {  // first pass over a band of AC coefficients
+        if (eobrun > 0) { --eobrun; continue; }
+        for (int k = fr.ss; k <= fr.se; ++k) {
+          const int rs = br.decode(h);
+          if (rs < 0) { why = "corrupt JPEG data (AC)"; return false; }
+          const int r = rs >> 4, sz = rs & 15;
+          if (sz) {
+            k += r;
+            if (k > fr.se) { why = "corrupt JPEG data (run)"; return false; }
+            if (sz > 10) { why = "corrupt JPEG data (AC magnitude category above 10 at 8-bit precision)"; return false; }
+            c[k] = jpeg_extend(br.get(sz), sz) * (1 << fr.al);
+          } else if (r == 15) {
+            k += 15;
+          } else {  // end of band for this block and the next 2^r - 1 + (r bits)
+            eobrun = (1 << r) + (r ? br.get(r) : 0) - 1;
+            break;
+          }
+        }
+        continue;
+      }
+      // refinement of a band: one more bit for every coefficient that is already nonzero, new +-1 coefficients in between
+      auto correct = [&](int& v) {
+        if (br.get(1) && (v & p1) == 0) v += v >= 0 ? p1 : m1;
+      };
+      int k = fr.ss;
+      if (eobrun == 0) {
+        for (; k <= fr.se; ++k) {
+          const int rs = br.decode(h);
+          if (rs < 0) { why = "corrupt JPEG data (AC)"; return false; }
+          int r = rs >> 4, val = 0;
+          const int sz = rs & 15;
+          if (sz) {
+            if (sz != 1) { why = "corrupt JPEG data (refinement)"; return false; }
+            val = br.get(1) ? p1 : m1;
+          } else if (r != 15) {
+            eobrun = (1 << r) + (r ? br.get(r) : 0);
+            break;  // the rest of the block: the end-of-band logic below
+          }
+          // over already-nonzero coefficients (a correction bit each) and r still-zero ones
+          do {
+            if (c[k] != 0) correct(c[k]);
+            else if (--r < 0) break;
+            ++k;
+          } while (k <= fr.se);
+          if (val) {
+            if (k > fr.se) { why = "corrupt JPEG data (refinement run)"; return false; }
+            c[k] = val;
+          }
+        }
+      }
+      if (eobrun > 0) {
+        for (; k <= fr.se; ++k)
+          if (c[k] != 0) correct(c[k]);
+        --eobrun;
+      }
+    }
+    // what follows the scan: tables, the next scan, or EOI
+    const size_t mk = br.next_marker();
+    if (mk >= n) { why = "JPEG stream ends without EOI"; return false; }
+    fr.eoi = false;
+    if (!jpeg_parse_segments(src, n, t, fr, off, false, why, mk)) return false;
+    if (fr.eoi) {
+      if (!dc_seen) { why = "progressive JPEG without a DC scan"; return false; }
+      return true;
+    }
+  }
+  why = "too many scans";
+  return false;
+}
+
 // one strip / tile: `src` is its JPEG stream, `tables` the stream of the JPEGTables tag (may be empty); out = expect_w x expect_h
-// 8-bit samples, row-major.  false + why on anything that is not a one-component sequential Huffman stream of that size.
+// 8-bit samples, row-major.  false + why on anything that is not a one-component Huffman-coded DCT stream of that size.
 bool unjpeg(const uint8_t* src, size_t n, const std::vector<uint8_t>& tables, std::vector<uint8_t>& out, size_t expect_w, size_t expect_h,
             std::string& why) {
   JpegTables t;
@@ -357,82 +530,59 @@ bool unjpeg(const uint8_t* src, size_t n, const std::vector<uint8_t>& tables, st
   if (!jpeg_parse_segments(src, n, t, fr, off, false, why)) return false;
   if (!fr.have_sof || fr.w <= 0 || fr.h <= 0) { why = "no frame header"; return false; }
   if ((size_t)fr.w != expect_w || (size_t)fr.h > expect_h) { why = "JPEG frame size differs from the strip / tile"; return false; }
-  if (!t.have_q[fr.tq] || !t.dc[fr.td].ok || !t.ac[fr.ta].ok) { why = "missing quantisation / Huffman table"; return false; }
   const size_t bw = ((size_t)fr.w + 7) / 8, bh = ((size_t)fr.h + 7) / 8;
   std::vector<uint8_t> img(bw * 8 * bh * 8);
-  // entropy-coded segment: MSB-first bits, FF00 = a data byte FF, RSTn between restart intervals
-  size_t pos = off;
-  uint32_t acc = 0;
-  int nbits = 0;
-  bool hit_marker = false;
-  auto fill = [&]() {
-    while (nbits <= 24) {
-      unsigned b = 0;
-      if (!hit_marker && pos < n) {
-        b = src[pos];
-        if (b == 0xFF) {
-          if (pos + 1 < n && src[pos + 1] == 0x00) pos += 2;
-          else { hit_marker = true; b = 0; }   // a marker: feed zeros, the caller checks for RSTn / EOI
-        } else {
-          ++pos;
+  int blk[64];
+  if (fr.progressive) {
+    std::vector<int> coef;
+    if (!unjpeg_progressive(src, n, t, fr, off, bw, bh, coef, why)) return false;
+    if (!t.have_q[fr.tq]) { why = "missing quantisation table"; return false; }
+    for (size_t by = 0; by < bh; ++by)
+      for (size_t bx = 0; bx < bw; ++bx) {
+        const int* c = coef.data() + (by * bw + bx) * 64;
+        for (int k = 0; k < 64; ++k) {
+          // (an 8-bit frame's coefficients lie within +-2^13; a corrupt stream can shift a first-pass value up by 13 bits)
+          if (c[k] < -32768 || c[k] > 32767) { why = "corrupt JPEG data (coefficient out of range)"; return false; }
+          blk[kZigzag[k]] = c[k] * t.q[fr.tq][kZigzag[k]];
         }
+        jpeg_idct_islow(blk, img.data() + (by * 8) * (bw * 8) + bx * 8, bw * 8);
       }
-      acc |= (uint32_t)b << (24 - nbits);
-      nbits += 8;
-    }
-  };
-  auto getbits = [&](int c) -> int {
-    if (c == 0) return 0;
-    if (nbits < c) fill();
-    const int v = (int)(acc >> (32 - c));
-    acc <<= c;
-    nbits -= c;
-    return v;
-  };
-  auto decode = [&](const JpegTables::Huff& h) -> int {
-    int code = 0;
-    for (int l = 1; l <= 16; ++l) {
-      code = code << 1 | getbits(1);
-      if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
-    }
-    return -1;
-  };
-  auto extend = [](int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; };
-  int pred = 0, blk[64];
-  size_t mcu = 0;
-  for (size_t by = 0; by < bh; ++by)
-    for (size_t bx = 0; bx < bw; ++bx, ++mcu) {
-      if (t.restart && mcu && mcu % (size_t)t.restart == 0) {  // RSTn: byte-align, skip the marker, reset the predictor
-        acc = 0; nbits = 0; hit_marker = false;
-        while (pos + 1 < n && !(src[pos] == 0xFF && src[pos + 1] >= 0xD0 && src[pos + 1] <= 0xD7)) ++pos;
-        if (pos + 1 >= n) { why = "missing restart marker"; return false; }
-        pos += 2;
-        pred = 0;
-      }
-      for (int k = 0; k < 64; ++k) blk[k] = 0;
-      const int s = decode(t.dc[fr.td]);
-      if (s < 0 || s > 11) { why = "corrupt JPEG data (DC)"; return false; }
-      pred += extend(getbits(s), s);
-      // (an 8-bit sample's DC term lies within +-2^10 * 8; libjpeg range-limits, here a predictor that has run away is an error)
-      if (pred < -32768 || pred > 32767) { why = "corrupt JPEG data (DC predictor out of range)"; return false; }
-      blk[0] = pred * t.q[fr.tq][0];
-      for (int k = 1; k < 64;) {
-        const int rs = decode(t.ac[fr.ta]);
-        if (rs < 0) { why = "corrupt JPEG data (AC)"; return false; }
-        const int r = rs >> 4, sz = rs & 15;
-        if (sz == 0) {
-          if (r != 15) break;  // EOB
-          k += 16;
-          continue;
+  } else {
+    if (!t.have_q[fr.tq] || !t.dc[fr.td].ok || !t.ac[fr.ta].ok) { why = "missing quantisation / Huffman table"; return false; }
+    JpegBits br(src, n, off);
+    int pred = 0;
+    size_t mcu = 0;
+    for (size_t by = 0; by < bh; ++by)
+      for (size_t bx = 0; bx < bw; ++bx, ++mcu) {
+        if (t.restart && mcu && mcu % (size_t)t.restart == 0) {  // RSTn: byte-align, skip the marker, reset the predictor
+          if (!br.restart()) { why = "missing restart marker"; return false; }
+          pred = 0;
         }
-        k += r;
-        if (k > 63) { why = "corrupt JPEG data (run)"; return false; }
-        if (sz > 10) { why = "corrupt JPEG data (AC magnitude category above 10 at 8-bit precision)"; return false; }
-        blk[kZigzag[k]] = extend(getbits(sz), sz) * t.q[fr.tq][kZigzag[k]];
-        ++k;
+        for (int k = 0; k < 64; ++k) blk[k] = 0;
+        const int s = br.decode(t.dc[fr.td]);
+        if (s < 0 || s > 11) { why = "corrupt JPEG data (DC)"; return false; }
+        pred += jpeg_extend(br.get(s), s);
+        // (an 8-bit sample's DC term lies within +-2^10 * 8; libjpeg range-limits, here a predictor that has run away is an error)
+        if (pred < -32768 || pred > 32767) { why = "corrupt JPEG data (DC predictor out of range)"; return false; }
+        blk[0] = pred * t.q[fr.tq][0];
+        for (int k = 1; k < 64;) {
+          const int rs = br.decode(t.ac[fr.ta]);
+          if (rs < 0) { why = "corrupt JPEG data (AC)"; return false; }
+          const int r = rs >> 4, sz = rs & 15;
+          if (sz == 0) {
+            if (r != 15) break;  // EOB
+            k += 16;
+            continue;
+          }
+          k += r;
+          if (k > 63) { why = "corrupt JPEG data (run)"; return false; }
+          if (sz > 10) { why = "corrupt JPEG data (AC magnitude category above 10 at 8-bit precision)"; return false; }
+          blk[kZigzag[k]] = jpeg_extend(br.get(sz), sz) * t.q[fr.tq][kZigzag[k]];
+          ++k;
+        }
+        jpeg_idct_islow(blk, img.data() + (by * 8) * (bw * 8) + bx * 8, bw * 8);
       }
-      jpeg_idct_islow(blk, img.data() + (by * 8) * (bw * 8) + bx * 8, bw * 8);
-    }
+  }
   out.assign(expect_w * expect_h, 0);
   for (size_t y = 0; y < (size_t)fr.h && y < expect_h; ++y) memcpy(out.data() + y * expect_w, img.data() + y * bw * 8, expect_w);
   return true;
@@ -634,7 +784,7 @@ oi_status decode_page(const char* path, const File& f, const Ifd& pg, const Ifd&
   }
   const bool known = pg.comp == 1 || pg.comp == 5 || pg.comp == 8 || pg.comp == 32946 || pg.comp == 32773 || pg.comp == 7;
   if (!known) {
-    oi::set_error("'%s': TIFF compression %u is not supported (none, LZW, Deflate, PackBits and baseline JPEG are)", path, pg.comp);
+    oi::set_error("'%s': TIFF compression %u is not supported (none, LZW, Deflate, PackBits and JPEG are)", path, pg.comp);
     return OI_IO_ERROR;
   }
   if (pg.comp == 7 && (pg.bps != 8 || pg.fmt != 1)) {

@@ -300,25 +300,38 @@ def test_tiff_reader_jpeg_compressed_stacks(tmp_path, quality, rps):
     assert np.array_equal(oia.TiffReader(str(p)).threshold(128.5, z0=1, nz_local=2), (expect[1:] > 128.5).astype(np.uint8))
 
 
-def test_tiff_reader_jpeg_restart_intervals_and_refusals(tmp_path):
-    """A JPEG strip with restart markers (DRI; written by libjpeg through Pillow's JPEG writer, wrapped into a TIFF by hand: a
-    self-contained stream, no JPEGTables tag) decodes to libjpeg's own pixels; progressive streams and colour images are named."""
+def _wrap_jpeg_tiff(jpeg_bytes, w, h):
+    """classic little-endian TIFF, one strip that is a self-contained JPEG stream (no JPEGTables tag)"""
+    import struct
+    tags = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 8), (259, 3, 1, 7), (262, 3, 1, 1), (273, 4, 1, 8), (277, 3, 1, 1),
+            (278, 3, 1, h), (279, 4, 1, len(jpeg_bytes))]
+    ifd_off = 8 + len(jpeg_bytes) + (len(jpeg_bytes) & 1)
+    out = b"II" + struct.pack("<HI", 42, ifd_off) + jpeg_bytes + (b"\0" if len(jpeg_bytes) & 1 else b"")
+    out += struct.pack("<H", len(tags))
+    for tag, typ, cnt, val in tags:
+        out += struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+    return out + struct.pack("<I", 0)
+
+
+def test_tiff_reader_jpeg_restart_intervals_progressive_and_refusals(tmp_path):
+    """JPEG strips written by libjpeg through Pillow's JPEG writer and wrapped into a TIFF by hand (a self-contained stream, no JPEGTables
+    tag): with restart markers (DRI), and PROGRESSIVE (SOF2: spectral selection + successive approximation, several scans with their own
+    Huffman tables; round 5) -- each decodes to libjpeg's own pixels, bit for bit; libtiff (what the reference reads with) opens the
+    same files.  Colour images are refused like every multi-sample TIFF."""
     Image = _pil()
-    import io, struct
-    a = _jpeg_volume(9, (1, 64, 96))[0]
-
-    def wrap(jpeg_bytes, w, h):   # classic little-endian TIFF, one strip
-        tags = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 8), (259, 3, 1, 7), (262, 3, 1, 1), (273, 4, 1, 8), (277, 3, 1, 1),
-                (278, 3, 1, h), (279, 4, 1, len(jpeg_bytes))]
-        ifd_off = 8 + len(jpeg_bytes) + (len(jpeg_bytes) & 1)
-        out = b"II" + struct.pack("<HI", 42, ifd_off) + jpeg_bytes + (b"\0" if len(jpeg_bytes) & 1 else b"")
-        out += struct.pack("<H", len(tags))
-        for tag, typ, cnt, val in tags:
-            out += struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
-        return out + struct.pack("<I", 0)
-
-    for name, kw, ok in (("restart", dict(quality=85, restart_marker_blocks=5), True), ("plain", dict(quality=75), True),
-                         ("progressive", dict(quality=85, progressive=True), False)):
+    import io
+    cases = [("restart", (64, 96), dict(quality=85, restart_marker_blocks=5)), ("plain", (64, 96), dict(quality=75)),
+             ("progressive", (64, 96), dict(quality=85, progressive=True)),
+             ("progressive_ragged", (83, 131), dict(quality=60, progressive=True)),            # extents that are no multiples of 8
+             ("progressive_q100", (40, 57), dict(quality=100, progressive=True)),              # every coefficient survives: long refinement scans
+             ("progressive_flat", (33, 20), dict(quality=30, progressive=True)),               # long end-of-band runs
+             ("progressive_restart", (72, 104), dict(quality=90, progressive=True, restart_marker_blocks=7)),
+             ("progressive_optimised", (64, 96), dict(quality=80, progressive=True, optimize=True))]
+    decoded_progressive = 0
+    for name, shape, kw in cases:
+        a = _jpeg_volume(len(name), (1,) + shape)[0]
+        if name == "progressive_flat":
+            a = (a // 64 * 64).astype(np.uint8)
         buf = io.BytesIO()
         try:
             Image.fromarray(a).save(buf, format="JPEG", **kw)
@@ -327,20 +340,39 @@ def test_tiff_reader_jpeg_restart_intervals_and_refusals(tmp_path):
         data = buf.getvalue()
         if name == "restart" and b"\xff\xdd" not in data:
             pytest.skip("this Pillow does not write restart intervals")
+        if name.startswith("progressive"):
+            assert b"\xff\xc2" in data and data.count(b"\xff\xda") > 3       # SOF2 and several scans
+            if name == "progressive_restart" and b"\xff\xdd" not in data:
+                continue
         p = tmp_path / f"{name}.tif"
-        p.write_bytes(wrap(data, a.shape[1], a.shape[0]))
-        if ok:
-            expect = np.array(Image.open(io.BytesIO(data)))
-            for thr in (100.5, 128.5, 150.5):
-                assert np.array_equal(oia.TiffReader(str(p)).threshold(thr)[0], (expect > thr).astype(np.uint8)), (name, thr)
-        else:
-            with pytest.raises(oia.OpenImpalaError) as e:
-                oia.TiffReader(str(p)).threshold(1.0)
-            assert "progressive" in str(e.value)
+        p.write_bytes(_wrap_jpeg_tiff(data, a.shape[1], a.shape[0]))
+        expect = np.array(Image.open(io.BytesIO(data)))                          # libjpeg's decode of the stream
+        assert expect.shape == a.shape and np.abs(expect.astype(int) - a.astype(int)).max() < 120
+        try:                                                                     # and libtiff's decode of the wrapped file
+            with Image.open(p) as im:
+                via_libtiff = np.array(im)
+            assert np.array_equal(via_libtiff, expect), name
+        except (OSError, ValueError):
+            pass                                                                 # (a Pillow whose libtiff lacks JPEG: the stream's decode stands)
+        levels = np.unique(expect)
+        for thr in list(levels[:: max(1, len(levels) // 12)].astype(float) + 0.5) + [100.5, 128.5, 150.5]:
+            got = oia.TiffReader(str(p)).threshold(float(thr))[0]
+            assert np.array_equal(got, (expect > thr).astype(np.uint8)), (name, thr)
+        decoded_progressive += name.startswith("progressive")
+    assert decoded_progressive >= 4
     rgb = tmp_path / "rgb.tif"
+    a = _jpeg_volume(9, (1, 64, 96))[0]
     Image.fromarray(np.stack([a] * 3, axis=-1)).save(rgb, format="TIFF", compression="jpeg")
     with pytest.raises(oia.OpenImpalaError):   # three samples per pixel: refused like every multi-sample TIFF (TiffReader.cpp:167-173)
         oia.TiffReader(str(rgb)).threshold(1.0)
+    # a progressive stream cut short or with a scan removed is an error, not a picture
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="JPEG", quality=85, progressive=True)
+    data = buf.getvalue()
+    cut = tmp_path / "cut.tif"
+    cut.write_bytes(_wrap_jpeg_tiff(data[: len(data) * 2 // 3], a.shape[1], a.shape[0]))
+    with pytest.raises(oia.OpenImpalaError):
+        oia.TiffReader(str(cut)).threshold(1.0)
 
 
 def test_readers_load_a_z_slab_only(tmp_path):

@@ -120,6 +120,18 @@ def test_corrupted_and_crafted_files_under_sanitizers(drivers, tmp_path):
                 q = tmp_path / f"j{t}.tif"
                 q.write_bytes(bytes(corrupt(jsrc, t, rng)))
                 paths.append(str(q))
+            # progressive streams (round 5: spectral selection / successive approximation, end-of-band runs): a hand-wrapped strip, corrupted
+            import io
+            from test_abi_cpu import _wrap_jpeg_tiff
+            pb = io.BytesIO()
+            Image.fromarray(jv[0]).save(pb, format="JPEG", quality=85, progressive=True)
+            psrc = _wrap_jpeg_tiff(pb.getvalue(), jv.shape[2], jv.shape[1])
+            (tmp_path / "prog_src.tif").write_bytes(psrc)
+            paths.append(str(tmp_path / "prog_src.tif"))
+            for t in range(160):
+                q = tmp_path / f"p{t}.tif"
+                q.write_bytes(bytes(corrupt(psrc, t, rng)))
+                paths.append(str(q))
     except Exception:
         pass
     out = run([reader, "tiff", "-"] + paths)
