@@ -531,7 +531,7 @@ def main():
 
     # Everything below is reported beside the metric, never part of it.  A watchdog prints the line without the
     # unfinished parts if they overrun (a collective that never returns on some node must not cost the measurement).
-    extras = {"solve": None, "solve_mg": None, "variants": None, "homog": None, "cpu": None, "note": extras_note_early}
+    extras = {"solve": None, "solve_mg": None, "variants": None, "other_dirs": None, "homog": None, "cpu": None, "note": extras_note_early}
     emitted = threading.Lock()
 
     def emit():
@@ -553,7 +553,7 @@ def main():
             "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in ktimes.items()},
             "steps_effective": steps_done, "relres_after_timed_region": relres,
             "time_to_1e-6": extras["solve"], "time_to_1e-6_multigrid_pcg": extras["solve_mg"],
-            "variants": extras["variants"], "homogenization": extras["homog"],
+            "variants": extras["variants"], "directions_y_z": extras.get("other_dirs"), "homogenization": extras["homog"],
             "setup_s": {"generate": t_gen, "create_total": t_create, "mask": st.t_mask_s,
                         "flood_sweeps": st.flood_sweeps, "upload_pack": st.t_upload_s, "codes_vectors_placement": st.t_setup_s,
                         "placement_alloc_s": placement["alloc_s"], "placement_s": placement["search_s"]},
@@ -743,6 +743,37 @@ def main():
             "bytes_per_voxel_iter": alg_bytes_iter - (10.0 if args.kernel == "fused1" else 8.0),
             "kernels_ms_per_launch": {k: v[0] / max(1, v[1]) for k, v in vk.items()}}}
 
+    # ---- BASELINE config 3 names "all three directions": the same metric and the default solver's time to 1e-6 along Y and Z ----
+    other_dirs = None
+    if not args.no_variants and not args.no_solve and world == 1 and comm is None and args.kernel == "fused1" and args.direction == "X":
+        if t is not None:
+            t.destroy()
+            t = None
+        other_dirs = {}
+        bufd, _ = make_structure(oia, args, shape, z0, nzl)
+        for dname, dval in (("Y", oia.Direction.Y), ("Z", oia.Direction.Z)):
+            td = oia.TortuosityMI355(bufd, 1, dval, 0.0, 1.0, shape=shape, **kw)
+            td.cg_begin(); td.cg_iterate(args.warmup); td.sync(); td.reset_kernel_times()
+            d0 = time.perf_counter()
+            td.cg_iterate(args.steps); td.sync()
+            ddt = time.perf_counter() - d0
+            dk = td.kernel_times()
+            td.cg_finish()
+            live_d = td.live_fraction(oia.line_voxels())
+            td.destroy()
+            ms_d = dk["cg1"][0] / max(1, dk["cg1"][1])
+            ab_d = (1.0 + (BYTES_PER_VOXEL["cg1"] - 1.0) * live_d) * nvox
+            tmd = oia.TortuosityMI355(bufd, 1, dval, 0.0, 1.0, shape=shape, eps=1e-6, precond=oia.PRECOND_MG, maxiter=1000, device=local_rank)
+            m0 = time.perf_counter()
+            tmd.cg_begin(); ld = tmd.cg_run(1000); tmd.cg_finish()
+            mdt = time.perf_counter() - m0
+            mits, mrel, mdone = tmd.cg_state()
+            tmd.destroy()
+            other_dirs[dname] = {"value": nvox * args.steps / ddt / 1e6, "unit": "Mvoxel-iters/s", "ms_per_step": ddt / args.steps * 1e3,
+                                 "cg1_ms_per_launch": ms_d, "live_line_fraction": live_d, "roofline_frac": ab_d / ms_d / 1e6 / HBM_PEAK_GBS,
+                                 "multigrid_pcg_to_1e-6": {"converged": bool(mdone), "iterations": mits, "launches": ld, "relres": mrel, "seconds": mdt}}
+        bufd.free()
+
     # ---- the reference's default calculation_method on the same structure: three periodic cell problems + D_eff ----
     homog = None
     if not args.no_variants and world == 1 and comm is None and args.kernel not in ("unfused", "lean"):
@@ -779,6 +810,7 @@ def main():
                  "D_diag": [float(D[i, i]) for i in range(3)]}
 
     extras["variants"] = variants
+    extras["other_dirs"] = other_dirs
     extras["homog"] = homog
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         extras["cpu"] = cpu_baseline(oia, args, cpu_full)

@@ -39,6 +39,8 @@ def test_bench_line_single_gpu():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
     assert d["time_to_1e-6"]["converged"] and d["time_to_1e-6_multigrid_pcg"]["converged"]
     assert all(d["homogenization"]["converged"])
+    yz = d["directions_y_z"]   # BASELINE config 3: "all three directions"
+    assert set(yz) == {"Y", "Z"} and all(v["value"] > 0 and v["multigrid_pcg_to_1e-6"]["converged"] for v in yz.values())
     # the default solver path carries its own roofline record (round 5): the three fine kernels of an iteration + the coarse levels
     m = d["time_to_1e-6_multigrid_pcg"]
     assert m["launches"] in (m["iterations"], m["iterations"] + 1, m["iterations"] + 2) and m["create_total_s"] > 0
