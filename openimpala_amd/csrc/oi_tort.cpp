@@ -1541,8 +1541,9 @@ extern "C" oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_
   bool stop = rc == OI_OK && h->h_ctrl->done;
   if (h->mg) {
     const double tol2 = (h->opts.eps * h->bnorm) * (h->opts.eps * h->bnorm);
-    int k_prev = -1, next = batch;
-    double rr_prev = 0.0;
+    int next = batch;
+    constexpr int NH = 8;  // the last residuals seen: (iteration, log ||r||^2)
+    int hk[NH]; double hl[NH]; int nh = 0;
     while (rc == OI_OK && !stop && h->iters_issued < limit && budget_left()) {
       int n = std::max(1, std::min(next, batch));
       if (max_launches > 0) n = std::min(n, max_launches - (h->iters_issued - first_issued));
@@ -1557,15 +1558,32 @@ extern "C" oi_status oi_tort_cg_run(oi_tort* h, int max_launches, int* launches_
           hipStreamSynchronize(h->stream) != hipSuccess) { rc = OI_HIP_ERROR; break; }
       const double rr = h->h_scal[0];
       next = batch;
-      if (k_prev >= 0 && K > k_prev && rr > 0.0 && rr < rr_prev && tol2 > 0.0 && rr > tol2) {
-        const double per_iter = std::log(rr / rr_prev) / (double)(K - k_prev);  // < 0
-        const double need = std::log(tol2 / rr) / per_iter;                     // iterations until ||r||^2 <= tol2 at that rate
-        // (`need` more launches form -- and test -- the residual of iteration K + need in every variant)
-        // (CG's contraction is not uniform: within a batch and a half of the end the launches go out one by one -- a poll costs
-        // ~0.1 ms, a launch issued after convergence a whole coarse cycle)
-        next = need > (double)batch + 2.0 ? batch : 1;
+      if (rr > 0.0 && tol2 > 0.0 && rr > tol2) {
+        const double lr = std::log(rr);
+        // two estimates of the iterations still needed: from the contraction of the last step and from that of the last four to five
+        // iterations.  CG's contraction is not uniform here (0.65 to 0.9 per iteration, slowing down as the solve goes on:
+        // profiles/r05/mg_residual_history.txt): the window runs ahead of the truth while the contraction decays, one slow step runs behind
+        // it (a step of 0.92 after five of 0.75 once sent a whole batch out one iteration before the end: 24 launches for 21 iterations
+        // along Y).  A poll costs ~0.2 ms of idle device, a launch issued after convergence ~0.5 ms (its hundred kernels return at their
+        // first instruction): one by one as soon as EITHER estimate says the end is two iterations away or BOTH say it is within a batch
+        // and a half.  (1024^3 spheres: X 23 launches for 22 iterations, Y 22 for 21, Z 24 for 23; 0.310 / 0.299 / 0.322 s.)
+        int ref = -1, last = -1;
+        for (int q = 0; q < nh; ++q) {
+          if (K - hk[q] >= 1 && K - hk[q] <= 5 && (ref < 0 || hk[q] < hk[ref])) ref = q;
+          if (K - hk[q] >= 1 && (last < 0 || hk[q] > hk[last])) last = q;
+        }
+        auto need_from = [&](int q) {
+          if (q < 0 || !(hl[q] > lr)) return 1e30;  // (no contraction seen: no estimate)
+          return (std::log(tol2) - lr) / ((lr - hl[q]) / (double)(K - hk[q]));
+        };
+        const double need_w = need_from(ref), need_1 = need_from(last);
+        if (need_w < 1e29 || need_1 < 1e29) {
+          const double lo = std::min(need_w, need_1), hi = std::max(need_w < 1e29 ? need_w : need_1, need_1 < 1e29 ? need_1 : need_w);
+          next = (lo <= 2.0 || hi <= (double)batch + 2.0) ? 1 : batch;
+        }
+        if (nh < NH) { hk[nh] = K; hl[nh] = lr; ++nh; }
+        else { for (int q = 1; q < NH; ++q) { hk[q - 1] = hk[q]; hl[q - 1] = hl[q]; } hk[NH - 1] = K; hl[NH - 1] = lr; }
       }
-      k_prev = K; rr_prev = rr;
       if (h->opts.verbose > 1) fprintf(stderr, "[openimpala_amd] %d launches issued, ||r||^2 = %.3e, next batch %d\n", h->iters_issued, rr, std::min(next, batch));
     }
   } else {
